@@ -1,0 +1,82 @@
+"""ctypes loader for libgranne_hip.so (the C ABI declared in include/granne_hip.h).
+
+There is no fallback: if the library is missing or the GPU is absent, calls raise."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+F32, I8 = 0, 1
+UNUSED = 0xFFFFFFFF
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OVERFLOW, ERR_IO = -1, -2, -3, -4, -5
+
+OPT_VISITED_SLOTS, OPT_FORCE_SLOW, OPT_SLOW_SLOTS, OPT_SLOW_BLOCKS = 1, 2, 3, 4
+
+
+class GranneHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("granne_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+
+# name -> (restype, argtypes): every symbol include/granne_hip.h declares
+SIGNATURES = {
+    "granne_hip_last_error": (C.c_char_p, []),
+    "granne_hip_abi_version": (i32, []),
+    "granne_hip_device_count": (i32, [C.POINTER(i32)]),
+    "granne_hip_index_create": (i32, [C.POINTER(vp), vp, u64, u32, i32, u32, vp, vp, vp, i32]),
+    "granne_hip_index_create_csr": (i32, [C.POINTER(vp), vp, u64, u32, i32, u32, vp, vp, vp, i32]),
+    "granne_hip_index_create_device": (i32, [C.POINTER(vp), vp, u64, u32, i32, u32, vp, vp, vp, i32, vp]),
+    "granne_hip_index_destroy": (None, [vp]),
+    "granne_hip_index_len": (u64, [vp]),
+    "granne_hip_index_num_layers": (u32, [vp]),
+    "granne_hip_index_layer_len": (u64, [vp, u32]),
+    "granne_hip_index_dim": (u32, [vp]),
+    "granne_hip_index_dtype": (i32, [vp]),
+    "granne_hip_index_device": (i32, [vp]),
+    "granne_hip_index_hbm_bytes": (u64, [vp]),
+    "granne_hip_index_get_neighbors": (i32, [vp, u64, u32, vp, u32, C.POINTER(u32)]),
+    "granne_hip_index_get_element": (i32, [vp, u64, vp]),
+    "granne_hip_search_batch": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
+    "granne_hip_search_batch_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]),
+    "granne_hip_search": (i32, [vp, vp, u32, u32, vp, vp, C.POINTER(u32)]),
+    "granne_hip_normalize_f32_device": (i32, [vp, u64, u32, i32, vp]),
+    "granne_hip_quantize_f32_device": (i32, [vp, vp, u64, u32, i32, vp]),
+    "granne_hip_dist_pairs_device": (i32, [vp, vp, vp, vp, u64, vp, vp]),
+    "granne_hip_normalize_f32": (i32, [vp, u64, u32, i32]),
+    "granne_hip_quantize_f32": (i32, [vp, vp, u64, u32, i32]),
+    "granne_hip_dist_pairs": (i32, [vp, vp, u32, vp, vp, u64, vp]),
+    "granne_hip_synth_rows_device": (i32, [vp, u64, u64, u64, u32, i32, vp]),
+    "granne_hip_index_set_option": (i32, [vp, i32, u64]),
+    "granne_hip_index_get_option": (i32, [vp, i32, C.POINTER(u64)]),
+    "granne_hip_index_last_slow_count": (u64, [vp]),
+}
+
+
+def lib():
+    """The loaded library. Raises if it has not been built (python -m granne_amd.build)."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise GranneHipError(ERR_NO_DEVICE, "libgranne_hip.so is not built: run `python -m granne_amd.build` "
+                                 "(no CPU fallback exists)")
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise GranneHipError(rc, lib().granne_hip_last_error().decode("utf-8", "replace"))
+    return rc

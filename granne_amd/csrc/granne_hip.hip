@@ -1,0 +1,761 @@
+// granne_hip.hip -- host runtime + C ABI of libgranne_hip.so (see include/granne_hip.h).
+// Compiled by hipcc for gfx950 only; there is no CPU code path for search in this library.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/granne_hip.h"
+#include "search_kernel.h"
+#include "slow_kernel.h"
+#include "util_kernels.h"
+
+using namespace granne_hip;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? GRANNE_HIP_ERR_NO_DEVICE \
+                                                                            : GRANNE_HIP_ERR_HIP,  \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+extern "C" const char* granne_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" int granne_hip_abi_version(void) { return GRANNE_HIP_ABI_VERSION; }
+extern "C" int granne_hip_device_count(int* out_count) {
+    if (!out_count) return fail(GRANNE_HIP_ERR_INVALID, "out_count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_count = 0;
+        return fail(GRANNE_HIP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *out_count = n;
+    return GRANNE_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// index
+// ------------------------------------------------------------------------------------------------
+struct LayerHost {
+    uint64_t len = 0;
+    uint32_t width = 0;     // caller's row width
+    uint32_t dev_width = 0; // multiple of 32
+    uint32_t* d_adj = nullptr;
+};
+
+struct granne_hip_index {
+    int device = 0;
+    uint32_t dim = 0;
+    int dtype = 0;
+    uint64_t n_elements = 0;
+    uint32_t row_bytes = 0; // device stride
+    uint8_t* d_elements = nullptr;
+    std::vector<LayerHost> layers;
+    LayerDev* d_layers = nullptr;
+    uint64_t hbm_bytes = 0;
+    uint32_t max_dev_width = 32;
+    // options
+    uint64_t opt_visited_slots = 0;
+    uint64_t opt_force_slow = 0;
+    uint64_t opt_slow_slots = 1u << 18;
+    uint64_t opt_slow_blocks = 16;
+    std::atomic<uint64_t> last_slow_count{0};
+};
+
+static inline uint32_t elem_size(int dtype) { return dtype == GRANNE_HIP_F32 ? 4u : 1u; }
+
+static uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// device row stride: f32 rows are padded to 16 bytes; i8 rows to a power of two (<= 1024) or a
+// multiple of 1024 so that a row is split over a power-of-two number of lanes and never
+// straddles more 128-byte lines than it has to (SURVEY 7 "unaligned rows").
+static uint32_t device_row_bytes(uint32_t dim, int dtype) {
+    if (dtype == GRANNE_HIP_F32) return (dim * 4u + 15u) & ~15u;
+    if (dim <= 1024) return next_pow2(dim < 16 ? 16 : dim);
+    return (dim + 1023u) & ~1023u;
+}
+
+static int grid_for(uint64_t work, int block) {
+    uint64_t g = (work + block - 1) / block;
+    if (g > 256ull * 32) g = 256ull * 32;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static int validate_common(granne_hip_index** out, uint64_t n_elements, uint32_t dim, int dtype, uint32_t n_layers,
+                           const uint64_t* layer_len) {
+    if (!out) return fail(GRANNE_HIP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (dtype != GRANNE_HIP_F32 && dtype != GRANNE_HIP_I8) return fail(GRANNE_HIP_ERR_INVALID, "unknown dtype %d", dtype);
+    if (dim == 0) return fail(GRANNE_HIP_ERR_INVALID, "dim must be > 0");
+    if (n_elements >= 0xFFFFFFFFull)
+        return fail(GRANNE_HIP_ERR_INVALID, "too many elements (reference limit, src/index/mod.rs:420)");
+    if (n_layers && !layer_len) return fail(GRANNE_HIP_ERR_INVALID, "layer_len is null");
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        if (layer_len[l] > n_elements)
+            return fail(GRANNE_HIP_ERR_INVALID, "layer %u has %llu nodes but only %llu elements", l,
+                        (unsigned long long)layer_len[l], (unsigned long long)n_elements);
+        if (l > 0 && layer_len[l] < layer_len[l - 1])
+            return fail(GRANNE_HIP_ERR_INVALID, "layers must be prefix-nested (layer %u shrinks)", l);
+        if (layer_len[l] == 0) return fail(GRANNE_HIP_ERR_INVALID, "layer %u is empty", l);
+    }
+    return GRANNE_HIP_OK;
+}
+
+static void destroy_index(granne_hip_index* ix) {
+    if (!ix) return;
+    DeviceGuard g(ix->device);
+    if (ix->d_elements) (void)hipFree(ix->d_elements);
+    for (auto& L : ix->layers)
+        if (L.d_adj) (void)hipFree(L.d_adj);
+    if (ix->d_layers) (void)hipFree(ix->d_layers);
+    delete ix;
+}
+
+// src is a device pointer to dense rows; fills ix->d_elements
+static int upload_elements_from_device(granne_hip_index* ix, const void* d_src, hipStream_t s) {
+    uint64_t n = ix->n_elements;
+    uint32_t dense = ix->dim * elem_size(ix->dtype);
+    size_t bytes = (size_t)n * ix->row_bytes;
+    HIP_TRY(hipMalloc((void**)&ix->d_elements, bytes ? bytes : 16));
+    ix->hbm_bytes += bytes;
+    if (n == 0) return GRANNE_HIP_OK;
+    if (dense == ix->row_bytes) {
+        HIP_TRY(hipMemcpyAsync(ix->d_elements, d_src, bytes, hipMemcpyDeviceToDevice, s));
+    } else {
+        uint64_t units = n * (ix->row_bytes / 16);
+        hipLaunchKernelGGL(relayout_rows_kernel, dim3(grid_for(units, 256)), dim3(256), 0, s, (const uint8_t*)d_src,
+                           ix->d_elements, n, dense, ix->row_bytes);
+        HIP_TRY(hipGetLastError());
+    }
+    return GRANNE_HIP_OK;
+}
+
+static int finish_layers(granne_hip_index* ix, hipStream_t s) {
+    std::vector<LayerDev> h(ix->layers.size());
+    ix->max_dev_width = 32;
+    for (size_t l = 0; l < ix->layers.size(); ++l) {
+        h[l].adj = ix->layers[l].d_adj;
+        h[l].len = ix->layers[l].len;
+        h[l].width = ix->layers[l].dev_width;
+        h[l].pad_ = 0;
+        if (ix->layers[l].dev_width > ix->max_dev_width) ix->max_dev_width = ix->layers[l].dev_width;
+    }
+    size_t bytes = sizeof(LayerDev) * (h.size() ? h.size() : 1);
+    HIP_TRY(hipMalloc((void**)&ix->d_layers, bytes));
+    if (!h.empty()) HIP_TRY(hipMemcpyAsync(ix->d_layers, h.data(), sizeof(LayerDev) * h.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return GRANNE_HIP_OK;
+}
+
+static int add_layer_from_device_rows(granne_hip_index* ix, uint64_t len, uint32_t width, const uint32_t* d_rows,
+                                      hipStream_t s) {
+    LayerHost L;
+    L.len = len;
+    L.width = width;
+    L.dev_width = (width + 31u) & ~31u;
+    if (L.dev_width == 0) L.dev_width = 32;
+    size_t bytes = (size_t)len * L.dev_width * 4;
+    HIP_TRY(hipMalloc((void**)&L.d_adj, bytes ? bytes : 16));
+    ix->hbm_bytes += bytes;
+    ix->layers.push_back(L);
+    if (width == 0) {
+        HIP_TRY(hipMemsetAsync(L.d_adj, 0xFF, bytes, s));
+    } else {
+        hipLaunchKernelGGL(relayout_adj_kernel, dim3(grid_for(len * L.dev_width, 256)), dim3(256), 0, s, d_rows,
+                           L.d_adj, len, width, L.dev_width);
+        HIP_TRY(hipGetLastError());
+    }
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_index_create_device(granne_hip_index** out, const void* d_elements, uint64_t n_elements,
+                                              uint32_t dim, int dtype, uint32_t n_layers, const uint64_t* layer_len,
+                                              const uint32_t* const* d_layer_rows, const uint32_t* layer_width,
+                                              int device_id, void* stream) {
+    int rc = validate_common(out, n_elements, dim, dtype, n_layers, layer_len);
+    if (rc) return rc;
+    if (n_elements && !d_elements) return fail(GRANNE_HIP_ERR_INVALID, "elements is null");
+    if (n_layers && (!d_layer_rows || !layer_width)) return fail(GRANNE_HIP_ERR_INVALID, "layer arrays are null");
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    hipStream_t s = (hipStream_t)stream;
+    granne_hip_index* ix = new granne_hip_index();
+    ix->device = device_id;
+    ix->dim = dim;
+    ix->dtype = dtype;
+    ix->n_elements = n_elements;
+    ix->row_bytes = device_row_bytes(dim, dtype);
+    rc = upload_elements_from_device(ix, d_elements, s);
+    for (uint32_t l = 0; rc == 0 && l < n_layers; ++l)
+        rc = add_layer_from_device_rows(ix, layer_len[l], layer_width[l], d_layer_rows[l], s);
+    if (rc == 0) rc = finish_layers(ix, s);
+    if (rc) {
+        destroy_index(ix);
+        return rc;
+    }
+    *out = ix;
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_index_create(granne_hip_index** out, const void* elements, uint64_t n_elements, uint32_t dim,
+                                       int dtype, uint32_t n_layers, const uint64_t* layer_len,
+                                       const uint32_t* const* layer_rows, const uint32_t* layer_width, int device_id) {
+    int rc = validate_common(out, n_elements, dim, dtype, n_layers, layer_len);
+    if (rc) return rc;
+    if (n_elements && !elements) return fail(GRANNE_HIP_ERR_INVALID, "elements is null");
+    if (n_layers && (!layer_rows || !layer_width)) return fail(GRANNE_HIP_ERR_INVALID, "layer arrays are null");
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+
+    // stage the host buffers on the device, then share the device path
+    void* d_el = nullptr;
+    size_t el_bytes = (size_t)n_elements * dim * elem_size(dtype);
+    std::vector<uint32_t*> d_rows(n_layers, nullptr);
+    auto cleanup = [&]() {
+        if (d_el) (void)hipFree(d_el);
+        for (auto p : d_rows)
+            if (p) (void)hipFree(p);
+    };
+    hipError_t e = hipMalloc(&d_el, el_bytes ? el_bytes : 16);
+    if (e == hipSuccess && el_bytes) e = hipMemcpy(d_el, elements, el_bytes, hipMemcpyHostToDevice);
+    for (uint32_t l = 0; e == hipSuccess && l < n_layers; ++l) {
+        size_t b = (size_t)layer_len[l] * layer_width[l] * 4;
+        e = hipMalloc((void**)&d_rows[l], b ? b : 16);
+        if (e == hipSuccess && b) e = hipMemcpy(d_rows[l], layer_rows[l], b, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(e == hipErrorNoDevice ? GRANNE_HIP_ERR_NO_DEVICE : GRANNE_HIP_ERR_HIP, "staging upload failed: %s",
+                    hipGetErrorString(e));
+    }
+    rc = granne_hip_index_create_device(out, d_el, n_elements, dim, dtype, n_layers, layer_len,
+                                        (const uint32_t* const*)d_rows.data(), layer_width, device_id, nullptr);
+    cleanup();
+    return rc;
+}
+
+extern "C" int granne_hip_index_create_csr(granne_hip_index** out, const void* elements, uint64_t n_elements,
+                                           uint32_t dim, int dtype, uint32_t n_layers, const uint64_t* layer_len,
+                                           const uint64_t* const* layer_offsets, const uint32_t* const* layer_ids,
+                                           int device_id) {
+    int rc = validate_common(out, n_elements, dim, dtype, n_layers, layer_len);
+    if (rc) return rc;
+    if (n_elements && !elements) return fail(GRANNE_HIP_ERR_INVALID, "elements is null");
+    if (n_layers && (!layer_offsets || !layer_ids)) return fail(GRANNE_HIP_ERR_INVALID, "layer arrays are null");
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+
+    granne_hip_index* ix = new granne_hip_index();
+    ix->device = device_id;
+    ix->dim = dim;
+    ix->dtype = dtype;
+    ix->n_elements = n_elements;
+    ix->row_bytes = device_row_bytes(dim, dtype);
+    void* d_el = nullptr;
+    size_t el_bytes = (size_t)n_elements * dim * elem_size(dtype);
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc(&d_el, el_bytes ? el_bytes : 16));
+        if (el_bytes) HIP_TRY(hipMemcpy(d_el, elements, el_bytes, hipMemcpyHostToDevice));
+        int r = upload_elements_from_device(ix, d_el, nullptr);
+        if (r) return r;
+        for (uint32_t l = 0; l < n_layers; ++l) {
+            uint64_t len = layer_len[l];
+            const uint64_t* off = layer_offsets[l];
+            uint32_t maxdeg = 0;
+            for (uint64_t i = 0; i < len; ++i) {
+                if (off[i + 1] < off[i]) return fail(GRANNE_HIP_ERR_INVALID, "layer %u: offsets not monotone", l);
+                uint64_t d = off[i + 1] - off[i];
+                if (d > 0xFFFF) return fail(GRANNE_HIP_ERR_INVALID, "layer %u: degree too large", l);
+                if (d > maxdeg) maxdeg = (uint32_t)d;
+            }
+            LayerHost L;
+            L.len = len;
+            L.width = maxdeg;
+            L.dev_width = ((maxdeg ? maxdeg : 1) + 31u) & ~31u;
+            size_t bytes = (size_t)len * L.dev_width * 4;
+            HIP_TRY(hipMalloc((void**)&L.d_adj, bytes ? bytes : 16));
+            ix->hbm_bytes += bytes;
+            ix->layers.push_back(L);
+            uint64_t* d_off = nullptr;
+            uint32_t* d_ids = nullptr;
+            size_t nids = (size_t)off[len];
+            HIP_TRY(hipMalloc((void**)&d_off, (len + 1) * 8));
+            HIP_TRY(hipMalloc((void**)&d_ids, nids ? nids * 4 : 16));
+            hipError_t e1 = hipMemcpy(d_off, off, (len + 1) * 8, hipMemcpyHostToDevice);
+            hipError_t e2 = nids ? hipMemcpy(d_ids, layer_ids[l], nids * 4, hipMemcpyHostToDevice) : hipSuccess;
+            if (e1 == hipSuccess && e2 == hipSuccess) {
+                hipLaunchKernelGGL(csr_to_adj_kernel, dim3(grid_for(len * L.dev_width, 256)), dim3(256), 0, nullptr,
+                                   d_off, d_ids, L.d_adj, len, L.dev_width);
+                e1 = hipDeviceSynchronize();
+            }
+            (void)hipFree(d_off);
+            (void)hipFree(d_ids);
+            if (e1 != hipSuccess || e2 != hipSuccess) return fail(GRANNE_HIP_ERR_HIP, "CSR upload failed");
+        }
+        return finish_layers(ix, nullptr);
+    };
+    rc = body();
+    if (d_el) (void)hipFree(d_el);
+    if (rc) {
+        destroy_index(ix);
+        return rc;
+    }
+    *out = ix;
+    return GRANNE_HIP_OK;
+}
+
+extern "C" void granne_hip_index_destroy(granne_hip_index* index) { destroy_index(index); }
+
+extern "C" uint64_t granne_hip_index_len(const granne_hip_index* ix) {
+    return (ix && !ix->layers.empty()) ? ix->layers.back().len : 0; // src/index/mod.rs:76-83
+}
+extern "C" uint32_t granne_hip_index_num_layers(const granne_hip_index* ix) { return ix ? (uint32_t)ix->layers.size() : 0; }
+extern "C" uint64_t granne_hip_index_layer_len(const granne_hip_index* ix, uint32_t layer) {
+    return (ix && layer < ix->layers.size()) ? ix->layers[layer].len : 0;
+}
+extern "C" uint32_t granne_hip_index_dim(const granne_hip_index* ix) { return ix ? ix->dim : 0; }
+extern "C" int granne_hip_index_dtype(const granne_hip_index* ix) { return ix ? ix->dtype : -1; }
+extern "C" int granne_hip_index_device(const granne_hip_index* ix) { return ix ? ix->device : -1; }
+extern "C" uint64_t granne_hip_index_hbm_bytes(const granne_hip_index* ix) { return ix ? ix->hbm_bytes : 0; }
+
+extern "C" int granne_hip_index_get_neighbors(const granne_hip_index* ix, uint64_t node, uint32_t layer,
+                                              uint32_t* out_ids, uint32_t cap, uint32_t* out_count) {
+    if (!ix || !out_count) return fail(GRANNE_HIP_ERR_INVALID, "null argument");
+    if (layer >= ix->layers.size()) return fail(GRANNE_HIP_ERR_INVALID, "layer %u out of range", layer);
+    const LayerHost& L = ix->layers[layer];
+    if (node >= L.len) return fail(GRANNE_HIP_ERR_INVALID, "node out of range");
+    DeviceGuard g(ix->device);
+    std::vector<uint32_t> row(L.dev_width);
+    HIP_TRY(hipMemcpy(row.data(), L.d_adj + node * L.dev_width, (size_t)L.dev_width * 4, hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    while (n < L.dev_width && row[n] != GRANNE_HIP_UNUSED) ++n;
+    *out_count = n;
+    for (uint32_t i = 0; i < n && i < cap && out_ids; ++i) out_ids[i] = row[i];
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_index_get_element(const granne_hip_index* ix, uint64_t idx, void* out) {
+    if (!ix || !out) return fail(GRANNE_HIP_ERR_INVALID, "null argument");
+    if (idx >= ix->n_elements) return fail(GRANNE_HIP_ERR_INVALID, "element index out of range");
+    DeviceGuard g(ix->device);
+    HIP_TRY(hipMemcpy(out, ix->d_elements + idx * ix->row_bytes, (size_t)ix->dim * elem_size(ix->dtype),
+                      hipMemcpyDeviceToHost));
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uint64_t value) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    switch (option) {
+    case GRANNE_HIP_OPT_VISITED_SLOTS:
+        if (value != 0 && (value < 256 || value > 32768 || (value & (value - 1))))
+            return fail(GRANNE_HIP_ERR_INVALID, "visited slots must be 0 or a power of two in [256, 32768]");
+        ix->opt_visited_slots = value;
+        return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_FORCE_SLOW:
+        ix->opt_force_slow = value ? 1 : 0;
+        return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_SLOW_SLOTS:
+        if (value < 256 || value > (1ull << 30) || (value & (value - 1)))
+            return fail(GRANNE_HIP_ERR_INVALID, "slow slots must be a power of two in [256, 2^30]");
+        ix->opt_slow_slots = value;
+        return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_SLOW_BLOCKS:
+        if (value < 1 || value > 1024) return fail(GRANNE_HIP_ERR_INVALID, "slow blocks must be in [1, 1024]");
+        ix->opt_slow_blocks = value;
+        return GRANNE_HIP_OK;
+    default:
+        return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+extern "C" int granne_hip_index_get_option(const granne_hip_index* ix, int option, uint64_t* value) {
+    if (!ix || !value) return fail(GRANNE_HIP_ERR_INVALID, "null argument");
+    switch (option) {
+    case GRANNE_HIP_OPT_VISITED_SLOTS: *value = ix->opt_visited_slots; return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_FORCE_SLOW: *value = ix->opt_force_slow; return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_SLOW_SLOTS: *value = ix->opt_slow_slots; return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_SLOW_BLOCKS: *value = ix->opt_slow_blocks; return GRANNE_HIP_OK;
+    default: return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+extern "C" uint64_t granne_hip_index_last_slow_count(const granne_hip_index* ix) {
+    return ix ? ix->last_slow_count.load() : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------------
+typedef void (*search_fn)(const SearchParams);
+
+template <int DT, int DIM>
+static search_fn pick_s(uint32_t ef) {
+    if (ef <= 64) return search_kernel<DT, DIM, 1>;
+    if (ef <= 128) return search_kernel<DT, DIM, 2>;
+    return search_kernel<DT, DIM, 4>;
+}
+
+static search_fn pick_kernel(int dtype, uint32_t dim, uint32_t ef) {
+    if (dtype == GRANNE_HIP_I8) return pick_s<DT_I8, 0>(ef);
+    switch (dim) {
+    case 100: return pick_s<DT_F32, 100>(ef);
+    case 200: return pick_s<DT_F32, 200>(ef);
+    default: return pick_s<DT_F32, 0>(ef);
+    }
+}
+
+struct LaunchPlan {
+    uint32_t visited_slots, upper_slots, maxc, lrow_bytes, lds_bytes;
+};
+
+// LDS budget: four walkers per CU (one per SIMD) when it fits: 160 KiB / 4
+static LaunchPlan plan_launch(const granne_hip_index* ix, uint32_t ef) {
+    LaunchPlan P;
+    uint32_t want = ix->opt_visited_slots ? (uint32_t)ix->opt_visited_slots : next_pow2(ef * 128u);
+    if (want > 16384 && !ix->opt_visited_slots) want = 16384;
+    if (want < 1024 && !ix->opt_visited_slots) want = 1024;
+    if (want > 32768) want = 32768;
+    P.visited_slots = want;
+    P.upper_slots = want < 1024 ? want : 1024;
+    uint32_t fixed = lds_query_bytes(ix->row_bytes) + 512;
+    if (ix->dtype == GRANNE_HIP_F32) {
+        uint32_t row16 = ix->row_bytes / 16;
+        P.lrow_bytes = (row16 | 1u) * 16u; // odd number of 16-byte units: conflict-free ds_read_b128
+        uint32_t wmax = ix->max_dev_width < 64 ? ix->max_dev_width : 64;
+        uint32_t budget = 40u * 1024u;
+        uint32_t used = fixed + P.visited_slots * 4u;
+        uint32_t avail = budget > used ? budget - used : 0;
+        uint32_t maxc = avail / P.lrow_bytes;
+        if (maxc > wmax) maxc = wmax;
+        if (maxc < 8) { // do not starve the stage: take what a lone walker may use
+            uint32_t hard = 64u * 1024u;
+            avail = hard > used ? hard - used : 0;
+            maxc = avail / P.lrow_bytes;
+            if (maxc > 8) maxc = 8;
+            if (maxc < 1) maxc = 1;
+        }
+        P.maxc = maxc;
+    } else {
+        P.maxc = 0;
+        P.lrow_bytes = 16;
+    }
+    P.lds_bytes = fixed + (ix->dtype == GRANNE_HIP_F32 ? P.maxc * P.lrow_bytes : 0) + P.visited_slots * 4u;
+    return P;
+}
+
+static int search_device_impl(const granne_hip_index* ix, const void* d_queries, uint32_t nq, uint32_t ef, uint32_t k,
+                              uint64_t* d_ids, float* d_dists, uint32_t* d_counts, uint64_t* d_stats,
+                              uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (ef == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
+    if (nq == 0) return GRANNE_HIP_OK;
+    if (k == 0) return fail(GRANNE_HIP_ERR_INVALID, "num_neighbors must be > 0");
+    if (!d_queries || !d_ids || !d_dists || !d_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+
+    const bool all_slow = ix->opt_force_slow || ef > 256;
+    LaunchPlan plan = plan_launch(ix, ef > 256 ? 256 : ef);
+    if (plan.lds_bytes > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
+
+    // stream-ordered scratch: slow list + slow-path containers
+    const uint32_t slow_blocks = (uint32_t)ix->opt_slow_blocks;
+    const uint32_t slots = (uint32_t)ix->opt_slow_slots;
+    size_t off_list = 16;
+    size_t off_vis = off_list + (((size_t)nq * 4 + 15) & ~(size_t)15);
+    size_t off_pq = off_vis + (size_t)slow_blocks * slots * 4;
+    size_t off_res = off_pq + (size_t)slow_blocks * slots * 8;
+    size_t total = off_res + (size_t)slow_blocks * ef * 8;
+    uint8_t* scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
+    HIP_TRY(hipMemsetAsync(scratch, 0, 16, s)); // [0]=slow_count, [1]=status
+
+    SearchParams p;
+    p.elements = ix->d_elements;
+    p.n_elements = ix->n_elements;
+    p.dim = ix->dim;
+    p.row_bytes = ix->row_bytes;
+    p.layers = ix->d_layers;
+    p.n_layers = (uint32_t)ix->layers.size();
+    p.queries = (const uint8_t*)d_queries;
+    p.nq = nq;
+    p.ef = ef;
+    p.k = k;
+    p.out_ids = d_ids;
+    p.out_dists = d_dists;
+    p.out_counts = d_counts;
+    p.out_stats = d_stats;
+    p.visited_slots = plan.visited_slots;
+    p.upper_slots = plan.upper_slots;
+    p.maxc = plan.maxc;
+    p.lrow_bytes = plan.lrow_bytes;
+    p.slow_count = (uint32_t*)scratch;
+    p.slow_list = (uint32_t*)(scratch + off_list);
+    p.force_slow = all_slow ? 1 : 0;
+
+    search_fn fn = pick_kernel(ix->dtype, ix->dim, ef > 256 ? 256 : ef);
+    if (plan.lds_bytes > 48u * 1024u)
+        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes));
+    hipLaunchKernelGGL(fn, dim3(nq), dim3(64), plan.lds_bytes, s, p);
+    HIP_TRY(hipGetLastError());
+
+    SlowParams sp;
+    sp.sp = p;
+    sp.vis = (uint32_t*)(scratch + off_vis);
+    sp.pq = (uint64_t*)(scratch + off_pq);
+    sp.res = (uint64_t*)(scratch + off_res);
+    sp.slots = slots;
+    sp.status = ((uint32_t*)scratch) + 1;
+    uint32_t slow_lds = lds_query_bytes(ix->row_bytes) + 64 * 8;
+    if (ix->dtype == GRANNE_HIP_F32)
+        hipLaunchKernelGGL(slow_kernel<DT_F32>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
+    else
+        hipLaunchKernelGGL(slow_kernel<DT_I8>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
+    HIP_TRY(hipGetLastError());
+
+    if (d_status) HIP_TRY(hipMemcpyAsync(d_status, sp.status, 4, hipMemcpyDeviceToDevice, s));
+    if (h_slow_count) {
+        uint32_t hs[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(hs, scratch, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        h_slow_count[0] = hs[0];
+        h_slow_count[1] = hs[1];
+    }
+    HIP_TRY(hipFreeAsync(scratch, s));
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_search_batch_device(const granne_hip_index* ix, const void* d_queries, uint32_t nq,
+                                              uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
+                                              float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
+                                              uint32_t* d_status, void* stream) {
+    return search_device_impl(ix, d_queries, nq, max_search, num_neighbors, d_out_ids, d_out_dists, d_out_counts,
+                              d_out_stats, d_status, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int granne_hip_search_batch(const granne_hip_index* ix, const void* queries, uint32_t nq, uint32_t max_search,
+                                       uint32_t num_neighbors, uint64_t* out_ids, float* out_dists, uint32_t* out_counts,
+                                       uint64_t* out_stats) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (max_search == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
+    if (nq == 0) return GRANNE_HIP_OK;
+    if (num_neighbors == 0) return fail(GRANNE_HIP_ERR_INVALID, "num_neighbors must be > 0");
+    if (!queries || !out_ids || !out_dists || !out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+
+    const size_t k = num_neighbors;
+    size_t qb = (size_t)nq * ix->dim * elem_size(ix->dtype);
+    size_t o_q = 0;
+    size_t o_ids = (qb + 255) & ~(size_t)255;
+    size_t o_d = o_ids + (size_t)nq * k * 8;
+    size_t o_c = o_d + (((size_t)nq * k * 4 + 15) & ~(size_t)15);
+    size_t o_s = o_c + (((size_t)nq * 4 + 15) & ~(size_t)15);
+    size_t total = o_s + (size_t)nq * 24;
+    uint8_t* buf = nullptr;
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int rc = GRANNE_HIP_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc((void**)&buf, total));
+        HIP_TRY(hipMemcpyAsync(buf + o_q, queries, qb, hipMemcpyHostToDevice, s));
+        uint32_t slow[2] = {0, 0};
+        int r = search_device_impl(ix, buf + o_q, nq, max_search, num_neighbors, (uint64_t*)(buf + o_ids),
+                                   (float*)(buf + o_d), (uint32_t*)(buf + o_c), (uint64_t*)(buf + o_s), nullptr, s, slow);
+        if (r) return r;
+        const_cast<granne_hip_index*>(ix)->last_slow_count.store(slow[0]);
+        if (slow[1]) return fail(GRANNE_HIP_ERR_OVERFLOW, "exact-search scratch exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)");
+        HIP_TRY(hipMemcpyAsync(out_ids, buf + o_ids, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_dists, buf + o_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_counts, buf + o_c, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        if (out_stats) HIP_TRY(hipMemcpyAsync(out_stats, buf + o_s, (size_t)nq * 24, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return GRANNE_HIP_OK;
+    };
+    rc = body();
+    if (buf) (void)hipFree(buf);
+    (void)hipStreamDestroy(s);
+    return rc;
+}
+
+extern "C" int granne_hip_search(const granne_hip_index* ix, const void* query, uint32_t max_search,
+                                 uint32_t num_neighbors, uint64_t* out_ids, float* out_dists, uint32_t* out_count) {
+    if (!out_count) return fail(GRANNE_HIP_ERR_INVALID, "out_count is null");
+    return granne_hip_search_batch(ix, query, 1, max_search, num_neighbors, out_ids, out_dists, out_count, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// element preparation / Dist operator / synthetic data
+// ------------------------------------------------------------------------------------------------
+extern "C" int granne_hip_normalize_f32_device(float* d_rows, uint64_t n, uint32_t dim, int device_id, void* stream) {
+    if (!d_rows && n) return fail(GRANNE_HIP_ERR_INVALID, "rows is null");
+    if (dim == 0) return fail(GRANNE_HIP_ERR_INVALID, "dim must be > 0");
+    if (n == 0) return GRANNE_HIP_OK;
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    uint32_t lstride = dim | 1u;
+    uint32_t rpb = (60u * 1024u) / (lstride * 4u);
+    if (rpb > 256) rpb = 256;
+    if (rpb < 1) return fail(GRANNE_HIP_ERR_INVALID, "dim too large");
+    uint64_t blocks = (n + rpb - 1) / rpb;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((uint32_t)blocks), dim3(256), rpb * lstride * 4, (hipStream_t)stream,
+                       d_rows, n, dim, rpb, lstride);
+    HIP_TRY(hipGetLastError());
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_quantize_f32_device(const float* d_rows, int8_t* d_out, uint64_t n, uint32_t dim,
+                                              int device_id, void* stream) {
+    if ((!d_rows || !d_out) && n) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (n == 0) return GRANNE_HIP_OK;
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    hipLaunchKernelGGL(quantize_rows_kernel, dim3(grid_for(n * 64, 256)), dim3(256), 0, (hipStream_t)stream, d_rows,
+                       d_out, n, dim);
+    HIP_TRY(hipGetLastError());
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_dist_pairs_device(const granne_hip_index* ix, const void* d_queries, const uint32_t* d_qidx,
+                                            const uint32_t* d_ids, uint64_t n_pairs, float* d_out, void* stream) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (n_pairs == 0) return GRANNE_HIP_OK;
+    if (!d_queries || !d_qidx || !d_ids || !d_out) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+    if (ix->dtype == GRANNE_HIP_F32)
+        hipLaunchKernelGGL(dist_pairs_kernel<0>, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream,
+                           ix->d_elements, ix->row_bytes, ix->dim, (const uint8_t*)d_queries, d_qidx, d_ids, n_pairs, d_out);
+    else
+        hipLaunchKernelGGL(dist_pairs_kernel<1>, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream,
+                           ix->d_elements, ix->row_bytes, ix->dim, (const uint8_t*)d_queries, d_qidx, d_ids, n_pairs, d_out);
+    HIP_TRY(hipGetLastError());
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
+                                            int device_id, void* stream) {
+    if (!d_out && n) return fail(GRANNE_HIP_ERR_INVALID, "out is null");
+    if (n == 0) return GRANNE_HIP_OK;
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    hipLaunchKernelGGL(synth_rows_kernel, dim3(grid_for(n * dim, 256)), dim3(256), 0, (hipStream_t)stream, d_out, seed,
+                       row0, n, dim);
+    HIP_TRY(hipGetLastError());
+    return GRANNE_HIP_OK;
+}
+
+// host conveniences -------------------------------------------------------------------------------
+extern "C" int granne_hip_normalize_f32(float* rows, uint64_t n, uint32_t dim, int device_id) {
+    if (!rows && n) return fail(GRANNE_HIP_ERR_INVALID, "rows is null");
+    if (n == 0) return GRANNE_HIP_OK;
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    float* d = nullptr;
+    size_t bytes = (size_t)n * dim * 4;
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    int rc = GRANNE_HIP_OK;
+    hipError_t e = hipMemcpy(d, rows, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) rc = granne_hip_normalize_f32_device(d, n, dim, device_id, nullptr);
+    if (e == hipSuccess && rc == 0) e = hipMemcpy(rows, d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(GRANNE_HIP_ERR_HIP, "normalize: %s", hipGetErrorString(e));
+    return rc;
+}
+
+extern "C" int granne_hip_quantize_f32(const float* rows, int8_t* out, uint64_t n, uint32_t dim, int device_id) {
+    if ((!rows || !out) && n) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (n == 0) return GRANNE_HIP_OK;
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    float* d = nullptr;
+    int8_t* o = nullptr;
+    size_t bytes = (size_t)n * dim * 4;
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    hipError_t e = hipMalloc((void**)&o, (size_t)n * dim);
+    int rc = GRANNE_HIP_OK;
+    if (e == hipSuccess) e = hipMemcpy(d, rows, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) rc = granne_hip_quantize_f32_device(d, o, n, dim, device_id, nullptr);
+    if (e == hipSuccess && rc == 0) e = hipMemcpy(out, o, (size_t)n * dim, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (o) (void)hipFree(o);
+    if (e != hipSuccess) return fail(GRANNE_HIP_ERR_HIP, "quantize: %s", hipGetErrorString(e));
+    return rc;
+}
+
+extern "C" int granne_hip_dist_pairs(const granne_hip_index* ix, const void* queries, uint32_t nq, const uint32_t* qidx,
+                                     const uint32_t* ids, uint64_t n_pairs, float* out) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (n_pairs == 0) return GRANNE_HIP_OK;
+    if (!queries || !qidx || !ids || !out) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    for (uint64_t i = 0; i < n_pairs; ++i) {
+        if (qidx[i] >= nq) return fail(GRANNE_HIP_ERR_INVALID, "query index out of range");
+        if (ids[i] >= ix->n_elements) return fail(GRANNE_HIP_ERR_INVALID, "element id out of range");
+    }
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+    size_t qb = (size_t)nq * ix->dim * elem_size(ix->dtype);
+    uint8_t *dq = nullptr, *dqi = nullptr, *did = nullptr, *dout = nullptr;
+    auto freeall = [&]() {
+        if (dq) (void)hipFree(dq);
+        if (dqi) (void)hipFree(dqi);
+        if (did) (void)hipFree(did);
+        if (dout) (void)hipFree(dout);
+    };
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc((void**)&dq, qb));
+        HIP_TRY(hipMalloc((void**)&dqi, n_pairs * 4));
+        HIP_TRY(hipMalloc((void**)&did, n_pairs * 4));
+        HIP_TRY(hipMalloc((void**)&dout, n_pairs * 4));
+        HIP_TRY(hipMemcpy(dq, queries, qb, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dqi, qidx, n_pairs * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(did, ids, n_pairs * 4, hipMemcpyHostToDevice));
+        int r = granne_hip_dist_pairs_device(ix, dq, (const uint32_t*)dqi, (const uint32_t*)did, n_pairs, (float*)dout, nullptr);
+        if (r) return r;
+        HIP_TRY(hipMemcpy(out, dout, n_pairs * 4, hipMemcpyDeviceToHost));
+        return GRANNE_HIP_OK;
+    };
+    int rc = body();
+    freeall();
+    return rc;
+}

@@ -1,0 +1,375 @@
+// search_kernel.h -- Granne::search as one gfx950 kernel: one wavefront walks one query through
+// every layer (find_entrypoint + search_for_neighbors, /root/reference/src/index/mod.rs:963-1037).
+//
+// Per expansion (one iteration of the reference's `while let Some(..) = pq.pop()` loop):
+//   1. the expanded node's adjacency row (device layout: fixed width, 128-byte aligned) is read
+//      with one coalesced load, one neighbor id per lane;
+//   2. every lane offers its id to the exact LDS visited set (ds_cmpst), new ids are compacted;
+//   3. f32: the new candidates' rows are gathered from HBM with 16-byte loads, 64 lanes wide,
+//      into an LDS stage; then ONE LANE PER CANDIDATE evaluates the reference's exact
+//      32-accumulator dot product from LDS (dist.h), the query being broadcast from LDS;
+//      i8: 16-byte pieces of the rows go straight to lanes, v_dot4_i32_i8, xor-shuffle reduce;
+//   4. candidate keys (dist,id) that pass the reference's filter are ranked into the register-
+//      resident sorted queue with ballots.
+// The walk is a strict restatement of the reference's control flow, so results are identical;
+// only memory (never logic) is parallel. Two bounded structures can overflow: the LDS visited
+// table, and the candidate queue (64*S entries; dropping its largest entry is provably safe
+// unless that entry ties with the max_search-th smallest distance). Either event hands the
+// query, untouched, to the unbounded global-memory walker (slow_kernel below), which is the
+// same algorithm with literal heaps -- still on the GPU, never on the CPU.
+#pragma once
+
+#include "dist.h"
+#include "wave_prims.h"
+
+namespace granne_hip {
+
+constexpr int DT_F32 = 0;
+constexpr int DT_I8 = 1;
+
+struct LayerDev {
+    const uint32_t* adj; // [len][width] u32, UNUSED-padded, valid ids first
+    uint64_t len;
+    uint32_t width;      // device row width (multiple of 32 -> rows are 128-byte aligned)
+    uint32_t pad_;
+};
+
+struct SearchParams {
+    const uint8_t* elements; // device layout: [n][row_bytes], zero padded
+    uint64_t n_elements;
+    uint32_t dim;
+    uint32_t row_bytes;      // multiple of 16
+    const LayerDev* layers;
+    uint32_t n_layers;
+    const uint8_t* queries;  // dense [nq][dim] scalars
+    uint32_t nq;
+    uint32_t ef;             // max_search
+    uint32_t k;              // num_neighbors
+    uint64_t* out_ids;       // [nq][k]
+    float* out_dists;        // [nq][k]
+    uint32_t* out_counts;    // [nq]
+    uint64_t* out_stats;     // [nq][3] or null
+    uint32_t visited_slots;  // bottom layer, power of two
+    uint32_t upper_slots;    // upper layers, power of two <= visited_slots
+    uint32_t maxc;           // f32: rows the LDS stage holds (<= 64)
+    uint32_t lrow_bytes;     // f32: LDS stage row stride (odd multiple of 16)
+    uint32_t* slow_count;    // queries handed to the slow path
+    uint32_t* slow_list;     // [nq]
+    uint32_t force_slow;
+};
+
+struct WalkStats {
+    uint64_t n_dist, n_expand, n_adj;
+};
+
+// LDS carve-up (dynamic shared memory), all offsets multiples of 16:
+//   [query: row_bytes][cand: 64 u32][dout: 64 f32][stage: maxc*lrow_bytes (f32)][visited]
+__host__ __device__ inline uint32_t lds_query_bytes(uint32_t row_bytes) { return (row_bytes + 15u) & ~15u; }
+
+template <int DT, int DIM, int S>
+struct Walker {
+    // ---- immutable per-launch state
+    const SearchParams& p;
+    uint32_t lane;
+    uint8_t* lds_q;
+    uint32_t* cand;
+    float* dout;
+    uint8_t* stage;
+    uint32_t* vis_tab;
+    int dy; // i8: sum of squares of the query
+    // ---- per-walk state
+    VisitedSet vis;
+    SortedList<S> res; // `res`, capped at ef entries
+    SortedList<S> pq;  // `pq`, bounded at 64*S entries
+    WalkStats st;
+    bool bail; // visited table full or unsafe queue drop: hand over to the slow path
+
+    __device__ __forceinline__ Walker(const SearchParams& p_, uint8_t* smem) : p(p_) {
+        lane = threadIdx.x;
+        uint32_t qb = lds_query_bytes(p.row_bytes);
+        lds_q = smem;
+        cand = reinterpret_cast<uint32_t*>(smem + qb);
+        dout = reinterpret_cast<float*>(smem + qb + 256);
+        stage = smem + qb + 512;
+        uint32_t stage_bytes = (DT == DT_F32) ? p.maxc * p.lrow_bytes : 0;
+        vis_tab = reinterpret_cast<uint32_t*>(stage + stage_bytes);
+        dy = 0;
+        st.n_dist = st.n_expand = st.n_adj = 0;
+        bail = false;
+    }
+
+    // stage the query in LDS, zero padded to row_bytes
+    __device__ __forceinline__ void load_query(uint32_t qi) {
+        if (DT == DT_F32) {
+            const float* q = reinterpret_cast<const float*>(p.queries) + (size_t)qi * p.dim;
+            float* l = reinterpret_cast<float*>(lds_q);
+            for (uint32_t i = lane; i < p.row_bytes / 4; i += 64) l[i] = (i < p.dim) ? q[i] : 0.0f;
+        } else {
+            const int8_t* q = reinterpret_cast<const int8_t*>(p.queries) + (size_t)qi * p.dim;
+            int8_t* l = reinterpret_cast<int8_t*>(lds_q);
+            int part = 0;
+            for (uint32_t i = lane; i < p.row_bytes; i += 64) {
+                int v = (i < p.dim) ? (int)q[i] : 0;
+                l[i] = (int8_t)v;
+                part += v * v;
+            }
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            dy = part; // exact i32, identical in every lane
+        }
+        __syncthreads();
+    }
+
+    // distances of candidates cand[0..m) (m <= 64) to the query; lane c < m returns d(c)
+    __device__ __forceinline__ float distances(uint32_t m) {
+        float d = 0.0f;
+        if constexpr (DT == DT_F32) {
+            const uint32_t row16 = p.row_bytes >> 4;
+            const uint32_t lrow16 = p.lrow_bytes >> 4;
+            for (uint32_t g0 = 0; g0 < m; g0 += p.maxc) {
+                uint32_t gm = min(p.maxc, m - g0);
+                uint32_t total = gm * row16;
+                // gather: 64 lanes x 16 bytes per step, 8 steps in flight before the first LDS write
+                for (uint32_t f0 = 0; f0 < total; f0 += 64 * 8) {
+                    uint4 v0, v1, v2, v3, v4, v5, v6, v7;
+                    uint32_t d0, d1, d2, d3, d4, d5, d6, d7;
+#define GRANNE_GATHER(U, V, D)                                                                       \
+    {                                                                                                \
+        uint32_t f = f0 + (U) * 64u + lane;                                                          \
+        uint32_t fc = f < total ? f : total - 1u; /* clamp: the load itself is unconditional */      \
+        uint32_t row;                                                                                \
+        if constexpr (DIM > 0) row = fc / (uint32_t)(DIM / 4);                                       \
+        else row = fc / row16;                                                                       \
+        uint32_t part = fc - row * row16;                                                            \
+        uint32_t id = cand[g0 + row];                                                                \
+        V = *reinterpret_cast<const uint4*>(p.elements + (size_t)id * p.row_bytes + (size_t)part * 16); \
+        D = f < total ? (row * lrow16 + part) * 16u : 0xFFFFFFFFu;                                   \
+    }
+                    GRANNE_GATHER(0, v0, d0)
+                    GRANNE_GATHER(1, v1, d1)
+                    GRANNE_GATHER(2, v2, d2)
+                    GRANNE_GATHER(3, v3, d3)
+                    GRANNE_GATHER(4, v4, d4)
+                    GRANNE_GATHER(5, v5, d5)
+                    GRANNE_GATHER(6, v6, d6)
+                    GRANNE_GATHER(7, v7, d7)
+#undef GRANNE_GATHER
+                    if (d0 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(stage + d0) = v0;
+                    if (d1 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(stage + d1) = v1;
+                    if (d2 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(stage + d2) = v2;
+                    if (d3 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(stage + d3) = v3;
+                    if (d4 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(stage + d4) = v4;
+                    if (d5 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(stage + d5) = v5;
+                    if (d6 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(stage + d6) = v6;
+                    if (d7 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(stage + d7) = v7;
+                }
+                __syncthreads();
+                if (lane >= g0 && lane < g0 + gm) {
+                    const float* x = reinterpret_cast<const float*>(stage + (size_t)(lane - g0) * p.lrow_bytes);
+                    const float* q = reinterpret_cast<const float*>(lds_q);
+                    float r;
+                    if constexpr (DIM > 0) r = dot_f32_exact<DIM>(x, q);
+                    else r = dot_f32_exact_rt(x, q, p.dim);
+                    d = angular_from_dot(r);
+                }
+                __syncthreads();
+            }
+        } else {
+            // lanes-per-row: 16 bytes per lane, up to 64 lanes (rows of up to 1024 bytes per step)
+            const uint32_t row16 = p.row_bytes >> 4;
+            const uint32_t lpr = min(64u, row16); // power of two by construction of row_bytes
+            const uint32_t rpp = 64u / lpr;       // rows per pass
+            const uint32_t sub = lane & (lpr - 1);
+            const uint32_t rip = lane / lpr;
+            for (uint32_t c0 = 0; c0 < m; c0 += rpp) {
+                uint32_t ci = c0 + rip;
+                int r = 0, dx = 0;
+                if (ci < m) {
+                    const uint8_t* row = p.elements + (size_t)cand[ci] * p.row_bytes;
+                    for (uint32_t u = sub; u < row16; u += lpr) {
+                        uint4 x = *reinterpret_cast<const uint4*>(row + (size_t)u * 16);
+                        uint4 y = *reinterpret_cast<const uint4*>(lds_q + (size_t)u * 16);
+                        r = dot4_i8(x.x, y.x, r); r = dot4_i8(x.y, y.y, r);
+                        r = dot4_i8(x.z, y.z, r); r = dot4_i8(x.w, y.w, r);
+                        dx = dot4_i8(x.x, x.x, dx); dx = dot4_i8(x.y, x.y, dx);
+                        dx = dot4_i8(x.z, x.z, dx); dx = dot4_i8(x.w, x.w, dx);
+                    }
+                }
+                for (uint32_t o = lpr >> 1; o > 0; o >>= 1) {
+                    r += __shfl_xor(r, (int)o, 64);
+                    dx += __shfl_xor(dx, (int)o, 64);
+                }
+                if (ci < m && sub == 0) dout[ci] = angular_int_from_sums(r, dx, dy);
+            }
+            __syncthreads();
+            if (lane < m) d = dout[lane];
+            __syncthreads();
+        }
+        return d;
+    }
+
+    // pq.push with the bounded queue; flags `bail` when dropping an entry is not provably safe
+    __device__ __forceinline__ void pq_push(uint64_t ck, uint32_t ef) {
+        constexpr uint32_t CAP = 64u * S;
+        uint32_t r = pq.rank(ck);
+        uint64_t dropped;
+        if (r >= CAP) {
+            dropped = ck;
+        } else {
+            dropped = pq.get(CAP - 1);
+            pq.insert_at(r, ck, lane);
+        }
+        if (dropped != KEY_INF) {
+            // every entry left in pq sorts before `dropped`; it could only ever be popped after
+            // >= ef smaller ones, i.e. when res.max.dist <= pq[ef-1].dist. Safe unless tied.
+            if (key_dist(dropped) == key_dist(pq.get(ef - 1))) bail = true;
+        }
+    }
+
+    // search_for_neighbors (mod.rs:999-1037) on one layer. Result: `res` (ascending).
+    __device__ __forceinline__ void search_layer(const LayerDev& L, uint32_t entrypoint, uint32_t ef,
+                                                 uint32_t slots) {
+        vis.reset(vis_tab, slots, lane);
+        res.init();
+        pq.init();
+        __syncthreads();
+        uint32_t n_popped = 0;
+
+        // distance to the entry point (mod.rs:1012-1016)
+        if (lane == 0) cand[0] = entrypoint;
+        vis.insert(entrypoint, lane == 0);
+        vis.count = 1;
+        __syncthreads();
+        {
+            float d0 = distances(1);
+            st.n_dist += 1;
+            uint64_t k0 = readlane64(make_key(d0, entrypoint), 0);
+            pq.insert_at(0, k0, lane);
+        }
+
+        for (;;) {
+            uint64_t x = pq.get(0); // pq.pop(), mod.rs:1018
+            if (x == KEY_INF) break;
+            bool full = n_popped >= ef;
+            if (full && key_dist(x) > key_dist(res.get(ef - 1))) break; // mod.rs:1019-1021
+            pq.pop_front(lane);
+
+            // res.push((d, idx)), max_size_heap.rs:18-32
+            {
+                uint32_t r = res.rank(x);
+                if (r < ef) {
+                    res.insert_at(r, x, lane);
+                    if (ef < 64u * S) res.clear_at(ef, lane);
+                }
+            }
+            n_popped += 1;
+            full = n_popped >= ef;
+            const float worst = full ? key_dist(res.get(ef - 1)) : 0.0f;
+
+            // layer.get_neighbors(idx), mod.rs:1025 / 540-552: row prefix until UNUSED
+            const uint32_t xid = key_id(x);
+            const uint32_t* row = L.adj + (size_t)xid * L.width;
+            st.n_expand += 1;
+            for (uint32_t base = 0; base < L.width; base += 64) {
+                uint32_t nb = (base + lane < L.width) ? row[base + lane] : ID_EMPTY;
+                uint64_t unused = wave_ballot(nb == ID_EMPTY);
+                uint32_t nvalid = unused ? (uint32_t)__builtin_ctzll(unused) : 64u;
+                st.n_adj += nvalid;
+                bool valid = lane < nvalid;
+
+                bool fresh = vis.insert(nb, valid); // visited.insert(neighbor_idx), mod.rs:1026
+                uint64_t fm = wave_ballot(fresh);
+                uint32_t m = (uint32_t)__popcll(fm);
+                if (m) {
+                    vis.count += m;
+                    uint32_t pos = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+                    if (fresh) cand[pos] = nb;
+                    __syncthreads();
+                    float d = distances(m); // mod.rs:1027
+                    st.n_dist += m;
+                    uint32_t cid = (lane < m) ? cand[lane] : 0u;
+                    uint64_t ck = make_key(d, cid);
+                    // mod.rs:1029-1031: `res` is frozen during an expansion, so the filter is too
+                    bool pass = (lane < m) && (!full || d < worst);
+                    // entries that cannot enter a full queue are dropped right here
+                    uint64_t last = pq.get(64u * S - 1);
+                    if (last != KEY_INF) {
+                        bool dropnow = pass && ck > last;
+                        if (wave_ballot(dropnow && d == key_dist(pq.get(ef - 1)))) bail = true;
+                        pass = pass && !dropnow;
+                    }
+                    uint64_t pm = wave_ballot(pass);
+                    while (pm) {
+                        uint32_t src = (uint32_t)__builtin_ctzll(pm);
+                        pm &= pm - 1;
+                        pq_push(readlane64(ck, src), ef);
+                    }
+                    __syncthreads();
+                }
+                if (vis.count > vis.limit) bail = true;
+                if (nvalid < 64u) break;
+            }
+            if (bail) return;
+        }
+    }
+};
+
+template <int DT, int DIM, int S>
+__global__ __launch_bounds__(64) void search_kernel(const SearchParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t qi = blockIdx.x;
+    if (qi >= p.nq) return;
+    const uint32_t lane = threadIdx.x;
+
+    if (p.force_slow) {
+        if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+        return;
+    }
+
+    Walker<DT, DIM, S> w(p, smem);
+    w.load_query(qi);
+
+    uint32_t entrypoint = 0; // mod.rs:989
+    for (uint32_t l = 0; l < p.n_layers; ++l) {
+        const LayerDev L = p.layers[l];
+        const bool bottom = (l + 1 == p.n_layers);
+        w.search_layer(L, entrypoint, bottom ? p.ef : 1u, bottom ? p.visited_slots : p.upper_slots);
+        if (w.bail) break;
+        if (!bottom) entrypoint = key_id(w.res.get(0)); // res[0].0, mod.rs:993
+    }
+
+    if (w.bail) { // hand the untouched query to the exact global-memory walker
+        if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+        return;
+    }
+
+    // .take(num_neighbors), mod.rs:974-977
+    uint32_t count = 0;
+    if (p.n_layers > 0) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) count += (uint32_t)__popcll(wave_ballot(w.res.key[s] != KEY_INF));
+        count = min(count, p.k);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        uint32_t e = (uint32_t)s * 64u + lane;
+        if (e < p.k) {
+            bool ok = e < count;
+            p.out_ids[(size_t)qi * p.k + e] = ok ? (uint64_t)key_id(w.res.key[s]) : ~0ull;
+            p.out_dists[(size_t)qi * p.k + e] = ok ? key_dist(w.res.key[s]) : __builtin_inff();
+        }
+    }
+    for (uint32_t e = 64u * S + lane; e < p.k; e += 64) { // k beyond the list capacity: padding
+        p.out_ids[(size_t)qi * p.k + e] = ~0ull;
+        p.out_dists[(size_t)qi * p.k + e] = __builtin_inff();
+    }
+    if (lane == 0) {
+        p.out_counts[qi] = count;
+        if (p.out_stats) {
+            p.out_stats[(size_t)qi * 3 + 0] = w.st.n_dist;
+            p.out_stats[(size_t)qi * 3 + 1] = w.st.n_expand;
+            p.out_stats[(size_t)qi * 3 + 2] = w.st.n_adj;
+        }
+    }
+}
+
+} // namespace granne_hip

@@ -1,0 +1,154 @@
+// wave_prims.h -- wave64 building blocks of the on-device HNSW walk (gfx950 / CDNA4).
+//
+// One wavefront (64 lanes) owns one query. The reference's three containers
+// (/root/reference/src/index/mod.rs:1006-1010) map to:
+//   MaxSizeHeap `res`        -> SortedList<S>: ascending keys held in VGPRs, entry e in
+//   BinaryHeap  `pq`         -> SortedList<S>   (slot e/64, lane e%64); insert = ballot-rank +
+//                               one-lane shift (DPP wave_shr), pop-min = shift the other way
+//   HashSet     `visited`    -> VisitedSet: exact open-addressing table in LDS, ds_cmpst CAS
+// A key packs the reference's (NotNan<f32>, usize) tuple into one u64: distance bits in the
+// high word, id in the low word. Distances are >= +0.0 (clamped, angular.rs:72), never NaN
+// and never -0.0, so unsigned integer order on the key IS the tuple's lexicographic Ord.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace granne_hip {
+
+constexpr uint64_t KEY_INF = ~0ull;      // sorts after every real key (dist bits <= 0x40000000)
+constexpr uint32_t ID_EMPTY = 0xFFFFFFFFu; // == UNUSED (src/index/mod.rs:27-28): never a node id
+
+__device__ __forceinline__ uint64_t make_key(float d, uint32_t id) {
+    return ((uint64_t)__float_as_uint(d) << 32) | (uint64_t)id;
+}
+__device__ __forceinline__ float key_dist(uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); }
+__device__ __forceinline__ uint32_t key_id(uint64_t k) { return (uint32_t)k; }
+
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
+
+// v_readlane with a wave-uniform lane index
+__device__ __forceinline__ uint32_t readlane32(uint32_t v, uint32_t lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t lane) {
+    uint32_t lo = readlane32((uint32_t)v, lane);
+    uint32_t hi = readlane32((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// lane i receives lane i-1's value (lane 0: unspecified)
+__device__ __forceinline__ uint32_t shift_up1(uint32_t v) {
+#if GRANNE_HIP_USE_DPP
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+#else
+    return (uint32_t)__shfl_up((int)v, 1, 64);
+#endif
+}
+// lane i receives lane i+1's value (lane 63: unspecified)
+__device__ __forceinline__ uint32_t shift_down1(uint32_t v) {
+#if GRANNE_HIP_USE_DPP
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+#else
+    return (uint32_t)__shfl_down((int)v, 1, 64);
+#endif
+}
+__device__ __forceinline__ uint64_t shift_up1(uint64_t v) {
+    return ((uint64_t)shift_up1((uint32_t)(v >> 32)) << 32) | shift_up1((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t shift_down1(uint64_t v) {
+    return ((uint64_t)shift_down1((uint32_t)(v >> 32)) << 32) | shift_down1((uint32_t)v);
+}
+
+// Ascending sorted list of up to 64*S keys spread over the wave's registers.
+template <int S>
+struct SortedList {
+    uint64_t key[S];
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < S; ++s) key[s] = KEY_INF;
+    }
+    // number of entries strictly smaller than c (wave-uniform)
+    __device__ __forceinline__ uint32_t rank(uint64_t c) const {
+        uint32_t r = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) r += (uint32_t)__popcll(wave_ballot(key[s] < c));
+        return r;
+    }
+    // entry e (wave-uniform index)
+    __device__ __forceinline__ uint64_t get(uint32_t e) const {
+        uint64_t v = readlane64(key[0], e & 63u);
+#pragma unroll
+        for (int s = 1; s < S; ++s) {
+            uint64_t t = readlane64(key[s], e & 63u);
+            if ((e >> 6) == (uint32_t)s) v = t;
+        }
+        return v;
+    }
+    // insert c at position r (< 64*S): entries at >= r move up one, the last one falls off
+    __device__ __forceinline__ void insert_at(uint32_t r, uint64_t c, uint32_t lane) {
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {
+            uint64_t up = shift_up1(key[s]);
+            if (s > 0) {
+                uint64_t carry = readlane64(key[s - 1], 63);
+                if (lane == 0) up = carry;
+            }
+            uint32_t e = (uint32_t)s * 64u + lane;
+            key[s] = (e > r) ? up : ((e == r) ? c : key[s]);
+        }
+    }
+    // remove entry 0
+    __device__ __forceinline__ void pop_front(uint32_t lane) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            uint64_t dn = shift_down1(key[s]);
+            uint64_t carry = KEY_INF;
+            if (s + 1 < S) carry = readlane64(key[s + 1], 0);
+            key[s] = (lane == 63) ? carry : dn;
+        }
+    }
+    // overwrite entry e with KEY_INF (used to cap `res` at max_search entries)
+    __device__ __forceinline__ void clear_at(uint32_t e, uint32_t lane) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if ((uint32_t)s * 64u + lane == e) key[s] = KEY_INF;
+    }
+};
+
+// Exact visited set in LDS (HashSet<usize>, src/index/mod.rs:1009-1010,1016,1026).
+struct VisitedSet {
+    uint32_t* tab;  // LDS
+    uint32_t mask;  // slots - 1
+    uint32_t count; // wave-uniform number of stored ids
+    uint32_t limit; // max ids before the walk is handed to the global-memory path
+
+    __device__ __forceinline__ void reset(uint32_t* lds, uint32_t slots, uint32_t lane) {
+        tab = lds;
+        mask = slots - 1;
+        count = 0;
+        limit = slots - (slots >> 2) - (slots >> 3); // 62.5 % load
+        uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
+        uint4* t4 = reinterpret_cast<uint4*>(lds);
+        for (uint32_t i = lane; i < (slots >> 2); i += 64) t4[i] = e;
+    }
+    __device__ __forceinline__ static uint32_t hash(uint32_t id) { return (id * 0x9E3779B1u) >> 7; }
+
+    // HashSet::insert: true iff id was not present. Lanes with active==false do nothing.
+    __device__ __forceinline__ bool insert(uint32_t id, bool active) {
+        bool fresh = false;
+        if (active) {
+            uint32_t slot = hash(id) & mask;
+            for (;;) {
+                uint32_t old = atomicCAS(&tab[slot], ID_EMPTY, id);
+                if (old == ID_EMPTY) { fresh = true; break; }
+                if (old == id) break;
+                slot = (slot + 1) & mask;
+            }
+        }
+        return fresh;
+    }
+};
+
+} // namespace granne_hip

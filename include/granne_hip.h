@@ -1,0 +1,172 @@
+/*
+ * granne_hip.h -- C ABI of libgranne_hip.so, the MI355X (gfx950) search path for granne.
+ *
+ * This is the drop-in boundary for ONE path of the reference: `Granne::search`
+ * (/root/reference/src/index/mod.rs:140-150) and everything below it (find_entrypoint :984-997,
+ * search_for_neighbors :999-1037, MaxSizeHeap src/max_size_heap.rs:5-45, the angular distances
+ * src/elements/angular.rs:63-74 / angular_int.rs:47-60 over src/math.rs:5-52,59-89). The
+ * reference has no FFI for this path (it is generic Rust over the ElementContainer/Dist traits,
+ * src/elements/mod.rs:17-70); these entry points are what a `GpuGranne` Rust wrapper binds --
+ * INTEGRATION.md shows the `extern "C"` block and the wrapper.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns GRANNE_HIP_OK (0) or a negative error code and never throws or
+ *     aborts; granne_hip_last_error() returns a thread-local message for the last failure;
+ *   - the reference's panics on this path become error codes (max_search == 0,
+ *     src/index/mod.rs:1019 -> GRANNE_HIP_ERR_INVALID);
+ *   - results are bit-identical to the reference's CPU search on the same index and queries:
+ *     ids exact, distances exact (same f32 operation order), order ascending by (dist, id);
+ *   - "host" functions take host pointers and copy; "_device" functions take device pointers
+ *     (hipMalloc'd on the index's device) plus a hipStream_t passed as void* and are
+ *     asynchronous with respect to the host.
+ */
+#ifndef GRANNE_HIP_H
+#define GRANNE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRANNE_HIP_ABI_VERSION 1
+
+/* element scalar types: granne::angular::Vectors (f32, rows normalised) and
+ * granne::angular_int::Vectors (i8, rows quantised) -- src/elements/angular.rs:53,
+ * src/elements/angular_int.rs:17 */
+enum { GRANNE_HIP_F32 = 0, GRANNE_HIP_I8 = 1 };
+
+enum {
+    GRANNE_HIP_OK = 0,
+    GRANNE_HIP_ERR_INVALID = -1,  /* bad argument (incl. the reference's panic conditions) */
+    GRANNE_HIP_ERR_HIP = -2,      /* a HIP runtime call failed; see granne_hip_last_error() */
+    GRANNE_HIP_ERR_NO_DEVICE = -3,/* no gfx950 device / kernels not loadable: never falls back to CPU */
+    GRANNE_HIP_ERR_OVERFLOW = -4, /* exact-search scratch exhausted; raise GRANNE_HIP_OPT_SLOW_* */
+    GRANNE_HIP_ERR_IO = -5        /* malformed index / elements file */
+};
+
+/* NeighborId padding value of fixed-width adjacency rows (src/index/mod.rs:27-28) */
+#define GRANNE_HIP_UNUSED 0xFFFFFFFFu
+
+typedef struct granne_hip_index granne_hip_index; /* opaque; owns HBM copies of elements + graph */
+
+const char* granne_hip_last_error(void);
+int granne_hip_abi_version(void);
+int granne_hip_device_count(int* out_count);
+
+/* ---- index lifetime -------------------------------------------------------------------------
+ * granne_hip_index_create: replaces building a `Granne` from a builder's layers
+ * (GranneBuilder::get_index, src/index/mod.rs:483-488 -> Layers::FixWidth). Layers are
+ * prefix-nested (layer i holds nodes 0..layer_len[i]); layer_rows[i] is a row-major
+ * [layer_len[i]][layer_width[i]] u32 matrix, valid ids first, padded with GRANNE_HIP_UNUSED
+ * (FixedWidthSliceVector<u32>, src/slice_vector/mod.rs:42-45, 344-356). `elements` is the
+ * payload of an angular(_int)::Vectors file: row-major [n_elements][dim] scalars
+ * (src/slice_vector/mod.rs:213-221). All inputs are host memory and are copied to HBM; the
+ * caller may free/unmap them afterwards. n_layers == 0 is a valid (empty) index.           */
+int granne_hip_index_create(granne_hip_index** out, const void* elements, uint64_t n_elements,
+                            uint32_t dim, int dtype, uint32_t n_layers, const uint64_t* layer_len,
+                            const uint32_t* const* layer_rows, const uint32_t* layer_width,
+                            int device_id);
+
+/* Same, from the decoded form of the on-disk layers (MultiSetVector,
+ * src/slice_vector/set_vector.rs:8-115; Layers::Compressed, src/index/io.rs:72-87): per layer a
+ * CSR pair offsets[layer_len+1] (u64) / ids[offsets[layer_len]] (u32, any order).          */
+int granne_hip_index_create_csr(granne_hip_index** out, const void* elements, uint64_t n_elements,
+                                uint32_t dim, int dtype, uint32_t n_layers, const uint64_t* layer_len,
+                                const uint64_t* const* layer_offsets, const uint32_t* const* layer_ids,
+                                int device_id);
+
+/* Same as granne_hip_index_create but `elements` and every layer_rows[i] are DEVICE pointers on
+ * device_id (e.g. produced on the GPU); they are re-laid-out into the index's own HBM buffers. */
+int granne_hip_index_create_device(granne_hip_index** out, const void* d_elements, uint64_t n_elements,
+                                   uint32_t dim, int dtype, uint32_t n_layers, const uint64_t* layer_len,
+                                   const uint32_t* const* d_layer_rows, const uint32_t* layer_width,
+                                   int device_id, void* stream);
+
+void granne_hip_index_destroy(granne_hip_index* index);
+
+/* Index trait (src/index/mod.rs:54-71) */
+uint64_t granne_hip_index_len(const granne_hip_index* index);        /* bottom layer length */
+uint32_t granne_hip_index_num_layers(const granne_hip_index* index);
+uint64_t granne_hip_index_layer_len(const granne_hip_index* index, uint32_t layer);
+uint32_t granne_hip_index_dim(const granne_hip_index* index);
+int granne_hip_index_dtype(const granne_hip_index* index);
+int granne_hip_index_device(const granne_hip_index* index);
+uint64_t granne_hip_index_hbm_bytes(const granne_hip_index* index);
+/* Index::get_neighbors(index, layer) (src/index/mod.rs:64): copies up to cap ids, returns count
+ * in *out_count. */
+int granne_hip_index_get_neighbors(const granne_hip_index* index, uint64_t node, uint32_t layer,
+                                   uint32_t* out_ids, uint32_t cap, uint32_t* out_count);
+/* Granne::get_element (src/index/mod.rs:153-155): copies dim scalars of element `idx`. */
+int granne_hip_index_get_element(const granne_hip_index* index, uint64_t idx, void* out);
+
+/* ---- search -----------------------------------------------------------------------------------
+ * granne_hip_search_batch: `nq` independent `Granne::search(&query, max_search, num_neighbors)`
+ * calls (src/index/mod.rs:140-150). queries: row-major [nq][dim] scalars of the index's dtype,
+ * ALREADY prepared the way Vector::from does it (normalised f32: src/elements/angular.rs:55-61;
+ * quantised i8: src/elements/angular_int.rs:19-45) -- granne_hip_normalize_f32 /
+ * granne_hip_quantize_f32 below do that on the device, bit-exactly.
+ * Outputs (row-major [nq][num_neighbors], may be NULL where noted):
+ *   out_ids    u64 (usize)  neighbor ids, ascending by (dist, id); unused slots = UINT64_MAX
+ *   out_dists  f32          the distances; unused slots = +inf
+ *   out_counts u32 [nq]     results per query = min(num_neighbors, max_search, #reachable)
+ *   out_stats  u64 [nq][3]  (optional) per query: n_dist, n_expand, n_adj -- the counters the
+ *                           roofline uses: dist_to_element calls, get_neighbors
+ *                           calls, neighbor ids returned by those calls.
+ * Thread-safe on a shared index.                                                              */
+int granne_hip_search_batch(const granne_hip_index* index, const void* queries, uint32_t nq,
+                            uint32_t max_search, uint32_t num_neighbors, uint64_t* out_ids,
+                            float* out_dists, uint32_t* out_counts, uint64_t* out_stats);
+
+/* Device-resident variant: all pointers are device memory on the index's device; the work is
+ * enqueued on `stream` (a hipStream_t) and NOT synchronised. d_status (u32[1], optional) is set
+ * non-zero if any query exhausted the exact-search scratch (GRANNE_HIP_ERR_OVERFLOW).          */
+int granne_hip_search_batch_device(const granne_hip_index* index, const void* d_queries, uint32_t nq,
+                                   uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
+                                   float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
+                                   uint32_t* d_status, void* stream);
+
+/* Granne::search for one query (host pointers); *out_count results written. */
+int granne_hip_search(const granne_hip_index* index, const void* query, uint32_t max_search,
+                      uint32_t num_neighbors, uint64_t* out_ids, float* out_dists, uint32_t* out_count);
+
+/* ---- element preparation and the Dist / ElementContainer operators on device ------------------ */
+/* angular::Vector::from(Vec<f32>) over n rows, in place (src/math.rs:123-150). Device pointers. */
+int granne_hip_normalize_f32_device(float* d_rows, uint64_t n, uint32_t dim, int device_id, void* stream);
+/* angular_int::Vector::quantize over n rows (src/elements/angular_int.rs:27-45). */
+int granne_hip_quantize_f32_device(const float* d_rows, int8_t* d_out, uint64_t n, uint32_t dim,
+                                   int device_id, void* stream);
+/* ElementContainer::dist_to_element for explicit (query, element id) pairs
+ * (src/elements/dense_vector.rs:149-151): d_out[i] = dist(elements[d_ids[i]], queries[d_qidx[i]]). */
+int granne_hip_dist_pairs_device(const granne_hip_index* index, const void* d_queries,
+                                 const uint32_t* d_qidx, const uint32_t* d_ids, uint64_t n_pairs,
+                                 float* d_out, void* stream);
+/* Host conveniences over the two above (copy in, run, copy out). */
+int granne_hip_normalize_f32(float* rows, uint64_t n, uint32_t dim, int device_id);
+int granne_hip_quantize_f32(const float* rows, int8_t* out, uint64_t n, uint32_t dim, int device_id);
+int granne_hip_dist_pairs(const granne_hip_index* index, const void* queries, uint32_t nq,
+                          const uint32_t* qidx, const uint32_t* ids, uint64_t n_pairs, float* out);
+
+/* Synthetic element rows: component (row, col) = uniform [-0.5, 0.5) from a
+ * splitmix64 counter, the distribution of src/test_helper.rs:3-6. Device pointer out [n][dim]. */
+int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
+                                 int device_id, void* stream);
+
+/* ---- options (per index) ---------------------------------------------------------------------- */
+enum {
+    GRANNE_HIP_OPT_VISITED_SLOTS = 1, /* LDS visited-table slots per query, power of two; 0 = auto */
+    GRANNE_HIP_OPT_FORCE_SLOW = 2,    /* 1: route every query through the exact global-memory path */
+    GRANNE_HIP_OPT_SLOW_SLOTS = 3,    /* global visited/queue slots per slow-path query (pow2)      */
+    GRANNE_HIP_OPT_SLOW_BLOCKS = 4    /* concurrent slow-path walkers                               */
+};
+int granne_hip_index_set_option(granne_hip_index* index, int option, uint64_t value);
+int granne_hip_index_get_option(const granne_hip_index* index, int option, uint64_t* value);
+/* number of queries of the last search_batch (host variant) that took the slow exact path */
+uint64_t granne_hip_index_last_slow_count(const granne_hip_index* index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+"""CPU-side checks of the drop-in boundary: libgranne_hip.so builds for gfx950, loads, and exports
+exactly the symbols include/granne_hip.h declares. No compute is attempted without a GPU, and
+the library must refuse -- not fall back -- when no device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from granne_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_library()
+    return _lib.lib()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "granne_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(granne_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(lib):
+    declared = _declared()
+    assert len(declared) >= 25
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_every_declared_symbol_is_exported(lib):
+    raw = C.CDLL(build.LIB_PATH)
+    for name in _declared():
+        assert hasattr(raw, name), name
+
+
+def test_abi_version(lib):
+    assert lib.granne_hip_abi_version() == 1
+
+
+def test_library_contains_gfx950_code_object():
+    blob = open(build.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"search_kernel" in blob
+
+
+def _has_gpu(lib):
+    n = C.c_int(0)
+    lib.granne_hip_device_count(C.byref(n))
+    return n.value > 0
+
+
+def test_no_silent_cpu_fallback(lib):
+    """Without a GPU every entry point that would compute must fail with a device error."""
+    if _has_gpu(lib):
+        pytest.skip("a GPU is present; the failure path is for GPU-less hosts")
+    el = np.zeros((4, 8), np.float32)
+    h = C.c_void_p()
+    rc = lib.granne_hip_index_create(C.byref(h), el.ctypes.data_as(C.c_void_p), 4, 8, 0, 0, None, None, None, 0)
+    assert rc in (_lib.ERR_NO_DEVICE, _lib.ERR_HIP)
+    assert not h.value
+    assert lib.granne_hip_last_error()
+    rc = lib.granne_hip_normalize_f32(el.ctypes.data_as(C.c_void_p), 4, 8, 0)
+    assert rc in (_lib.ERR_NO_DEVICE, _lib.ERR_HIP)
+
+
+def test_argument_validation_needs_no_device(lib):
+    h = C.c_void_p()
+    el = np.zeros((4, 8), np.float32)
+    p = el.ctypes.data_as(C.c_void_p)
+    assert lib.granne_hip_index_create(None, p, 4, 8, 0, 0, None, None, None, 0) == _lib.ERR_INVALID
+    assert lib.granne_hip_index_create(C.byref(h), p, 4, 8, 7, 0, None, None, None, 0) == _lib.ERR_INVALID  # dtype
+    assert lib.granne_hip_index_create(C.byref(h), p, 4, 0, 0, 0, None, None, None, 0) == _lib.ERR_INVALID  # dim
+    lens = (C.c_uint64 * 2)(4, 2)  # not prefix-nested
+    assert lib.granne_hip_index_create(C.byref(h), p, 4, 8, 0, 2, lens, None, None, 0) == _lib.ERR_INVALID
+    assert b"prefix" in lib.granne_hip_last_error()
+    assert lib.granne_hip_search_batch(None, p, 1, 10, 1, p, p, p, None) == _lib.ERR_INVALID

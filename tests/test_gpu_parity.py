@@ -1,0 +1,363 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs. Bar: neighbor ids bit-exact, distances bit-exact (the f32 kernel keeps the
+reference's operation order), result order ascending by (dist, id), counters equal.
+
+Run on the MI355X box: python -m pytest tests -m gpu
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.conftest import random_floats  # noqa: E402
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import granne_amd
+    from granne_amd import _lib, build
+    assert os.path.exists(build.LIB_PATH), "libgranne_hip.so must be built in-tree (python -m granne_amd.build)"
+    _lib.lib()
+    return granne_amd
+
+
+def prep(oracle, raw, int8):
+    return oracle.quantize(raw) if int8 else oracle.normalize_f32(raw)
+
+
+def assert_same(oracle_index, gpu_index, queries, max_search, k, check_stats=True):
+    ids, ds, cnt, st = gpu_index.search_batch(queries, max_search, k, stats=True)
+    oi, od, oc, octr = oracle_index.search_batch(queries, max_search, k)
+    assert (cnt == oc).all(), (cnt, oc)
+    for i in range(len(queries)):
+        c = int(cnt[i])
+        assert ids[i, :c].tolist() == oi[i, :c].tolist(), (i, ids[i, :c], oi[i, :c])
+        assert ds[i, :c].tobytes() == od[i, :c].tobytes(), (i, ds[i, :c], od[i, :c])
+        assert (ids[i, c:] == np.iinfo(np.uint64).max).all() and np.isinf(ds[i, c:]).all()
+    if check_stats:
+        assert (st == octr).all()
+    return ids, ds, cnt
+
+
+# ---- element preparation and the Dist operator ---------------------------------------------------
+@pytest.mark.parametrize("dim", [1, 3, 25, 32, 100, 128, 200, 333])
+def test_normalize_bit_exact(ga, oracle, dim):
+    rng = np.random.default_rng(dim)
+    raw = random_floats(rng, 777, dim)
+    raw[5] = 0  # zero row stays zero (src/math.rs:134)
+    assert ga.normalize(raw).tobytes() == oracle.normalize_f32(raw).tobytes()
+
+
+@pytest.mark.parametrize("dim", [1, 3, 32, 100, 200, 333])
+def test_quantize_bit_exact(ga, oracle, dim):
+    rng = np.random.default_rng(1000 + dim)
+    raw = random_floats(rng, 500, dim)
+    raw[7] = 0
+    assert (ga.quantize(raw) == oracle.quantize(raw)).all()
+
+
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("dim", [3, 28, 100, 200, 257])
+def test_dist_operator_bit_exact(ga, oracle, int8, dim):
+    rng = np.random.default_rng(dim + 7 * int8)
+    el = prep(oracle, random_floats(rng, 300, dim), int8)
+    q = prep(oracle, random_floats(rng, 20, dim), int8)
+    ix = ga.Granne("angular_int" if int8 else "angular", el, [])
+    qi = rng.integers(0, 20, 2000)
+    ei = rng.integers(0, 300, 2000)
+    got = ix.dists(q, qi, ei)
+    want = np.array([oracle.dist(el[e], q[a]) for a, e in zip(qi, ei)], np.float32)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_synthetic_rows_match_oracle(ga, oracle):
+    import torch
+    from granne_amd import _lib
+    import ctypes as C
+    t = torch.empty((1000, 100), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().granne_hip_synth_rows_device(C.c_void_p(t.data_ptr()), 0x6772616E6E65, 17, 1000, 100, 0,
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert t.cpu().numpy().tobytes() == oracle.synth_rows(0x6772616E6E65, 17, 1000, 100).tobytes()
+
+
+def test_compute_distance(ga, oracle):
+    """py/src/lib.rs:58-86."""
+    rng = np.random.default_rng(3)
+    a, b = random_floats(rng, 100), random_floats(rng, 100)
+    assert ga.compute_distance("angular", a, b) == oracle.dist(oracle.normalize_f32(a), oracle.normalize_f32(b))
+    assert ga.compute_distance("angular_int", a, b) == oracle.dist(oracle.quantize(a), oracle.quantize(b))
+    with pytest.raises(ValueError):
+        ga.compute_distance("euclid", a, b)
+
+
+# ---- golden fixtures --------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_gpu_reproduces_golden(ga, path):
+    z = np.load(path)
+    layers = [z["layer%d" % l] for l in range(int(z["n_layers"]))]
+    et = "angular" if z["elements"].dtype == np.float32 else "angular_int"
+    ix = ga.Granne(et, z["elements"], layers)
+    assert len(ix) == layers[-1].shape[0] and ix.num_layers() == len(layers)
+    for key in [k for k in z.files if k.startswith("ids_")]:
+        ms, k = int(key.split("_")[1]), int(key.split("_")[2])
+        ids, ds, cnt, st = ix.search_batch(z["queries"], ms, k, stats=True)
+        assert (cnt == z["counts_%d_%d" % (ms, k)]).all()
+        want_ids, want_ds = z[key], z["dists_%d_%d" % (ms, k)]
+        for i in range(len(cnt)):
+            c = int(cnt[i])
+            assert ids[i, :c].tolist() == want_ids[i, :c].tolist()
+            assert ds[i, :c].tobytes() == want_ds[i, :c].tobytes()
+        assert (st == z["stats_%d_%d" % (ms, k)]).all()
+
+
+# ---- search parity on seeded random indexes ---------------------------------------------------------
+CASES = [
+    # n, dim, int8, num_neighbors, build max_search
+    (2000, 100, False, 30, 30),
+    (1200, 200, False, 30, 30),
+    (1500, 28, False, 20, 20),
+    (800, 24, False, 8, 20),
+    (600, 3, False, 10, 20),
+    (2000, 100, True, 30, 30),
+    (500, 32, True, 20, 20),
+    (700, 130, True, 12, 20),
+]
+
+
+@pytest.mark.parametrize("n,dim,int8,nn,ms", CASES)
+def test_search_parity(ga, oracle, n, dim, int8, nn, ms):
+    rng = np.random.default_rng(n + dim)
+    el = prep(oracle, random_floats(rng, n, dim), int8)
+    oix = oracle.build_index(el, num_neighbors=nn, max_search=ms, n_threads=4)
+    gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 64, dim), int8)
+    for max_search, k in [(1, 1), (7, 3), (50, 10), (64, 64), (65, 10), (128, 128), (200, 10), (256, 40)]:
+        assert_same(oix, gix, q, max_search, k)
+    # the elements themselves as queries (verify_search, src/index/tests.rs:50-62)
+    ids, _, _ = assert_same(oix, gix, el[:200], 20, 1)
+    assert (ids[:, 0] == np.arange(200)).mean() > 0.95
+
+
+def test_get_element_and_neighbors(ga, oracle):
+    rng = np.random.default_rng(5)
+    el = prep(oracle, random_floats(rng, 300, 20), False)
+    oix = oracle.build_index(el, num_neighbors=10, max_search=20)
+    gix = ga.Granne("angular", el, oix.layers)
+    assert len(gix) == 300 and gix.num_layers() == len(oix.layers)
+    for l, layer in enumerate(oix.layers):
+        assert gix.layer_len(l) == layer.shape[0]
+        for i in (0, layer.shape[0] - 1):
+            d = int((layer[i] != oracle.UNUSED).sum())
+            assert gix.get_neighbors(i, l) == layer[i, :d].tolist()
+    assert gix.get_neighbors(7) == oix.layers[-1][7, :int((oix.layers[-1][7] != oracle.UNUSED).sum())].tolist()
+    assert (gix.get_element(17) == el[17]).all()
+
+
+def test_raw_query_goes_through_vector_from(ga, oracle):
+    """py/src/variants/index.rs:8-17: the binding normalises/quantises the query first."""
+    rng = np.random.default_rng(6)
+    raw = random_floats(rng, 500, 32)
+    for int8 in (False, True):
+        el = prep(oracle, raw, int8)
+        oix = oracle.build_index(el, num_neighbors=10, max_search=20)
+        gix = ga.Granne("angular_int" if int8 else "angular", raw, oix.layers, prepared=False)
+        rq = random_floats(rng, 32)
+        assert gix.search(rq, 30, 5, prepared=False) == oix.search(prep(oracle, rq, int8), 30, 5)
+
+
+# ---- edge cases -------------------------------------------------------------------------------------
+def test_empty_index(ga):
+    ix = ga.Granne("angular", np.zeros((0, 8), np.float32), [])
+    assert len(ix) == 0 and ix.num_layers() == 0
+    assert ix.search(np.zeros(8, np.float32), 10, 5) == []  # src/index/mod.rs:978-980
+
+
+def test_one_and_two_elements(ga, oracle):
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3):
+        el = prep(oracle, random_floats(rng, n, 8), False)
+        oix = oracle.build_index(el)
+        gix = ga.Granne("angular", el, oix.layers)
+        q = prep(oracle, random_floats(rng, 4, 8), False)
+        assert_same(oix, gix, q, 5, 5)
+        assert_same(oix, gix, q, 1, 1)
+
+
+def test_max_search_zero_is_an_error(ga, oracle):
+    rng = np.random.default_rng(8)
+    el = prep(oracle, random_floats(rng, 50, 8), False)
+    gix = ga.Granne("angular", el, oracle.build_index(el).layers)
+    with pytest.raises(ga.GranneHipError) as e:
+        gix.search(el[0], 0, 1)
+    assert e.value.code == -1 and "max_search" in str(e.value)
+
+
+def test_k_larger_than_max_search_and_than_index(ga, oracle):
+    rng = np.random.default_rng(9)
+    el = prep(oracle, random_floats(rng, 40, 16), False)
+    oix = oracle.build_index(el, num_neighbors=6, max_search=10)
+    gix = ga.Granne("angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 8, 16), False)
+    ids, ds, cnt = assert_same(oix, gix, q, 5, 20)   # count = min(k, max_search)
+    assert (cnt == 5).all()
+    ids, ds, cnt = assert_same(oix, gix, q, 100, 100)  # count = reachable nodes
+    assert (cnt <= 40).all()
+
+
+def test_unindexed_zero_rows_and_partial_index(ga, oracle):
+    """Zero vectors keep all-UNUSED rows (src/index/mod.rs:813-815); Granne::len() may be smaller
+    than elements.len() (:76-83)."""
+    rng = np.random.default_rng(10)
+    el = prep(oracle, random_floats(rng, 400, 16), False)
+    el[[0, 50, 399]] = 0
+    oix = oracle.build_index(el, num_neighbors=8, max_search=20, num_elements=300)
+    assert len(oix) == 300
+    gix = ga.Granne("angular", el, oix.layers)
+    assert len(gix) == 300
+    q = prep(oracle, random_floats(rng, 16, 16), False)
+    assert_same(oix, gix, q, 20, 10)  # entry point 0 is itself a zero vector here
+
+
+def test_wide_rows_and_large_degree(ga, oracle):
+    """num_neighbors up to 254 is legal (u8 count in the file format); rows wider than a wave."""
+    rng = np.random.default_rng(11)
+    el = prep(oracle, random_floats(rng, 600, 12), False)
+    oix = oracle.build_index(el, num_neighbors=100, max_search=120, reinsert_elements=False)
+    assert max(int((l != oracle.UNUSED).sum(axis=1).max()) for l in oix.layers) > 64
+    gix = ga.Granne("angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 16, 12), False)
+    assert_same(oix, gix, q, 30, 10)
+
+
+def test_csr_layers_equal_fixed_width_layers(ga, oracle):
+    """Layers::Compressed (sorted ids, src/slice_vector/set_vector.rs:40-46) and Layers::FixWidth
+    search identically."""
+    rng = np.random.default_rng(12)
+    el = prep(oracle, random_floats(rng, 900, 20), False)
+    oix = oracle.build_index(el, num_neighbors=10, max_search=20)
+    offsets, ids = [], []
+    for layer in oix.layers:
+        deg = (layer != oracle.UNUSED).sum(axis=1)
+        offsets.append(np.concatenate([[0], np.cumsum(deg)]).astype(np.uint64))
+        ids.append(np.concatenate([np.sort(r[:d]) for r, d in zip(layer, deg)]).astype(np.uint32))
+    gix = ga.Granne.from_csr("angular", el, offsets, ids)
+    q = prep(oracle, random_floats(rng, 32, 20), False)
+    assert_same(oix, gix, q, 25, 10)
+
+
+# ---- the two hand-over conditions and the exact global-memory walker -------------------------------
+def test_slow_path_equals_fast_path(ga, oracle):
+    from granne_amd import _lib
+    rng = np.random.default_rng(13)
+    for int8 in (False, True):
+        el = prep(oracle, random_floats(rng, 1500, 100), int8)
+        oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
+        gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
+        q = prep(oracle, random_floats(rng, 40, 100), int8)
+        assert_same(oix, gix, q, 50, 10)
+        assert gix.last_slow_count() == 0
+        gix.set_option(_lib.OPT_FORCE_SLOW, 1)
+        assert_same(oix, gix, q, 50, 10)
+        assert gix.last_slow_count() == 40
+        assert_same(oix, gix, q, 300, 50)  # max_search > 256 always takes the exact walker
+        gix.set_option(_lib.OPT_FORCE_SLOW, 0)
+        assert_same(oix, gix, q, 300, 50)
+        assert gix.last_slow_count() == 40
+
+
+def test_visited_table_overflow_hands_over(ga, oracle):
+    from granne_amd import _lib
+    rng = np.random.default_rng(14)
+    el = prep(oracle, random_floats(rng, 3000, 32), False)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
+    gix = ga.Granne("angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 64, 32), False)
+    gix.set_option(_lib.OPT_VISITED_SLOTS, 256)  # far too small for max_search=100
+    assert_same(oix, gix, q, 100, 10)
+    assert gix.last_slow_count() > 0
+    gix.set_option(_lib.OPT_VISITED_SLOTS, 0)
+    assert_same(oix, gix, q, 100, 10)
+    assert gix.last_slow_count() == 0
+
+
+def test_slow_scratch_exhaustion_is_reported(ga, oracle):
+    from granne_amd import _lib
+    rng = np.random.default_rng(15)
+    el = prep(oracle, random_floats(rng, 3000, 16), False)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
+    gix = ga.Granne("angular", el, oix.layers)
+    gix.set_option(_lib.OPT_FORCE_SLOW, 1)
+    gix.set_option(_lib.OPT_SLOW_SLOTS, 256)
+    with pytest.raises(ga.GranneHipError) as e:
+        gix.search_batch(el[:8], 200, 10)
+    assert e.value.code == _lib.ERR_OVERFLOW
+    gix.set_option(_lib.OPT_SLOW_SLOTS, 1 << 16)
+    assert_same(oix, gix, el[:8], 200, 10)
+
+
+def test_exact_ties_from_duplicate_vectors(ga, oracle):
+    """Duplicated int8 rows produce exactly equal distances. The comparisons are asymmetric
+    (break on `>`, enqueue on `<`, replace on tuple `<`): every query must
+    still agree with the oracle, whichever walker ends up serving it."""
+    rng = np.random.default_rng(16)
+    base = oracle.quantize(random_floats(rng, 30, 16))
+    el = np.ascontiguousarray(base[rng.integers(0, 30, 2000)])
+    layer = np.full((2000, 32), oracle.UNUSED, np.uint32)
+    for i in range(2000):
+        layer[i, :24] = rng.choice(2000, 24, replace=False)
+    top = np.full((20, 32), oracle.UNUSED, np.uint32)
+    for i in range(20):
+        top[i, :5] = rng.choice(20, 5, replace=False)
+    oix = oracle.Index(el, [top, layer])
+    gix = ga.Granne("angular_int", el, [top, layer])
+    for ms, k in [(1, 1), (4, 4), (16, 16), (50, 10), (64, 64), (100, 100)]:
+        assert_same(oix, gix, base, ms, k)
+    # the same with float rows (exact duplicates -> exact ties)
+    fb = oracle.normalize_f32(random_floats(rng, 30, 100))
+    fel = np.ascontiguousarray(fb[rng.integers(0, 30, 2000)])
+    oix = oracle.Index(fel, [top, layer])
+    gix = ga.Granne("angular", fel, [top, layer])
+    for ms, k in [(1, 1), (16, 16), (50, 10), (100, 100)]:
+        assert_same(oix, gix, fb, ms, k)
+
+
+def test_large_batch_and_repeatability(ga, oracle):
+    rng = np.random.default_rng(17)
+    el = prep(oracle, random_floats(rng, 20000, 100), False)
+    oix = oracle.build_index(el, num_neighbors=30, max_search=40, reinsert_elements=False, n_threads=0)
+    gix = ga.Granne("angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 4096, 100), False)
+    a = assert_same(oix, gix, q, 50, 10)
+    b = gix.search_batch(q, 50, 10)
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+
+
+def test_device_resident_api(ga, oracle):
+    """granne_hip_search_batch_device with torch-owned buffers on torch's current stream."""
+    import torch
+    rng = np.random.default_rng(18)
+    el = prep(oracle, random_floats(rng, 5000, 100), False)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=20, reinsert_elements=False, n_threads=0)
+    gix = ga.Granne("angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 256, 100), False)
+    dq = torch.from_numpy(q).cuda()
+    ids = torch.empty((256, 10), dtype=torch.int64, device="cuda")
+    ds = torch.empty((256, 10), dtype=torch.float32, device="cuda")
+    cnt = torch.empty(256, dtype=torch.int32, device="cuda")
+    st = torch.empty((256, 3), dtype=torch.int64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gix.search_batch_device(dq.data_ptr(), 256, 50, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(),
+                            st.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    oi, od, oc, octr = oix.search_batch(q, 50, 10)
+    assert (ids.cpu().numpy().astype(np.uint64) == oi).all()
+    assert ds.cpu().numpy().tobytes() == od.tobytes()
+    assert (cnt.cpu().numpy().astype(np.uint32) == oc).all()
+    assert (st.cpu().numpy().astype(np.uint64) == octr).all()
+    assert int(status.item()) == 0
