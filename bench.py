@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""bench.py -- queries/sec of the MI355X Granne::search path on BASELINE.json's workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): 10M synthetic 100-d f32 angular vectors (uniform
+[-0.5,0.5) per component, then angular::Vector::from), HNSW graph with granne's structure built
+on the GPU (GranneBuilder mirror), batches of 1024 fresh queries, max_search (ef) = 50, k = 10.
+A "step" is ONE batch of 1024 queries through Granne::search on one GPU (one search_kernel
+launch); every step uses a different batch; queries, elements and graph are resident in HBM
+before the timed region. With N > 1 every rank holds a replica of the index on its own GPU and
+searches its own batches (the path shards by query: no data-path collective; scaling = weak).
+
+Rank 0 prints ONE JSON line. Besides the contract fields it carries
+  roofline      HBM roofline of the dominant kernel (search_kernel): algorithmic bytes per launch
+                (n_dist*d*s + 4*n_adj + d*s + 8*k per query, from the kernel's own
+                exact counters) / mean launch duration from HIP events on the launch stream
+  cpu_baseline  the CPU oracle (restatement of the reference's search, OpenMP over queries = the
+                caller-side rayon par_iter) timed on this box's host cores on a bounded sample of
+                the same batches, with the GPU results checked against it (ids + distances)
+  recall_at_10  against exact brute force on the first batch
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 0x6772616E6E65  # "granne"; queries use SEED + 1
+HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 measured copy ceiling
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=100)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "i8"])
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--ef", type=int, default=50)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--build-max-search", type=int, default=50)
+    ap.add_argument("--build-reinsert", type=int, default=0)
+    ap.add_argument("--num-neighbors", type=int, default=30)
+    ap.add_argument("--batch-max", type=int, default=65536)
+    ap.add_argument("--cpu-batches", type=int, default=16, help="batches of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--recall-ef", default="", help="extra comma-separated ef values to report recall/QPS for")
+    ap.add_argument("--no-recall", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import ctypes as C
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = local_rank
+
+    import granne_amd
+    from granne_amd import _lib
+    lib = _lib.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    sp = C.c_void_p(stream)
+
+    n, dim, nq, ef, k = args.n, args.dim, args.batch, args.ef, args.k
+    et = "angular" if args.dtype == "f32" else "angular_int"
+    esize = 4 if args.dtype == "f32" else 1
+
+    # ---- synthetic elements and queries, generated and prepared on the device -----------------
+    t0 = time.time()
+
+    def synth(seed, row0, rows):
+        raw = torch.empty((rows, dim), dtype=torch.float32, device="cuda")
+        _lib.check(lib.granne_hip_synth_rows_device(C.c_void_p(raw.data_ptr()), seed, row0, rows, dim, dev, sp))
+        if args.dtype == "f32":
+            _lib.check(lib.granne_hip_normalize_f32_device(C.c_void_p(raw.data_ptr()), rows, dim, dev, sp))
+            return raw
+        q = torch.empty((rows, dim), dtype=torch.int8, device="cuda")
+        _lib.check(lib.granne_hip_quantize_f32_device(C.c_void_p(raw.data_ptr()), C.c_void_p(q.data_ptr()), rows, dim,
+                                                      dev, sp))
+        return q
+
+    elements = synth(SEED, 0, n)
+    n_batches = args.warmup + args.steps
+    # every rank searches its own batches: rows [rank*n_batches*nq, ...) of the query stream
+    queries = synth(SEED + 1, rank * n_batches * nq, n_batches * nq)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+
+    # ---- graph: GranneBuilder on the GPU ----------------------------------------------------------
+    t0 = time.time()
+    builder = granne_amd.GranneBuilder.from_device(
+        et, elements.data_ptr(), n, dim, device=dev, stream=stream, num_neighbors=args.num_neighbors,
+        max_search=args.build_max_search, reinsert_elements=bool(args.build_reinsert), batch_max=args.batch_max,
+        show_progress=(rank == 0 and bool(os.environ.get("GRANNE_BENCH_VERBOSE"))))
+    builder.build()
+    index = builder.get_index()
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    layer_sizes = [builder.layer_len(l) for l in range(builder.num_layers())]
+    if rank == 0:
+        log("gen %.1fs, gpu build %.1fs, layers %s, index %.2f GB HBM" % (t_gen, t_build, layer_sizes,
+                                                                         index.hbm_bytes() / 1e9))
+
+    # ---- outputs ---------------------------------------------------------------------------------
+    ids = torch.empty((n_batches, nq, k), dtype=torch.int64, device="cuda")
+    dists = torch.empty((n_batches, nq, k), dtype=torch.float32, device="cuda")
+    counts = torch.empty((n_batches, nq), dtype=torch.int32, device="cuda")
+    stats = torch.zeros((n_batches, nq, 3), dtype=torch.int64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def step(b, ef_=None, out=None):
+        o_ids, o_d, o_c, o_s = out if out is not None else (ids[b], dists[b], counts[b], stats[b])
+        index.search_batch_device(queries[b * nq:(b + 1) * nq].data_ptr(), nq, ef_ or ef, k, o_ids.data_ptr(),
+                                  o_d.data_ptr(), o_c.data_ptr(), o_s.data_ptr(), status.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup, then EXACTLY K timed steps --------------------------------------------------------
+    for b in range(args.warmup):
+        step(b)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step(args.warmup + i)
+        ev[i][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if int(status.item()) != 0:
+        raise RuntimeError("exact-search scratch exhausted during the timed steps")
+
+    step_ms = [a.elapsed_time(b) for a, b in ev]  # HIP events on the launch stream
+    total_queries = world * args.steps * nq
+    value = total_queries / elapsed
+
+    # ---- roofline of the dominant kernel -----------------------------------------------------------
+    st = stats[args.warmup:].sum(dim=(0, 1)).cpu().numpy().astype(np.float64)  # n_dist, n_expand, n_adj
+    alg_bytes_total = st[0] * dim * esize + st[2] * 4 + args.steps * nq * (dim * esize + k * 8)
+    alg_bytes_per_launch = alg_bytes_total / args.steps
+    mean_launch_ms = float(np.mean(step_ms))
+    achieved = alg_bytes_per_launch / (mean_launch_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "search_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "alg_bytes_per_launch": int(alg_bytes_per_launch), "launch_ms_mean": round(mean_launch_ms, 4),
+        "launch_ms_min": round(float(np.min(step_ms)), 4),
+        "per_query": {"n_dist": round(st[0] / (args.steps * nq), 1), "n_expand": round(st[1] / (args.steps * nq), 1),
+                      "n_adj": round(st[2] / (args.steps * nq), 1)},
+    }
+
+    out = {
+        "metric": "queries/sec (recall@10 alongside), 10M x 100-d angular, batch=1024",
+        "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {
+            "workload": "C2: %d x %d-d %s angular (BASELINE.json configs[1]), batch=%d, ef_search=%d, k=%d"
+                        % (n, dim, args.dtype, nq, ef, k),
+            "n_elements": n, "dim": dim, "batch": nq, "ef_search": ef, "k": k, "layers": layer_sizes,
+            "graph": {"builder": "gpu-batched", "num_neighbors": args.num_neighbors,
+                      "max_search": args.build_max_search, "reinsert": bool(args.build_reinsert),
+                      "layer_multiplier": 15.0, "batch_max": args.batch_max, "build_s": round(t_build, 1)},
+            "parallelism": "replica x%d (one process per GPU, no data-path collective)" % world,
+        },
+        "roofline": roofline,
+    }
+
+    # ---- rank 0, N = 1: recall and the CPU baseline --------------------------------------------------
+    if rank == 0:
+        b0 = args.warmup
+        if not args.no_recall:
+            q0 = queries[b0 * nq:(b0 + 1) * nq].float()
+            best_v = torch.full((nq, k), -3.0e38, device="cuda")
+            best_i = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+            chunk = 1_000_000
+            for c0 in range(0, n, chunk):
+                e = elements[c0:c0 + chunk].float()
+                if args.dtype == "i8":  # cosine on the quantised rows
+                    e = e / e.norm(dim=1, keepdim=True).clamp_min(1e-30)
+                sim = q0 @ e.T
+                v, i = sim.topk(k, dim=1)
+                cat_v = torch.cat([best_v, v], 1)
+                cat_i = torch.cat([best_i, i + c0], 1)
+                best_v, sel = cat_v.topk(k, dim=1)
+                best_i = cat_i.gather(1, sel)
+            gt = best_i.cpu().numpy()
+
+            def recall_of(id_tensor):
+                got = id_tensor.cpu().numpy()
+                return float(np.mean([len(set(gt[i]) & set(got[i])) / k for i in range(nq)]))
+
+            out["recall_at_10"] = round(recall_of(ids[b0]), 4)
+            sweeps = []
+            for e_ in [int(x) for x in args.recall_ef.split(",") if x]:
+                o = (torch.empty_like(ids[0]), torch.empty_like(dists[0]), torch.empty_like(counts[0]),
+                     torch.zeros_like(stats[0]))
+                step(b0, e_, o)
+                torch.cuda.synchronize()
+                a, bb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for j in range(args.steps):
+                    step(args.warmup + j, e_, o)
+                bb.record()
+                torch.cuda.synchronize()
+                step(b0, e_, o)
+                torch.cuda.synchronize()
+                sweeps.append({"ef": e_, "recall_at_10": round(recall_of(o[0]), 4),
+                               "qps": round(args.steps * nq / (a.elapsed_time(bb) * 1e-3), 1)})
+            if sweeps:
+                out["ef_sweep"] = sweeps
+
+        if world == 1 and args.cpu_batches > 0:
+            # the ONLY use of oracle/ in this file: the CPU baseline + parity check
+            from oracle import oracle as orc
+            orc.build()
+            t0 = time.time()
+            h_el = elements.cpu().numpy()
+            h_layers = builder.layers()
+            oix = orc.Index(h_el, h_layers)
+            nb = min(args.cpu_batches, args.steps)
+            h_q = queries[b0 * nq:(b0 + nb) * nq].cpu().numpy()
+            threads = args.cpu_threads or (os.cpu_count() or 1)
+            oix.search_batch(h_q[:nq], ef, k, n_threads=threads)  # touch pages / spin up threads
+            t1 = time.time()
+            o_ids, o_d, o_c, o_ctr = oix.search_batch(h_q, ef, k, n_threads=threads)
+            cpu_s = time.time() - t1
+            g_ids = ids[b0:b0 + nb].reshape(-1, k).cpu().numpy().astype(np.uint64)
+            g_d = dists[b0:b0 + nb].reshape(-1, k).cpu().numpy()
+            ids_ok = bool((g_ids == o_ids).all())
+            d_ok = g_d.tobytes() == o_d.tobytes()
+            out["cpu_baseline"] = {
+                "value": round(nb * nq / cpu_s, 1), "unit": "queries/s", "cores": threads, "kind": "port",
+                "sample": "%d batches x %d queries of the timed workload, same index; oracle/granne_oracle.c "
+                          "(C restatement of the reference's search; Rust toolchain absent), OpenMP dynamic over "
+                          "queries; %.2f s wall (+%.1f s to copy index to host)" % (nb, nq, cpu_s, t1 - t0),
+                "gpu_matches_oracle": {"ids_bit_exact": ids_ok, "dists_bit_exact": bool(d_ok),
+                                       "queries_checked": int(nb * nq)},
+            }
+            out["speedup_vs_cpu"] = round(value / (nb * nq / cpu_s), 2)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

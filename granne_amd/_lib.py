@@ -21,6 +21,20 @@ class GranneHipError(RuntimeError):
         self.code = code
 
 
+class BuildConfig(C.Structure):
+    """granne_hip_build_config (include/granne_hip.h) = BuildConfig (src/index/mod.rs:198-231)."""
+    _fields_ = [
+        ("layer_multiplier", C.c_float),
+        ("expected_num_elements", C.c_uint64),
+        ("num_neighbors", C.c_uint32),
+        ("max_search", C.c_uint32),
+        ("reinsert_elements", C.c_int),
+        ("show_progress", C.c_int),
+        ("batch_max", C.c_uint32),
+        ("batch_div", C.c_uint32),
+    ]
+
+
 _lib = None
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
@@ -53,6 +67,17 @@ SIGNATURES = {
     "granne_hip_quantize_f32": (i32, [vp, vp, u64, u32, i32]),
     "granne_hip_dist_pairs": (i32, [vp, vp, u32, vp, vp, u64, vp]),
     "granne_hip_synth_rows_device": (i32, [vp, u64, u64, u64, u32, i32, vp]),
+    "granne_hip_build_config_default": (None, [vp]),
+    "granne_hip_builder_create": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, i32]),
+    "granne_hip_builder_create_device": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, i32, vp]),
+    "granne_hip_builder_build": (i32, [vp, u64]),
+    "granne_hip_builder_len": (u64, [vp]),
+    "granne_hip_builder_num_elements": (u64, [vp]),
+    "granne_hip_builder_num_layers": (u32, [vp]),
+    "granne_hip_builder_layer_len": (u64, [vp, u32]),
+    "granne_hip_builder_get_layer": (i32, [vp, u32, vp]),
+    "granne_hip_builder_get_index": (i32, [vp, C.POINTER(vp)]),
+    "granne_hip_builder_destroy": (None, [vp]),
     "granne_hip_index_set_option": (i32, [vp, i32, u64]),
     "granne_hip_index_get_option": (i32, [vp, i32, C.POINTER(u64)]),
     "granne_hip_index_last_slow_count": (u64, [vp]),
@@ -67,6 +92,13 @@ def lib():
         if not os.path.exists(path):
             raise GranneHipError(ERR_NO_DEVICE, "libgranne_hip.so is not built: run `python -m granne_amd.build` "
                                  "(no CPU fallback exists)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64. If torch is
+        # importable, load it first so that libgranne_hip.so binds to the same runtime (two
+        # runtimes in one process leave the second without devices).
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol

@@ -1,0 +1,409 @@
+// builder_kernels.h -- device side of the batched HNSW builder (GranneBuilder on the GPU).
+//
+// Restates /root/reference/src/index/mod.rs:805-960 (index_element, select_neighbors,
+// initialize_node, connect_nodes, add_and_limit_neighbors) under the BATCHED schedule that
+// oracle/granne_oracle.h documents at gro_build_config.batch_max:
+//   phase A  every member of a batch searches the frozen graph (search_kernel.h, the same
+//            kernel Granne::search uses) and runs select_neighbors       -> select_kernel
+//   phase B  the link updates of the whole batch are turned into (target row, order) keyed ops,
+//            radix-sorted, and each target row replays its ops in the order the sequential
+//            phase B would have issued them                               -> apply_kernel
+//   finally  every row is re-limited to the layer's num_neighbors          -> final_prune_kernel
+// One wavefront owns one node / target row. All distances use the exact routines of dist.h, so
+// a build is a deterministic function of (elements, config) and equals the oracle's batched
+// build bit for bit (tests/test_gpu_builder.py).
+#pragma once
+
+#include "dist.h"
+#include "search_kernel.h"
+#include "wave_prims.h"
+
+namespace granne_hip {
+
+constexpr uint64_t OP_INVALID = ~0ull;
+// op key = target row : 32 | position in batch : 20 | phase (0 own forward, 1 reverse) : 1 | k : 8
+__host__ __device__ inline uint64_t op_key(uint32_t target, uint32_t p, uint32_t phase, uint32_t k) {
+    return ((uint64_t)target << 29) | ((uint64_t)p << 9) | ((uint64_t)phase << 8) | (uint64_t)k;
+}
+__host__ __device__ inline uint32_t op_target(uint64_t key) { return (uint32_t)(key >> 29); }
+__host__ __device__ inline uint32_t op_pos(uint64_t key) { return (uint32_t)(key >> 9) & 0xFFFFFu; }
+__host__ __device__ inline uint32_t op_phase(uint64_t key) { return (uint32_t)(key >> 8) & 1u; }
+constexpr int OP_KEY_BITS = 61;
+constexpr uint32_t BUILD_MAX_NEIGHBORS = 63; // one lane per neighbor, +1 for the extra candidate
+constexpr uint32_t BUILD_MAX_CAND = 256;     // search candidates per element (max_search <= 256)
+constexpr uint32_t BUILD_CHUNK = 32;         // candidate rows staged per gather round
+constexpr float EPS100 = 100.0f * 1.1920929e-07f; // 100.0 * f32::EPSILON (mod.rs:813, 829)
+
+struct BuildParams {
+    const uint8_t* elements;
+    uint32_t row_bytes, dim, lrow; // lrow: LDS row stride (odd multiple of 16 bytes)
+    uint32_t* adj;                 // the layer being built: [len][W]
+    uint32_t W;                    // device row width
+    uint32_t cap;                  // logical row capacity = BuildConfig.num_neighbors (node.len())
+    uint32_t m_layer;              // num_neighbors used for this layer (halved above the bottom)
+    uint64_t layer_len;
+    // phase A
+    int64_t first_idx, idx_step;   // batch member t is element first_idx + t * idx_step
+    uint32_t batch;
+    uint32_t efc;                  // stride of the search outputs
+    const uint64_t* s_ids;
+    const float* s_dists;
+    const uint32_t* s_counts;
+    uint64_t* op_keys;             // [batch * cap * 2]
+    uint64_t* op_vals;
+    // phase B
+    const uint64_t* sorted_keys;
+    const uint64_t* sorted_vals;
+    uint32_t n_ops;
+    uint32_t* seg_start;
+    uint32_t* n_seg;
+};
+
+// LDS carve-up shared by the three kernels
+struct BuildLds {
+    uint8_t* qrow;    // [lrow]
+    uint8_t* chunk;   // [BUILD_CHUNK][lrow]
+    uint8_t* selrows; // [cap][lrow]
+    uint32_t* cid;    // [BUILD_MAX_CAND]
+    float* cd;        // [BUILD_MAX_CAND]
+    uint32_t* sid;    // [64]
+    float* sd;        // [64]
+    uint32_t* cur;    // [64]
+    uint32_t* slot;   // [64]
+};
+__host__ __device__ inline uint32_t build_lds_bytes(uint32_t lrow, uint32_t cap) {
+    return lrow * (1 + BUILD_CHUNK + cap) + BUILD_MAX_CAND * 8 + 64 * 4 * 4;
+}
+
+template <int DT, int DIM>
+struct RowWork {
+    const BuildParams& P;
+    BuildLds L;
+    uint32_t lane;
+
+    __device__ __forceinline__ RowWork(const BuildParams& p, uint8_t* smem) : P(p) {
+        lane = threadIdx.x;
+        L.qrow = smem;
+        L.chunk = smem + p.lrow;
+        L.selrows = L.chunk + (size_t)BUILD_CHUNK * p.lrow;
+        uint8_t* a = L.selrows + (size_t)p.cap * p.lrow;
+        L.cid = reinterpret_cast<uint32_t*>(a);
+        L.cd = reinterpret_cast<float*>(a + BUILD_MAX_CAND * 4);
+        a += BUILD_MAX_CAND * 8;
+        L.sid = reinterpret_cast<uint32_t*>(a);
+        L.sd = reinterpret_cast<float*>(a + 256);
+        L.cur = reinterpret_cast<uint32_t*>(a + 512);
+        L.slot = reinterpret_cast<uint32_t*>(a + 768);
+    }
+
+    // copy one element row into LDS (zero padded device row)
+    __device__ __forceinline__ void load_row(uint8_t* dst, uint32_t id) {
+        const uint32_t row16 = P.row_bytes >> 4;
+        const uint8_t* src = P.elements + (size_t)id * P.row_bytes;
+        for (uint32_t u = lane; u < row16; u += 64)
+            *reinterpret_cast<uint4*>(dst + (size_t)u * 16) = *reinterpret_cast<const uint4*>(src + (size_t)u * 16);
+    }
+    // copy a row LDS -> LDS
+    __device__ __forceinline__ void copy_row(uint8_t* dst, const uint8_t* src) {
+        const uint32_t row16 = P.row_bytes >> 4;
+        for (uint32_t u = lane; u < row16; u += 64)
+            *reinterpret_cast<uint4*>(dst + (size_t)u * 16) = *reinterpret_cast<const uint4*>(src + (size_t)u * 16);
+    }
+    // gather rows ids[0..n) (n <= BUILD_CHUNK, ids in LDS) into the chunk stage
+    __device__ __forceinline__ void gather_chunk(const uint32_t* ids, uint32_t n) {
+        const uint32_t row16 = P.row_bytes >> 4;
+        const uint32_t lrow16 = P.lrow >> 4;
+        const uint32_t total = n * row16;
+        for (uint32_t f0 = 0; f0 < total; f0 += 64 * 4) {
+            uint4 v0, v1, v2, v3;
+            uint32_t d0, d1, d2, d3;
+#define GRANNE_BGATHER(U, V, D)                                                                           \
+    {                                                                                                     \
+        uint32_t f = f0 + (U) * 64u + lane;                                                               \
+        uint32_t fc = f < total ? f : total - 1u;                                                         \
+        uint32_t row;                                                                                     \
+        if constexpr (DIM > 0 && DT == DT_F32) row = fc / (uint32_t)(DIM / 4);                            \
+        else row = fc / row16;                                                                            \
+        uint32_t part = fc - row * row16;                                                                 \
+        V = *reinterpret_cast<const uint4*>(P.elements + (size_t)ids[row] * P.row_bytes + (size_t)part * 16); \
+        D = f < total ? (row * lrow16 + part) * 16u : 0xFFFFFFFFu;                                        \
+    }
+            GRANNE_BGATHER(0, v0, d0)
+            GRANNE_BGATHER(1, v1, d1)
+            GRANNE_BGATHER(2, v2, d2)
+            GRANNE_BGATHER(3, v3, d3)
+#undef GRANNE_BGATHER
+            if (d0 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(L.chunk + d0) = v0;
+            if (d1 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(L.chunk + d1) = v1;
+            if (d2 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(L.chunk + d2) = v2;
+            if (d3 != 0xFFFFFFFFu) *reinterpret_cast<uint4*>(L.chunk + d3) = v3;
+        }
+    }
+
+    // exact distance between two LDS rows (one lane)
+    __device__ __forceinline__ float dist_lds(const uint8_t* x, const uint8_t* y) {
+        if constexpr (DT == DT_F32) {
+            float r;
+            if constexpr (DIM > 0) r = dot_f32_exact<DIM>(reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(y));
+            else r = dot_f32_exact_rt(reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(y), P.dim);
+            return angular_from_dot(r);
+        } else {
+            const uint32_t row16 = P.row_bytes >> 4;
+            int r = 0, dx = 0, dy = 0;
+            for (uint32_t u = 0; u < row16; ++u) {
+                uint4 a = *reinterpret_cast<const uint4*>(x + (size_t)u * 16);
+                uint4 b = *reinterpret_cast<const uint4*>(y + (size_t)u * 16);
+                r = dot4_i8(a.x, b.x, r); r = dot4_i8(a.y, b.y, r); r = dot4_i8(a.z, b.z, r); r = dot4_i8(a.w, b.w, r);
+                dx = dot4_i8(a.x, a.x, dx); dx = dot4_i8(a.y, a.y, dx); dx = dot4_i8(a.z, a.z, dx); dx = dot4_i8(a.w, a.w, dx);
+                dy = dot4_i8(b.x, b.x, dy); dy = dot4_i8(b.y, b.y, dy); dy = dot4_i8(b.z, b.z, dy); dy = dot4_i8(b.w, b.w, dy);
+            }
+            return angular_int_from_sums(r, dx, dy);
+        }
+    }
+
+    // select_neighbors (mod.rs:849-883). Candidates cid/cd[0..n) sorted ascending. If `preloaded`,
+    // candidate j's row already sits in chunk[slot[j]] (n <= BUILD_CHUNK). Result in sid/sd.
+    __device__ __forceinline__ uint32_t select_neighbors(uint32_t n, uint32_t max_neighbors, bool preloaded) {
+        if (n <= max_neighbors) { // :854-856
+            if (lane < n) {
+                L.sid[lane] = L.cid[lane];
+                L.sd[lane] = L.cd[lane];
+            }
+            __syncthreads();
+            return n;
+        }
+        uint32_t nsel = 0;
+        for (uint32_t c0 = 0; c0 < n && nsel < max_neighbors; c0 += BUILD_CHUNK) {
+            const uint32_t cn = min(BUILD_CHUNK, n - c0);
+            if (!preloaded) {
+                __syncthreads();
+                gather_chunk(L.cid + c0, cn);
+                if (lane < cn) L.slot[c0 + lane] = lane;
+                __syncthreads();
+            }
+            for (uint32_t j = c0; j < c0 + cn && nsel < max_neighbors; ++j) { // :866-881
+                const float dj = L.cd[j];
+                const uint8_t* rj = L.chunk + (size_t)L.slot[preloaded ? j : j] * P.lrow;
+                bool bad = false;
+                if (lane < nsel) {
+                    float dd = dist_lds(L.selrows + (size_t)lane * P.lrow, rj); // dist_to_element(n, &element_j)
+                    bad = !(dj <= dd);
+                }
+                if (wave_ballot(bad) == 0) {
+                    copy_row(L.selrows + (size_t)nsel * P.lrow, rj);
+                    if (lane == 0) {
+                        L.sid[nsel] = L.cid[j];
+                        L.sd[nsel] = dj;
+                    }
+                    nsel += 1;
+                    __syncthreads();
+                }
+            }
+            if (preloaded) break; // a preloaded set is one chunk
+        }
+        __syncthreads();
+        return nsel;
+    }
+
+    // add_and_limit_neighbors (mod.rs:923-959) on the row held in L.cur[0..c): optional extra
+    // candidate (ex_id, ex_d). qrow must hold the node's own element. Returns the new count.
+    __device__ __forceinline__ uint32_t add_and_limit(uint32_t c, bool has_extra, uint32_t ex_id, float ex_d,
+                                                      uint32_t num_neighbors) {
+        const uint32_t n = c + (has_extra ? 1u : 0u);
+        // elements.dists(node_id, &neighbors), :938 -- candidate rows go through the chunk stage
+        float d = 0.0f;
+        uint32_t id = ID_EMPTY;
+        if (lane < c) id = L.cur[lane];
+        if (has_extra && lane == c) { id = ex_id; d = ex_d; }
+        __syncthreads();
+        if (lane < n) L.cid[lane] = id; // unsorted for now: gather source
+        __syncthreads();
+        const bool one_chunk = n <= BUILD_CHUNK;
+        for (uint32_t c0 = 0; c0 < n; c0 += BUILD_CHUNK) {
+            const uint32_t cn = min(BUILD_CHUNK, n - c0);
+            gather_chunk(L.cid + c0, cn);
+            __syncthreads();
+            if (lane >= c0 && lane < c0 + cn && lane < c)
+                d = dist_lds(L.qrow, L.chunk + (size_t)(lane - c0) * P.lrow); // element(node).dist(element(j))
+            __syncthreads();
+        }
+        // sort by (d, id), :943 (ties by id: the reference's unstable sort leaves them unspecified)
+        const uint64_t key = (lane < n) ? make_key(d, id) : KEY_INF;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += (readlane64(key, j) < key) ? 1u : 0u;
+        if (lane < n) {
+            L.cid[rank] = id;
+            L.cd[rank] = d;
+            L.slot[rank] = lane; // where this candidate's row sits when everything fits one chunk
+        }
+        __syncthreads();
+        const uint32_t ns = select_neighbors(n, num_neighbors, one_chunk); // :947
+        if (lane < 64) L.cur[lane] = (lane < ns) ? L.sid[lane] : ID_EMPTY;  // :950-958
+        __syncthreads();
+        return ns;
+    }
+};
+
+// ---- phase A tail: filter, select_neighbors, dead-node rule, emit ops (mod.rs:813-845) ------------
+template <int DT, int DIM>
+__global__ __launch_bounds__(64) void select_kernel(const BuildParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    RowWork<DT, DIM> w(P, smem);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t t = blockIdx.x;
+    if (t >= P.batch) return;
+    const uint32_t idx = (uint32_t)(P.first_idx + (int64_t)t * P.idx_step);
+
+    w.load_row(w.L.qrow, idx);
+    __syncthreads();
+    // do not index elements that are zero, :813-815
+    float dself = 0.0f;
+    if (lane == 0) dself = w.dist_lds(w.L.qrow, w.L.qrow);
+    const bool skip = __uint_as_float(readlane32(__float_as_uint(dself), 0)) > EPS100;
+
+    uint32_t nsel = 0;
+    if (!skip) {
+        // candidates.filter(id != idx), :822
+        const uint32_t cnt = min(P.s_counts[t], BUILD_MAX_CAND);
+        uint32_t m = 0;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            uint32_t i = base + lane;
+            uint32_t id = ID_EMPTY;
+            float d = 0.0f;
+            if (i < cnt) {
+                id = (uint32_t)P.s_ids[(size_t)t * P.efc + i];
+                d = P.s_dists[(size_t)t * P.efc + i];
+            }
+            bool keep = (i < cnt) && id != idx;
+            uint64_t km = wave_ballot(keep);
+            uint32_t pos = m + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+            if (keep) {
+                w.L.cid[pos] = id;
+                w.L.cd[pos] = d;
+            }
+            m += (uint32_t)__popcll(km);
+        }
+        __syncthreads();
+        nsel = w.select_neighbors(m, P.m_layer, false); // :824
+        // duplicates rule, :828-832
+        const uint32_t half = P.m_layer / 2;
+        if (half < nsel && w.L.sd[half] < EPS100) nsel = 0;
+    }
+    // link updates of this element as ops: own row first (:834-841), then the reverse links (:843-845)
+    for (uint32_t k = lane; k < P.cap; k += 64) {
+        size_t o = ((size_t)t * P.cap + k) * 2;
+        if (k < nsel) {
+            uint32_t nb = w.L.sid[k];
+            uint64_t dbits = (uint64_t)__float_as_uint(w.L.sd[k]);
+            P.op_keys[o] = op_key(idx, t, 0, k);
+            P.op_vals[o] = ((uint64_t)nb << 32) | dbits;
+            P.op_keys[o + 1] = op_key(nb, t, 1, k);
+            P.op_vals[o + 1] = ((uint64_t)idx << 32) | dbits;
+        } else {
+            P.op_keys[o] = OP_INVALID;
+            P.op_vals[o] = 0;
+            P.op_keys[o + 1] = OP_INVALID;
+            P.op_vals[o + 1] = 0;
+        }
+    }
+}
+
+// segment heads of the sorted op list (one segment per target row)
+__global__ void mark_heads_kernel(const uint64_t* __restrict__ keys, uint32_t n_ops, uint32_t* __restrict__ seg_start,
+                                  uint32_t* __restrict__ n_seg) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_ops; i += gridDim.x * blockDim.x) {
+        uint64_t k = keys[i];
+        if (k == OP_INVALID) continue;
+        if (i == 0 || op_target(keys[i - 1]) != op_target(k)) seg_start[atomicAdd(n_seg, 1u)] = i;
+    }
+}
+
+// ---- phase B: replay one target row's ops in order (initialize_node / connect_nodes) --------------
+template <int DT, int DIM>
+__global__ __launch_bounds__(64) void apply_kernel(const BuildParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    RowWork<DT, DIM> w(P, smem);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_seg = *P.n_seg;
+    for (uint32_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+        uint32_t i = P.seg_start[seg];
+        const uint32_t t = op_target(P.sorted_keys[i]);
+        uint32_t* row = P.adj + (size_t)t * P.W;
+        __syncthreads();
+        uint32_t nb = (lane < P.W) ? row[lane] : ID_EMPTY;
+        uint64_t un = wave_ballot(nb == ID_EMPTY);
+        uint32_t c = un ? (uint32_t)__builtin_ctzll(un) : 64u;
+        w.L.cur[lane] = (lane < c) ? nb : ID_EMPTY;
+        bool qloaded = false;
+        __syncthreads();
+
+        while (i < P.n_ops) {
+            const uint64_t key = P.sorted_keys[i];
+            if (key == OP_INVALID || op_target(key) != t) break;
+            const uint64_t val = P.sorted_vals[i];
+            const uint32_t other = (uint32_t)(val >> 32);
+            const float d = __uint_as_float((uint32_t)val);
+            if (op_phase(key) == 0 && (key & 0xFF) == 0 && c == 0) {
+                // initialize_node, :886-896: the whole own-forward group of this source at once
+                const uint32_t p0 = op_pos(key);
+                while (i < P.n_ops) {
+                    const uint64_t k2 = P.sorted_keys[i];
+                    if (k2 == OP_INVALID || op_target(k2) != t || op_phase(k2) != 0 || op_pos(k2) != p0) break;
+                    if (c < P.cap) {
+                        if (lane == 0) w.L.cur[c] = (uint32_t)(P.sorted_vals[i] >> 32);
+                        c += 1;
+                    }
+                    i += 1;
+                }
+                __syncthreads();
+                continue;
+            }
+            // connect_nodes(t <- other, d), :898-921
+            if (other != t) {
+                uint32_t v = (lane < c) ? w.L.cur[lane] : ID_EMPTY;
+                uint64_t found = wave_ballot(lane < c && v == other);
+                uint32_t pos = found ? (uint32_t)__builtin_ctzll(found) : c; // first UNUSED or j_id, :912
+                if (pos < P.cap) {
+                    if (pos == c) {
+                        if (lane == 0) w.L.cur[c] = other;
+                        c += 1;
+                        __syncthreads();
+                    }
+                } else {
+                    if (!qloaded) {
+                        w.load_row(w.L.qrow, t);
+                        qloaded = true;
+                        __syncthreads();
+                    }
+                    c = w.add_and_limit(c, true, other, d, P.cap); // num_neighbors = node.len(), :916-917
+                }
+            }
+            i += 1;
+        }
+        __syncthreads();
+        if (lane < P.W) row[lane] = (lane < c) ? w.L.cur[lane] : ID_EMPTY;
+    }
+}
+
+// ---- the final pass of index_elements (mod.rs:795-797): limit every row to num_neighbors ----------
+template <int DT, int DIM>
+__global__ __launch_bounds__(64) void final_prune_kernel(const BuildParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    RowWork<DT, DIM> w(P, smem);
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t t = blockIdx.x; t < P.layer_len; t += gridDim.x) {
+        uint32_t* row = P.adj + (size_t)t * P.W;
+        __syncthreads();
+        uint32_t nb = (lane < P.W) ? row[lane] : ID_EMPTY;
+        uint64_t un = wave_ballot(nb == ID_EMPTY);
+        uint32_t c = un ? (uint32_t)__builtin_ctzll(un) : 64u;
+        if (c == 0) continue; // nothing to sort or limit; row stays all-UNUSED
+        w.L.cur[lane] = (lane < c) ? nb : ID_EMPTY;
+        w.load_row(w.L.qrow, (uint32_t)t);
+        __syncthreads();
+        c = w.add_and_limit(c, false, 0, 0.0f, P.m_layer);
+        if (lane < P.W) row[lane] = (lane < c) ? w.L.cur[lane] : ID_EMPTY;
+    }
+}
+
+} // namespace granne_hip

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -425,6 +426,38 @@ extern "C" uint64_t granne_hip_index_last_slow_count(const granne_hip_index* ix)
 // ------------------------------------------------------------------------------------------------
 // search
 // ------------------------------------------------------------------------------------------------
+// what a search launch needs to know about the graph it walks (an index, or a builder's layers)
+struct SearchTarget {
+    int device;
+    const uint8_t* d_elements;
+    uint64_t n_elements;
+    uint32_t dim;
+    int dtype;
+    uint32_t row_bytes;
+    const LayerDev* d_layers;
+    uint32_t n_layers;
+    uint32_t max_dev_width;
+    uint64_t opt_visited_slots, opt_force_slow, opt_slow_slots, opt_slow_blocks;
+};
+
+static SearchTarget target_of(const granne_hip_index* ix) {
+    SearchTarget T;
+    T.device = ix->device;
+    T.d_elements = ix->d_elements;
+    T.n_elements = ix->n_elements;
+    T.dim = ix->dim;
+    T.dtype = ix->dtype;
+    T.row_bytes = ix->row_bytes;
+    T.d_layers = ix->d_layers;
+    T.n_layers = (uint32_t)ix->layers.size();
+    T.max_dev_width = ix->max_dev_width;
+    T.opt_visited_slots = ix->opt_visited_slots;
+    T.opt_force_slow = ix->opt_force_slow;
+    T.opt_slow_slots = ix->opt_slow_slots;
+    T.opt_slow_blocks = ix->opt_slow_blocks;
+    return T;
+}
+
 typedef void (*search_fn)(const SearchParams);
 
 template <int DT, int DIM>
@@ -447,13 +480,16 @@ struct LaunchPlan {
     uint32_t visited_slots, upper_slots, maxc, lrow_bytes, lds_bytes;
 };
 
-// LDS budget: four walkers per CU (one per SIMD) when it fits: 160 KiB / 4
-static LaunchPlan plan_launch(const granne_hip_index* ix, uint32_t ef) {
+// LDS plan. The visited table dominates; the f32 stage gets what keeps four walkers per CU
+// (160 KiB / 4) when that leaves it at least 16 rows, else up to 32 rows within 64 KiB, else
+// whatever fits in the CU's 160 KiB. GRANNE_HIP_MAXC overrides the stage rows (experiments).
+static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef) {
     LaunchPlan P;
     uint32_t want = ix->opt_visited_slots ? (uint32_t)ix->opt_visited_slots : next_pow2(ef * 128u);
-    if (want > 16384 && !ix->opt_visited_slots) want = 16384;
-    if (want < 1024 && !ix->opt_visited_slots) want = 1024;
-    if (want > 32768) want = 32768;
+    if (!ix->opt_visited_slots) {
+        if (want < 1024) want = 1024;
+        if (want > 16384) want = 16384;
+    }
     P.visited_slots = want;
     P.upper_slots = want < 1024 ? want : 1024;
     uint32_t fixed = lds_query_bytes(ix->row_bytes) + 512;
@@ -461,18 +497,17 @@ static LaunchPlan plan_launch(const granne_hip_index* ix, uint32_t ef) {
         uint32_t row16 = ix->row_bytes / 16;
         P.lrow_bytes = (row16 | 1u) * 16u; // odd number of 16-byte units: conflict-free ds_read_b128
         uint32_t wmax = ix->max_dev_width < 64 ? ix->max_dev_width : 64;
-        uint32_t budget = 40u * 1024u;
         uint32_t used = fixed + P.visited_slots * 4u;
-        uint32_t avail = budget > used ? budget - used : 0;
-        uint32_t maxc = avail / P.lrow_bytes;
+        auto rows_in = [&](uint32_t budget) { return budget > used ? (budget - used) / P.lrow_bytes : 0u; };
+        uint32_t maxc = rows_in(40u * 1024u);
+        if (maxc < 16) maxc = rows_in(64u * 1024u) < 32u ? rows_in(64u * 1024u) : 32u;
+        if (maxc < 16) maxc = rows_in(160u * 1024u) < 32u ? rows_in(160u * 1024u) : 32u;
         if (maxc > wmax) maxc = wmax;
-        if (maxc < 8) { // do not starve the stage: take what a lone walker may use
-            uint32_t hard = 64u * 1024u;
-            avail = hard > used ? hard - used : 0;
-            maxc = avail / P.lrow_bytes;
-            if (maxc > 8) maxc = 8;
-            if (maxc < 1) maxc = 1;
+        if (const char* e = getenv("GRANNE_HIP_MAXC")) {
+            uint32_t v = (uint32_t)atoi(e);
+            if (v >= 1 && v <= 64) maxc = v;
         }
+        if (maxc < 1) maxc = 1;
         P.maxc = maxc;
     } else {
         P.maxc = 0;
@@ -482,10 +517,9 @@ static LaunchPlan plan_launch(const granne_hip_index* ix, uint32_t ef) {
     return P;
 }
 
-static int search_device_impl(const granne_hip_index* ix, const void* d_queries, uint32_t nq, uint32_t ef, uint32_t k,
-                              uint64_t* d_ids, float* d_dists, uint32_t* d_counts, uint64_t* d_stats,
-                              uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */) {
-    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t q_stride, uint32_t nq, uint32_t ef,
+                         uint32_t k, uint64_t* d_ids, float* d_dists, uint32_t* d_counts, uint64_t* d_stats,
+                         uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */) {
     if (ef == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
     if (nq == 0) return GRANNE_HIP_OK;
     if (k == 0) return fail(GRANNE_HIP_ERR_INVALID, "num_neighbors must be > 0");
@@ -515,8 +549,9 @@ static int search_device_impl(const granne_hip_index* ix, const void* d_queries,
     p.dim = ix->dim;
     p.row_bytes = ix->row_bytes;
     p.layers = ix->d_layers;
-    p.n_layers = (uint32_t)ix->layers.size();
+    p.n_layers = ix->n_layers;
     p.queries = (const uint8_t*)d_queries;
+    p.q_stride = q_stride;
     p.nq = nq;
     p.ef = ef;
     p.k = k;
@@ -545,6 +580,7 @@ static int search_device_impl(const granne_hip_index* ix, const void* d_queries,
     sp.res = (uint64_t*)(scratch + off_res);
     sp.slots = slots;
     sp.status = ((uint32_t*)scratch) + 1;
+    sp.status2 = d_status;
     uint32_t slow_lds = lds_query_bytes(ix->row_bytes) + 64 * 8;
     if (ix->dtype == GRANNE_HIP_F32)
         hipLaunchKernelGGL(slow_kernel<DT_F32>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
@@ -552,7 +588,6 @@ static int search_device_impl(const granne_hip_index* ix, const void* d_queries,
         hipLaunchKernelGGL(slow_kernel<DT_I8>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
     HIP_TRY(hipGetLastError());
 
-    if (d_status) HIP_TRY(hipMemcpyAsync(d_status, sp.status, 4, hipMemcpyDeviceToDevice, s));
     if (h_slow_count) {
         uint32_t hs[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(hs, scratch, 8, hipMemcpyDeviceToHost, s));
@@ -568,8 +603,10 @@ extern "C" int granne_hip_search_batch_device(const granne_hip_index* ix, const 
                                               uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
                                               float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
                                               uint32_t* d_status, void* stream) {
-    return search_device_impl(ix, d_queries, nq, max_search, num_neighbors, d_out_ids, d_out_dists, d_out_counts,
-                              d_out_stats, d_status, (hipStream_t)stream, nullptr);
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    SearchTarget T = target_of(ix);
+    return search_launch(&T, d_queries, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
+                         d_out_ids, d_out_dists, d_out_counts, d_out_stats, d_status, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int granne_hip_search_batch(const granne_hip_index* ix, const void* queries, uint32_t nq, uint32_t max_search,
@@ -599,8 +636,10 @@ extern "C" int granne_hip_search_batch(const granne_hip_index* ix, const void* q
         HIP_TRY(hipMalloc((void**)&buf, total));
         HIP_TRY(hipMemcpyAsync(buf + o_q, queries, qb, hipMemcpyHostToDevice, s));
         uint32_t slow[2] = {0, 0};
-        int r = search_device_impl(ix, buf + o_q, nq, max_search, num_neighbors, (uint64_t*)(buf + o_ids),
-                                   (float*)(buf + o_d), (uint32_t*)(buf + o_c), (uint64_t*)(buf + o_s), nullptr, s, slow);
+        SearchTarget T = target_of(ix);
+        int r = search_launch(&T, buf + o_q, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
+                              (uint64_t*)(buf + o_ids), (float*)(buf + o_d), (uint32_t*)(buf + o_c),
+                              (uint64_t*)(buf + o_s), nullptr, s, slow);
         if (r) return r;
         const_cast<granne_hip_index*>(ix)->last_slow_count.store(slow[0]);
         if (slow[1]) return fail(GRANNE_HIP_ERR_OVERFLOW, "exact-search scratch exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)");
@@ -759,3 +798,8 @@ extern "C" int granne_hip_dist_pairs(const granne_hip_index* ix, const void* que
     freeall();
     return rc;
 }
+
+// ------------------------------------------------------------------------------------------------
+// GranneBuilder on the GPU
+// ------------------------------------------------------------------------------------------------
+#include "builder_host.h"

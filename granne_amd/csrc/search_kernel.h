@@ -41,7 +41,8 @@ struct SearchParams {
     uint32_t row_bytes;      // multiple of 16
     const LayerDev* layers;
     uint32_t n_layers;
-    const uint8_t* queries;  // dense [nq][dim] scalars
+    const uint8_t* queries;  // query i starts at queries + i * q_stride (dim scalars each)
+    int64_t q_stride;        // bytes; dense batches: dim * sizeof(scalar); may be negative
     uint32_t nq;
     uint32_t ef;             // max_search
     uint32_t k;              // num_neighbors
@@ -101,11 +102,11 @@ struct Walker {
     // stage the query in LDS, zero padded to row_bytes
     __device__ __forceinline__ void load_query(uint32_t qi) {
         if (DT == DT_F32) {
-            const float* q = reinterpret_cast<const float*>(p.queries) + (size_t)qi * p.dim;
+            const float* q = reinterpret_cast<const float*>(p.queries + (int64_t)qi * p.q_stride);
             float* l = reinterpret_cast<float*>(lds_q);
             for (uint32_t i = lane; i < p.row_bytes / 4; i += 64) l[i] = (i < p.dim) ? q[i] : 0.0f;
         } else {
-            const int8_t* q = reinterpret_cast<const int8_t*>(p.queries) + (size_t)qi * p.dim;
+            const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
             int8_t* l = reinterpret_cast<int8_t*>(lds_q);
             int part = 0;
             for (uint32_t i = lane; i < p.row_bytes; i += 64) {

@@ -20,6 +20,7 @@ struct SlowParams {
     uint64_t* res;   // [blocks][ef]      max-heap of keys
     uint32_t slots;  // power of two
     uint32_t* status;// set to 1 when a walk exhausts `slots`
+    uint32_t* status2; // caller's copy of the same flag (optional)
 };
 
 // binary heaps over u64 keys, run by one lane
@@ -109,11 +110,11 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
         // query to LDS
         int dy = 0;
         if (DT == DT_F32) {
-            const float* q = reinterpret_cast<const float*>(p.queries) + (size_t)qi * p.dim;
+            const float* q = reinterpret_cast<const float*>(p.queries + (int64_t)qi * p.q_stride);
             float* l = reinterpret_cast<float*>(lds_q);
             for (uint32_t i = lane; i < p.row_bytes / 4; i += 64) l[i] = (i < p.dim) ? q[i] : 0.0f;
         } else {
-            const int8_t* q = reinterpret_cast<const int8_t*>(p.queries) + (size_t)qi * p.dim;
+            const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
             int8_t* l = reinterpret_cast<int8_t*>(lds_q);
             int part = 0;
             for (uint32_t i = lane; i < p.row_bytes; i += 64) {
@@ -231,7 +232,10 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
         // output: ascending (dist, id) = repeatedly take the max of `res` from the back
         uint32_t count = 0;
         if (overflow) {
-            if (lane == 0) atomicExch(P.status, 1u);
+            if (lane == 0) {
+                atomicExch(P.status, 1u);
+                if (P.status2) atomicExch(P.status2, 1u);
+            }
         } else if (p.n_layers > 0) {
             if (lane == 0) {
                 // heap-sort in place: res[0..n_res) ascending

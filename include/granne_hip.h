@@ -121,8 +121,8 @@ int granne_hip_search_batch(const granne_hip_index* index, const void* queries, 
                             float* out_dists, uint32_t* out_counts, uint64_t* out_stats);
 
 /* Device-resident variant: all pointers are device memory on the index's device; the work is
- * enqueued on `stream` (a hipStream_t) and NOT synchronised. d_status (u32[1], optional) is set
- * non-zero if any query exhausted the exact-search scratch (GRANNE_HIP_ERR_OVERFLOW).          */
+ * enqueued on `stream` (a hipStream_t) and NOT synchronised. d_status (u32[1], optional, zeroed by
+ * the caller) is set to 1 if any query exhausted the exact-search scratch (GRANNE_HIP_ERR_OVERFLOW).          */
 int granne_hip_search_batch_device(const granne_hip_index* index, const void* d_queries, uint32_t nq,
                                    uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
                                    float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
@@ -153,6 +153,55 @@ int granne_hip_dist_pairs(const granne_hip_index* index, const void* queries, ui
  * splitmix64 counter, the distribution of src/test_helper.rs:3-6. Device pointer out [n][dim]. */
 int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
                                  int device_id, void* stream);
+
+/* ---- GranneBuilder on the GPU ------------------------------------------------------------------
+ * Mirrors GranneBuilder / BuildConfig / Builder (src/index/mod.rs:198-531): the same layer
+ * pyramid (compute_num_elements_in_layer :634-643), the same per-element work (index_element
+ * :805-846 = entry search + search_for_neighbors at the build max_search -- the SAME kernel
+ * Granne::search runs -- + select_neighbors :849-883 + connect_nodes/add_and_limit_neighbors
+ * :898-959 + the final per-row limit :795-797), with every distance bit-exact. What differs is
+ * the SCHEDULE: the reference inserts with a rayon par_iter over per-node RwLocks (:757-782,
+ * nondeterministic); this builder inserts in batches -- every member of a batch searches the
+ * graph as it stood when the batch began, then the batch's link updates are applied in element
+ * order. Batch = clamp(nodes_in_graph / batch_div, 1, batch_max). The result is deterministic. */
+typedef struct granne_hip_builder granne_hip_builder;
+
+typedef struct {
+    float layer_multiplier;         /* 15.0  (BuildConfig::default, src/index/mod.rs:220-231) */
+    uint64_t expected_num_elements; /* 0 = None */
+    uint32_t num_neighbors;         /* 30; at most 63 on the GPU */
+    uint32_t max_search;            /* 200; at most 256 stays on the fast search path */
+    int reinsert_elements;          /* 1 */
+    int show_progress;              /* 0 */
+    uint32_t batch_max;             /* 0 = default (65536); at most 2^20 */
+    uint32_t batch_div;             /* 0 = default (8) */
+} granne_hip_build_config;
+
+void granne_hip_build_config_default(granne_hip_build_config* config);
+
+/* GranneBuilder::new(config, elements): elements are host rows [n][dim], prepared like a
+ * Vectors file (normalised f32 / quantised i8); copied to HBM. */
+int granne_hip_builder_create(granne_hip_builder** out, const granne_hip_build_config* config,
+                              const void* elements, uint64_t n_elements, uint32_t dim, int dtype,
+                              int device_id);
+/* Same with elements already in device memory (dense [n][dim]). */
+int granne_hip_builder_create_device(granne_hip_builder** out, const granne_hip_build_config* config,
+                                     const void* d_elements, uint64_t n_elements, uint32_t dim, int dtype,
+                                     int device_id, void* stream);
+/* Builder::build_partial(num_elements) (src/index/mod.rs:374-402); num_elements == 0 means
+ * Builder::build() = all elements. Synchronous. */
+int granne_hip_builder_build(granne_hip_builder* builder, uint64_t num_elements);
+uint64_t granne_hip_builder_len(const granne_hip_builder* builder);          /* indexed elements */
+uint64_t granne_hip_builder_num_elements(const granne_hip_builder* builder);
+uint32_t granne_hip_builder_num_layers(const granne_hip_builder* builder);
+uint64_t granne_hip_builder_layer_len(const granne_hip_builder* builder, uint32_t layer);
+/* copies layer `layer` as a host [layer_len][num_neighbors] u32 matrix, UNUSED padded: the
+ * FixedWidthSliceVector<u32> the reference's builder holds (src/index/mod.rs:300) */
+int granne_hip_builder_get_layer(const granne_hip_builder* builder, uint32_t layer, uint32_t* out_rows);
+/* GranneBuilder::get_index (src/index/mod.rs:483-488): a searchable index over the current
+ * layers (device-to-device copy; the builder stays usable). */
+int granne_hip_builder_get_index(const granne_hip_builder* builder, granne_hip_index** out);
+void granne_hip_builder_destroy(granne_hip_builder* builder);
 
 /* ---- options (per index) ---------------------------------------------------------------------- */
 enum {

@@ -523,6 +523,8 @@ void gro_build_config_default(gro_build_config* cfg) { /* mod.rs:220-231 */
     cfg->max_search = 200;
     cfg->reinsert_elements = 1;
     cfg->n_threads = 1;
+    cfg->batch_max = 0;
+    cfg->batch_div = 8;
 }
 
 gro_builder* gro_builder_create(const gro_build_config* cfg, const void* elements, uint64_t n_elements,
@@ -660,12 +662,14 @@ static void connect_nodes(const gro_builder* b, uint32_t* rows, uint32_t width, 
     if (locks) node_unlock(&locks[i]);
 }
 
-/* index_element, mod.rs:805-846 */
-static void index_element(const gro_builder* b, const gro_build_config* config, const gro_index* prev,
-                          uint32_t* rows, uint32_t width, uint64_t layer_len, volatile unsigned char* locks,
-                          uint64_t idx, scratch_t* S) {
+/* index_element, mod.rs:805-846, split in two so that the batched schedule can reuse it:
+ * phase A = everything up to the dead-node rule (reads the graph), phase B = the link updates. */
+static size_t index_element_select(const gro_builder* b, const gro_build_config* config, const gro_index* prev,
+                                   uint32_t* rows, uint32_t width, uint64_t layer_len,
+                                   volatile unsigned char* locks, uint64_t idx, scratch_t* S, uint64_t** out_ids,
+                                   float** out_d) {
     const float EPS100 = 100.0f * 1.1920929e-07f; /* 100.0 * f32::EPSILON */
-    if (bdist(b, idx, idx) > EPS100) return;     /* zero vectors, :813-815 */
+    if (bdist(b, idx, idx) > EPS100) return 0;   /* zero vectors, :813-815 */
     const void* element = row_ptr(b->elements, b->dim, b->dtype, idx);
 
     /* prev_layers.search(&element, 1, 1).first().map_or(0, |r| r.0), :819 */
@@ -706,8 +710,19 @@ static void index_element(const gro_builder* b, const gro_build_config* config, 
 
     /* duplicate ("dead node") rule, :828-832 */
     size_t half = config->num_neighbors / 2;
-    if (half < nsel && nd[half] < EPS100) return;
+    if (half < nsel && nd[half] < EPS100) return 0;
+    *out_ids = nid;
+    *out_d = nd;
+    return nsel;
+}
 
+static void index_element_apply(const gro_builder* b, uint32_t* rows, uint32_t width, volatile unsigned char* locks,
+                                uint64_t idx, const uint64_t* nid, const float* nd, size_t nsel) {
+    if (nsel == 0) {
+        /* the reference still runs the (empty) loops; an empty selection leaves the row as is,
+         * except that an empty row is "initialised" with nothing. Either way: no change. */
+        return;
+    }
     uint32_t* node = rows + idx * width;
     int empty;
     if (locks) node_lock(&locks[idx]);
@@ -720,6 +735,64 @@ static void index_element(const gro_builder* b, const gro_build_config* config, 
         for (size_t k = 0; k < nsel; ++k) connect_nodes(b, rows, width, locks, idx, nid[k], nd[k]); /* :838-840 */
     }
     for (size_t k = 0; k < nsel; ++k) connect_nodes(b, rows, width, locks, nid[k], idx, nd[k]); /* :843-845 */
+}
+
+static void index_element(const gro_builder* b, const gro_build_config* config, const gro_index* prev,
+                          uint32_t* rows, uint32_t width, uint64_t layer_len, volatile unsigned char* locks,
+                          uint64_t idx, scratch_t* S) {
+    uint64_t* nid = NULL;
+    float* nd = NULL;
+    size_t nsel = index_element_select(b, config, prev, rows, width, layer_len, locks, idx, S, &nid, &nd);
+    index_element_apply(b, rows, width, locks, idx, nid, nd, nsel);
+}
+
+/* The batched schedule (see gro_build_config.batch_max). */
+static void index_elements_batched(gro_builder* b, const gro_build_config* config, const gro_index* prev,
+                                   uint32_t* rows, uint32_t width, uint64_t layer_len, uint64_t already_indexed,
+                                   int reinsert) {
+    int nt = config->n_threads <= 0 ? gro_max_threads() : config->n_threads;
+    uint64_t total = reinsert ? layer_len : layer_len - already_indexed;
+    uint32_t nn = config->num_neighbors;
+    uint64_t bmax = config->batch_max;
+    uint64_t* sel_ids = (uint64_t*)malloc(sizeof(uint64_t) * bmax * nn);
+    float* sel_d = (float*)malloc(sizeof(float) * bmax * nn);
+    uint32_t* sel_n = (uint32_t*)malloc(sizeof(uint32_t) * bmax);
+    uint64_t pos = 0;
+    while (pos < total) {
+        uint64_t n_in_graph = reinsert ? layer_len : already_indexed + pos;
+        uint64_t B = n_in_graph / (config->batch_div ? config->batch_div : 1);
+        if (B < 1) B = 1;
+        if (B > bmax) B = bmax;
+        if (B > total - pos) B = total - pos;
+        /* phase A: graph frozen */
+#pragma omp parallel num_threads(nt)
+        {
+            scratch_t S;
+            memset(&S, 0, sizeof(S));
+#pragma omp for schedule(dynamic, 16)
+            for (long long t = 0; t < (long long)B; ++t) {
+                uint64_t idx = reinsert ? (layer_len - 1 - (pos + (uint64_t)t)) : (already_indexed + pos + (uint64_t)t);
+                uint64_t* nid = NULL;
+                float* nd = NULL;
+                size_t ns = index_element_select(b, config, prev, rows, width, layer_len, NULL, idx, &S, &nid, &nd);
+                sel_n[t] = (uint32_t)ns;
+                for (size_t k = 0; k < ns; ++k) {
+                    sel_ids[(uint64_t)t * nn + k] = nid[k];
+                    sel_d[(uint64_t)t * nn + k] = nd[k];
+                }
+            }
+            scratch_free(&S);
+        }
+        /* phase B: apply in batch order */
+        for (uint64_t t = 0; t < B; ++t) {
+            uint64_t idx = reinsert ? (layer_len - 1 - (pos + t)) : (already_indexed + pos + t);
+            index_element_apply(b, rows, width, NULL, idx, sel_ids + t * nn, sel_d + t * nn, sel_n[t]);
+        }
+        pos += B;
+    }
+    free(sel_ids);
+    free(sel_d);
+    free(sel_n);
 }
 
 /* index_elements, mod.rs:715-802 */
@@ -738,7 +811,13 @@ static void index_elements(gro_builder* b, const gro_build_config* config, uint6
     uint64_t layer_len = *len_p;
     int nt = config->n_threads <= 0 ? gro_max_threads() : config->n_threads;
 
-    if (nt == 1) { /* feature "singlethreaded": sequential, deterministic, :771-782 */
+    if (config->batch_max > 0) {
+        index_elements_batched(b, config, prev, rows, width, layer_len, already_indexed, reinsert);
+#pragma omp parallel for num_threads(nt) schedule(dynamic, 256)
+        for (long long t = 0; t < (long long)layer_len; ++t) /* :795-797 */
+            add_and_limit_neighbors(b, rows + (uint64_t)t * width, width, (uint64_t)t, NULL, 0,
+                                    config->num_neighbors);
+    } else if (nt == 1) { /* feature "singlethreaded": sequential, deterministic, :771-782 */
         scratch_t S;
         memset(&S, 0, sizeof(S));
         if (reinsert) {

@@ -90,6 +90,16 @@ typedef struct {
     uint32_t max_search;        /* 200 */
     int reinsert_elements;      /* 1 */
     int n_threads;              /* 1 = feature "singlethreaded" order (deterministic) */
+    /* batch_max > 0 selects the BATCHED insertion schedule of the GPU builder
+     * (granne_amd/csrc/builder.hip) instead of the reference's sequential / rayon schedule:
+     * ids are taken in the reference's order in batches of clamp(n_in_graph / batch_div, 1,
+     * batch_max); every member of a batch runs index_element's search + select_neighbors
+     * against the graph as it was when the batch started, then the link updates
+     * (initialize_node / connect_nodes) are applied in batch order. Deterministic for any
+     * n_threads. The per-element arithmetic is the reference's, only the schedule differs
+     * (the reference's own rayon schedule is nondeterministic, src/index/mod.rs:771-782). */
+    uint32_t batch_max;
+    uint32_t batch_div;
 } gro_build_config;
 
 void gro_build_config_default(gro_build_config* cfg); /* src/index/mod.rs:220-231 */

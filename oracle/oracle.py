@@ -46,6 +46,8 @@ class _BuildConfig(C.Structure):
         ("max_search", C.c_uint32),
         ("reinsert_elements", C.c_int),
         ("n_threads", C.c_int),
+        ("batch_max", C.c_uint32),
+        ("batch_div", C.c_uint32),
     ]
 
 
@@ -246,7 +248,7 @@ class Index:
 
 
 def build_index(elements, num_neighbors=30, max_search=200, layer_multiplier=15.0, reinsert_elements=True,
-                expected_num_elements=0, n_threads=1, num_elements=None):
+                expected_num_elements=0, n_threads=1, num_elements=None, batch_max=0, batch_div=8):
     """GranneBuilder::new(config, elements).build() -> get_index() (src/index/mod.rs:364-488).
     n_threads=1 is the reference's `singlethreaded` feature: deterministic insertion order."""
     elements = np.ascontiguousarray(elements)
@@ -258,6 +260,8 @@ def build_index(elements, num_neighbors=30, max_search=200, layer_multiplier=15.
     cfg.max_search = max_search
     cfg.reinsert_elements = int(bool(reinsert_elements))
     cfg.n_threads = n_threads
+    cfg.batch_max = batch_max
+    cfg.batch_div = batch_div
     b = lib().gro_builder_create(C.byref(cfg), _p(elements), elements.shape[0], elements.shape[1],
                                  _dtype_code(elements))
     try:

@@ -1,0 +1,125 @@
+"""GPU GranneBuilder: bit-exact against the oracle's batched build (same schedule, same
+arithmetic), and the reference's own quality bar (verify_search, src/index/tests.rs:50-62)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.conftest import random_floats  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ga():
+    import granne_amd
+    return granne_amd
+
+
+def prep(oracle, raw, int8):
+    return oracle.quantize(raw) if int8 else oracle.normalize_f32(raw)
+
+
+CASES = [
+    # n, dim, int8, num_neighbors, max_search, reinsert, batch_max
+    (1500, 28, False, 20, 20, True, 64),
+    (3000, 100, False, 30, 40, True, 256),
+    (2500, 100, False, 30, 50, False, 4096),
+    (1200, 200, False, 16, 30, True, 128),
+    (500, 32, True, 20, 20, True, 64),
+    (3000, 100, True, 30, 40, False, 512),
+    (700, 3, False, 10, 20, True, 32),
+    (40, 16, False, 30, 200, True, 65536),
+]
+
+
+@pytest.mark.parametrize("n,dim,int8,nn,ms,reinsert,bmax", CASES)
+def test_gpu_build_equals_oracle_batched_build(ga, oracle, n, dim, int8, nn, ms, reinsert, bmax):
+    rng = np.random.default_rng(n * 7 + dim)
+    el = prep(oracle, random_floats(rng, n, dim), int8)
+    b = ga.GranneBuilder("angular_int" if int8 else "angular", el, num_neighbors=nn, max_search=ms,
+                         reinsert_elements=reinsert, batch_max=bmax, batch_div=8)
+    b.build()
+    assert len(b) == n and b.num_elements() == n
+    oix = oracle.build_index(el, num_neighbors=nn, max_search=ms, reinsert_elements=reinsert, batch_max=bmax,
+                             batch_div=8, n_threads=0)
+    assert b.num_layers() == len(oix.layers)
+    for l, want in enumerate(oix.layers):
+        got = b.get_layer(l)
+        assert got.shape == want.shape
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (l, bad[:5], got[bad[:1]], want[bad[:1]])
+    # and the index it hands out searches like the oracle's
+    gix = b.get_index()
+    q = prep(oracle, random_floats(rng, 16, dim), int8)
+    ids, ds, cnt = gix.search_batch(q, 30, 10)
+    oi, od, oc, _ = oix.search_batch(q, 30, 10)
+    assert (ids == oi).all() and ds.tobytes() == od.tobytes() and (cnt == oc).all()
+
+
+def test_duplicates_and_zero_vectors(ga, oracle):
+    """dead-node rule (src/index/mod.rs:828-832) and zero-vector rule (:813-815)."""
+    rng = np.random.default_rng(3)
+    base = oracle.normalize_f32(random_floats(rng, 100, 24))
+    el = np.ascontiguousarray(np.concatenate([base, base[:30], base[:30], base[:30], base[:30], base[:30]]))
+    el[7] = 0
+    b = ga.GranneBuilder("angular", el, num_neighbors=6, max_search=20, batch_max=16)
+    b.build()
+    oix = oracle.build_index(el, num_neighbors=6, max_search=20, batch_max=16, n_threads=0)
+    for l, want in enumerate(oix.layers):
+        assert (b.get_layer(l) == want).all()
+    assert (b.get_layer(b.num_layers() - 1)[7] == 0xFFFFFFFF).all()
+
+
+def test_build_partial_then_more(ga, oracle):
+    """build_partial (src/index/mod.rs:374-402), cf. incremental_build tests (index/tests.rs:134-242)."""
+    rng = np.random.default_rng(4)
+    el = prep(oracle, random_floats(rng, 1000, 16), False)
+    b = ga.GranneBuilder("angular", el, num_neighbors=10, max_search=20, batch_max=64)
+    b.build(100)
+    assert len(b) == 100 and b.num_elements() == 1000
+    b.build(100)
+    assert len(b) == 100
+    b.build()
+    assert len(b) == 1000
+    sizes = [b.layer_len(l) for l in range(b.num_layers())]
+    assert sizes == [oracle.num_elements_in_layer(1000, 15.0, l) for l in range(len(sizes))]
+    with pytest.raises(ga.GranneHipError):
+        b.build(10)  # "Cannot index fewer elements than already in index."
+    gix = b.get_index()
+    found = sum(gix.search(el[i], 30, 1)[0][0] == i for i in range(0, 1000, 5))
+    assert found / 200 > 0.95
+
+
+def test_gpu_build_meets_the_reference_quality_bar(ga, oracle):
+    """build_and_search_float (src/index/tests.rs:114-121) on the GPU builder's default schedule."""
+    rng = np.random.default_rng(5)
+    el = prep(oracle, random_floats(rng, 1500, 28), False)
+    b = ga.GranneBuilder("angular", el, num_neighbors=20, max_search=20)
+    b.build()
+    gix = b.get_index()
+    ids, _, _ = gix.search_batch(el, 10, 1)
+    assert (ids[:, 0] == np.arange(1500)).mean() > 0.95
+
+
+def test_append_then_build(ga, oracle):
+    rng = np.random.default_rng(6)
+    raw = random_floats(rng, 300, 12)
+    b = ga.GranneBuilder("angular", None, num_neighbors=8, max_search=20, prepared=False)
+    for r in raw:
+        b.append(r)
+    assert b.num_elements() == 300 and len(b) == 0  # py/README: not indexed until build()
+    b.build()
+    assert len(b) == 300
+    el = oracle.normalize_f32(raw)
+    oix = oracle.build_index(el, num_neighbors=8, max_search=20, batch_max=65536, n_threads=0)
+    for l, want in enumerate(oix.layers):
+        assert (b.get_layer(l) == want).all()
+
+
+def test_invalid_configs(ga):
+    el = np.zeros((10, 8), np.float32)
+    with pytest.raises(ga.GranneHipError):
+        ga.GranneBuilder("angular", el, num_neighbors=64).build()
+    with pytest.raises(ga.GranneHipError):
+        ga.GranneBuilder("angular", el, max_search=0).build()
+    with pytest.raises(ValueError):
+        ga.GranneBuilder("cosine", el)

@@ -264,3 +264,26 @@ def test_synth_rows_are_reproducible_and_in_range(oracle):
     assert (a[32:] == b).all()
     assert a.min() >= -0.5 and a.max() < 0.5
     assert abs(float(a.mean())) < 0.02
+
+
+# ---- the batched insertion schedule (what the GPU builder implements) ---------------------------
+@pytest.mark.parametrize("int8", [False, True])
+def test_batched_build_meets_the_reference_bar(oracle, int8):
+    """Same quality bar as the reference's build tests (src/index/tests.rs:41-62) under the
+    batched schedule; deterministic whatever the thread count."""
+    rng = np.random.default_rng(40 + int8)
+    e = random_vectors(oracle, rng, 1500 if not int8 else 500, 28 if not int8 else 32, int8=int8)
+    a = oracle.build_index(e, num_neighbors=20, max_search=20, batch_max=64, n_threads=1)
+    b = oracle.build_index(e, num_neighbors=20, max_search=20, batch_max=64, n_threads=4)
+    assert all((x == y).all() for x, y in zip(a.layers, b.layers))
+    verify_search(a, 0.95, 10)
+    sizes = [l.shape[0] for l in a.layers]
+    assert sizes == [oracle.num_elements_in_layer(len(e), 15.0, l) for l in range(len(sizes))]
+
+
+def test_batched_build_with_batch_of_one_is_the_sequential_build(oracle):
+    rng = np.random.default_rng(42)
+    e = random_vectors(oracle, rng, 700, 20)
+    a = oracle.build_index(e, num_neighbors=10, max_search=20, n_threads=1)
+    b = oracle.build_index(e, num_neighbors=10, max_search=20, batch_max=1)
+    assert all((x == y).all() for x, y in zip(a.layers, b.layers))
