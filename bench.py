@@ -252,11 +252,19 @@ def main():
             oix = orc.Index(h_el, h_layers)
             nb = min(args.cpu_batches, args.steps)
             h_q = queries[b0 * nq:(b0 + nb) * nq].cpu().numpy()
-            threads = args.cpu_threads or (os.cpu_count() or 1)
-            oix.search_batch(h_q[:nq], ef, k, n_threads=threads)  # touch pages / spin up threads
-            t1 = time.time()
-            o_ids, o_d, o_c, o_ctr = oix.search_batch(h_q, ef, k, n_threads=threads)
-            cpu_s = time.time() - t1
+            # thread count: the best of {OpenMP default, all logical CPUs} unless given (a cgroup
+            # quota below the logical CPU count makes oversubscription much slower)
+            cands = [args.cpu_threads] if args.cpu_threads else sorted({orc.lib().gro_max_threads(), os.cpu_count() or 1})
+            best = None
+            for th in cands:
+                oix.search_batch(h_q[:nq], ef, k, n_threads=th)  # touch pages / spin up threads
+                t1 = time.time()
+                res = oix.search_batch(h_q, ef, k, n_threads=th)
+                dt = time.time() - t1
+                if best is None or dt < best[0]:
+                    best = (dt, th, res)
+            cpu_s, threads, (o_ids, o_d, o_c, o_ctr) = best
+            t1 = time.time() - cpu_s
             g_ids = ids[b0:b0 + nb].reshape(-1, k).cpu().numpy().astype(np.uint64)
             g_d = dists[b0:b0 + nb].reshape(-1, k).cpu().numpy()
             ids_ok = bool((g_ids == o_ids).all())
@@ -265,7 +273,7 @@ def main():
                 "value": round(nb * nq / cpu_s, 1), "unit": "queries/s", "cores": threads, "kind": "port",
                 "sample": "%d batches x %d queries of the timed workload, same index; oracle/granne_oracle.c "
                           "(C restatement of the reference's search; Rust toolchain absent), OpenMP dynamic over "
-                          "queries; %.2f s wall (+%.1f s to copy index to host)" % (nb, nq, cpu_s, t1 - t0),
+                          "queries; %.2f s wall; thread counts tried %s, best reported" % (nb, nq, cpu_s, cands),
                 "gpu_matches_oracle": {"ids_bit_exact": ids_ok, "dists_bit_exact": bool(d_ok),
                                        "queries_checked": int(nb * nq)},
             }

@@ -225,14 +225,23 @@ def test_unindexed_zero_rows_and_partial_index(ga, oracle):
 
 
 def test_wide_rows_and_large_degree(ga, oracle):
-    """num_neighbors up to 254 is legal (u8 count in the file format); rows wider than a wave."""
+    """num_neighbors up to 254 is legal (u8 count in the file format): rows wider than a wave."""
     rng = np.random.default_rng(11)
     el = prep(oracle, random_floats(rng, 600, 12), False)
-    oix = oracle.build_index(el, num_neighbors=100, max_search=120, reinsert_elements=False)
-    assert max(int((l != oracle.UNUSED).sum(axis=1).max()) for l in oix.layers) > 64
-    gix = ga.Granne("angular", el, oix.layers)
+    layer = np.full((600, 100), oracle.UNUSED, np.uint32)
+    for i in range(600):
+        d = int(rng.integers(0, 101))
+        layer[i, :d] = rng.choice(600, d, replace=False)
+    layer[0, :100] = rng.choice(600, 100, replace=False)
+    top = np.full((12, 100), oracle.UNUSED, np.uint32)
+    for i in range(12):
+        top[i, :4] = rng.choice(12, 4, replace=False)
+    assert int((layer != oracle.UNUSED).sum(axis=1).max()) > 64
+    oix = oracle.Index(el, [top, layer])
+    gix = ga.Granne("angular", el, [top, layer])
     q = prep(oracle, random_floats(rng, 16, 12), False)
     assert_same(oix, gix, q, 30, 10)
+    assert_same(oix, gix, q, 3, 3)
 
 
 def test_csr_layers_equal_fixed_width_layers(ga, oracle):
