@@ -237,6 +237,14 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     P.seg_start = S.seg_start;
     P.n_seg = S.counters;
 
+    const bool debug = getenv("GRANNE_HIP_DEBUG") != nullptr;
+    auto dbg = [&](const char* what, uint64_t pos_, uint64_t B_) {
+        if (!debug) return;
+        hipError_t e = hipStreamSynchronize(s);
+        fprintf(stderr, "[granne_hip build] layer %u %s pos %llu batch %llu: %s\n", last, what,
+                (unsigned long long)pos_, (unsigned long long)B_, hipGetErrorString(e));
+        fflush(stderr);
+    };
     uint64_t pos = 0;
     while (pos < total) {
         const uint64_t n_in_graph = reinsert ? layer_len : already + pos;
@@ -252,17 +260,20 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
                                max_search, max_search, S.s_ids, S.s_dists, S.s_counts, nullptr, S.counters + 1, s,
                                nullptr);
         if (rc) return rc;
+        dbg("search", pos, B);
         P.first_idx = first;
         P.idx_step = step;
         P.batch = (uint32_t)B;
         P.n_ops = (uint32_t)(B * cap * 2);
         hipLaunchKernelGGL(K.select, dim3((uint32_t)B), dim3(64), lds, s, P);
         HIP_TRY(hipGetLastError());
+        dbg("select", pos, B);
 
         // phase B: sort the ops by (target row, order), one wave per target row replays them
         size_t tmp_bytes = S.sort_tmp_bytes;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(S.sort_tmp, tmp_bytes, S.op_keys, S.sorted_keys, S.op_vals,
                                                    S.sorted_vals, (int)P.n_ops, 0, OP_KEY_BITS, s));
+        dbg("sort", pos, B);
         HIP_TRY(hipMemsetAsync(S.counters, 0, 4, s));
         hipLaunchKernelGGL(mark_heads_kernel, dim3(grid_for(P.n_ops, 256)), dim3(256), 0, s, S.sorted_keys, P.n_ops,
                            S.seg_start, S.counters);
@@ -270,12 +281,14 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
         uint32_t grid = P.n_ops < 4096 ? P.n_ops : 4096;
         hipLaunchKernelGGL(K.apply, dim3(grid), dim3(64), lds, s, P);
         HIP_TRY(hipGetLastError());
+        dbg("apply", pos, B);
         pos += B;
     }
     // limit number of neighbors, src/index/mod.rs:795-797
     uint32_t grid = layer_len < 8192 ? (uint32_t)layer_len : 8192u;
     hipLaunchKernelGGL(K.final_prune, dim3(grid ? grid : 1), dim3(64), lds, s, P);
     HIP_TRY(hipGetLastError());
+    dbg("final_prune", total, 0);
     return GRANNE_HIP_OK;
 }
 

@@ -178,12 +178,11 @@ struct RowWork {
             if (!preloaded) {
                 __syncthreads();
                 gather_chunk(L.cid + c0, cn);
-                if (lane < cn) L.slot[c0 + lane] = lane;
                 __syncthreads();
             }
             for (uint32_t j = c0; j < c0 + cn && nsel < max_neighbors; ++j) { // :866-881
                 const float dj = L.cd[j];
-                const uint8_t* rj = L.chunk + (size_t)L.slot[preloaded ? j : j] * P.lrow;
+                const uint8_t* rj = L.chunk + (size_t)(preloaded ? L.slot[j] : (j - c0)) * P.lrow;
                 bool bad = false;
                 if (lane < nsel) {
                     float dd = dist_lds(L.selrows + (size_t)lane * P.lrow, rj); // dist_to_element(n, &element_j)

@@ -56,6 +56,36 @@ __device__ __forceinline__ float dot_f32_exact(const float* __restrict__ x, cons
     return r;
 }
 
+// Same arithmetic with the query held in registers (q[k] are compile-time indexed).
+template <int DIM>
+__device__ __forceinline__ float dot_f32_exact_qreg(const float* __restrict__ x, const float (&q)[DIM]) {
+    static_assert(DIM % 4 == 0, "vector path needs dim % 4 == 0");
+    constexpr int FULL = (DIM / 32) * 32;
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < FULL; k += 4) {
+        float4 a = *reinterpret_cast<const float4*>(x + k);
+        acc[(k + 0) & 31] = __builtin_fmaf(a.x, q[k + 0], acc[(k + 0) & 31]);
+        acc[(k + 1) & 31] = __builtin_fmaf(a.y, q[k + 1], acc[(k + 1) & 31]);
+        acc[(k + 2) & 31] = __builtin_fmaf(a.z, q[k + 2], acc[(k + 2) & 31]);
+        acc[(k + 3) & 31] = __builtin_fmaf(a.w, q[k + 3], acc[(k + 3) & 31]);
+    }
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r = r + acc[i];
+#pragma unroll
+    for (int k = FULL; k < DIM; k += 4) {
+        float4 a = *reinterpret_cast<const float4*>(x + k);
+        r = __builtin_fmaf(a.x, q[k + 0], r);
+        r = __builtin_fmaf(a.y, q[k + 1], r);
+        r = __builtin_fmaf(a.z, q[k + 2], r);
+        r = __builtin_fmaf(a.w, q[k + 3], r);
+    }
+    return r;
+}
+
 // Any dimension, scalar reads (x, q 4-byte aligned).
 __device__ __forceinline__ float dot_f32_exact_rt(const float* __restrict__ x, const float* __restrict__ q,
                                                   uint32_t dim) {

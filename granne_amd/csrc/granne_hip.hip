@@ -485,14 +485,14 @@ struct LaunchPlan {
 // whatever fits in the CU's 160 KiB. GRANNE_HIP_MAXC overrides the stage rows (experiments).
 static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef) {
     LaunchPlan P;
-    uint32_t want = ix->opt_visited_slots ? (uint32_t)ix->opt_visited_slots : next_pow2(ef * 128u);
+    uint32_t want = ix->opt_visited_slots ? (uint32_t)ix->opt_visited_slots : next_pow2(ef * 64u);
     if (!ix->opt_visited_slots) {
         if (want < 1024) want = 1024;
         if (want > 16384) want = 16384;
     }
     P.visited_slots = want;
     P.upper_slots = want < 1024 ? want : 1024;
-    uint32_t fixed = lds_query_bytes(ix->row_bytes) + 512;
+    uint32_t fixed = lds_query_bytes(ix->row_bytes) + LDS_FIXED_BYTES;
     if (ix->dtype == GRANNE_HIP_F32) {
         uint32_t row16 = ix->row_bytes / 16;
         P.lrow_bytes = (row16 | 1u) * 16u; // odd number of 16-byte units: conflict-free ds_read_b128
@@ -566,6 +566,8 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.slow_count = (uint32_t*)scratch;
     p.slow_list = (uint32_t*)(scratch + off_list);
     p.force_slow = all_slow ? 1 : 0;
+    p.spec = 1;
+    if (const char* e = getenv("GRANNE_HIP_SPEC")) p.spec = atoi(e) ? 1 : 0;
 
     search_fn fn = pick_kernel(ix->dtype, ix->dim, ef > 256 ? 256 : ef);
     if (plan.lds_bytes > 48u * 1024u)

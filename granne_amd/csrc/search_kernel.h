@@ -57,6 +57,7 @@ struct SearchParams {
     uint32_t* slow_count;    // queries handed to the slow path
     uint32_t* slow_list;     // [nq]
     uint32_t force_slow;
+    uint32_t spec;           // 1: speculative adjacency prefetch (narrow layers)
 };
 
 struct WalkStats {
@@ -64,8 +65,9 @@ struct WalkStats {
 };
 
 // LDS carve-up (dynamic shared memory), all offsets multiples of 16:
-//   [query: row_bytes][cand: 64 u32][dout: 64 f32][stage: maxc*lrow_bytes (f32)][visited]
+//   [query: row_bytes][cand: 64 u32][dout: 64 f32][adjspec: 32x32 u32][stage: maxc*lrow_bytes (f32)][visited]
 __host__ __device__ inline uint32_t lds_query_bytes(uint32_t row_bytes) { return (row_bytes + 15u) & ~15u; }
+constexpr uint32_t LDS_FIXED_BYTES = 512 + 4096 + 16; // cand + dout + adjspec + a 16-byte dump slot
 
 template <int DT, int DIM, int S>
 struct Walker {
@@ -75,9 +77,11 @@ struct Walker {
     uint8_t* lds_q;
     uint32_t* cand;
     float* dout;
+    uint32_t* adjspec; // speculatively fetched adjacency rows of the last expansion's candidates
     uint8_t* stage;
     uint32_t* vis_tab;
     int dy; // i8: sum of squares of the query
+    float qv[(DT == DT_F32 && DIM > 0) ? DIM : 1]; // f32, known dim: the query lives in registers
     // ---- per-walk state
     VisitedSet vis;
     SortedList<S> res; // `res`, capped at ef entries
@@ -91,7 +95,8 @@ struct Walker {
         lds_q = smem;
         cand = reinterpret_cast<uint32_t*>(smem + qb);
         dout = reinterpret_cast<float*>(smem + qb + 256);
-        stage = smem + qb + 512;
+        adjspec = reinterpret_cast<uint32_t*>(smem + qb + 512);
+        stage = smem + qb + LDS_FIXED_BYTES;
         uint32_t stage_bytes = (DT == DT_F32) ? p.maxc * p.lrow_bytes : 0;
         vis_tab = reinterpret_cast<uint32_t*>(stage + stage_bytes);
         dy = 0;
@@ -105,6 +110,10 @@ struct Walker {
             const float* q = reinterpret_cast<const float*>(p.queries + (int64_t)qi * p.q_stride);
             float* l = reinterpret_cast<float*>(lds_q);
             for (uint32_t i = lane; i < p.row_bytes / 4; i += 64) l[i] = (i < p.dim) ? q[i] : 0.0f;
+            if constexpr (DT == DT_F32 && DIM > 0) {
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) qv[k] = q[k];
+            }
         } else {
             const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
             int8_t* l = reinterpret_cast<int8_t*>(lds_q);
@@ -168,7 +177,7 @@ struct Walker {
                     const float* x = reinterpret_cast<const float*>(stage + (size_t)(lane - g0) * p.lrow_bytes);
                     const float* q = reinterpret_cast<const float*>(lds_q);
                     float r;
-                    if constexpr (DIM > 0) r = dot_f32_exact<DIM>(x, q);
+                    if constexpr (DIM > 0) r = dot_f32_exact_qreg<DIM>(x, qv);
                     else r = dot_f32_exact_rt(x, q, p.dim);
                     d = angular_from_dot(r);
                 }
@@ -226,6 +235,121 @@ struct Walker {
         }
     }
 
+    // ---- narrow layers (device row width 32, the default 30/15-neighbor graphs) --------------------
+    // Everything one expansion needs from HBM is requested in ONE round trip: the candidates'
+    // element rows AND, speculatively, their adjacency rows (the next node to expand is either
+    // the queue's current head -- prefetched into registers at the start of the expansion -- or
+    // one of these candidates). Speculation only moves loads of immutable data earlier; the
+    // walk's logic, and so its result, is unchanged.
+    static constexpr int NSTEP = (DT == DT_F32 && DIM > 0) ? (32 * (DIM / 4) + 63) / 64 : 1;
+
+    // distances of cand[0..m), m <= 32 <= maxc, plus the speculative adjacency fetch
+    __device__ __forceinline__ float distances_narrow(uint32_t m, gptr_u32 adj) {
+        float d = 0.0f;
+        // adjacency rows of the candidates: 8 lanes x 16 bytes per row, 8 rows per step
+        const uint32_t au = m * 8u;
+        uint4 a0, a1, a2, a3;
+#define GRANNE_ASPEC(U, A)                                                                            \
+    {                                                                                                 \
+        uint32_t f = (U) * 64u + lane;                                                                \
+        uint32_t fc = f < au ? f : au - 1u;                                                           \
+        A = load_global_u4(adj + (size_t)cand[fc >> 3] * 32u + (fc & 7u) * 4u);                        \
+    }
+        if constexpr (DT == DT_F32 && DIM > 0) {
+            constexpr uint32_t ROW16 = DIM / 4;
+            const uint32_t lrow16 = p.lrow_bytes >> 4;
+            const uint32_t total = m * ROW16;
+            // NSTEP (<= 25) named registers, not an array: hipcc keeps uint4 arrays with guarded
+            // uses in scratch memory. Every load is unconditional (clamped), so all are in flight.
+#define GRANNE_ROW_LOAD(U)                                                                             \
+    uint4 v##U = make_uint4(0, 0, 0, 0);                                                               \
+    if constexpr ((U) < NSTEP) {                                                                       \
+        uint32_t f = (uint32_t)(U) * 64u + lane;                                                       \
+        uint32_t fc = f < total ? f : total - 1u;                                                      \
+        uint32_t row = fc / ROW16;                                                                     \
+        uint32_t part = fc - row * ROW16;                                                              \
+        v##U = *reinterpret_cast<const uint4*>(p.elements + (size_t)cand[row] * p.row_bytes + (size_t)part * 16); \
+    }
+#define GRANNE_ROW_STORE(U)                                                                            \
+    if constexpr ((U) < NSTEP) {                                                                       \
+        uint32_t f = (uint32_t)(U) * 64u + lane;                                                       \
+        if (f < total) {                                                                               \
+            uint32_t row = f / ROW16;                                                                  \
+            uint32_t part = f - row * ROW16;                                                           \
+            *reinterpret_cast<uint4*>(stage + (size_t)(row * lrow16 + part) * 16) = v##U;              \
+        }                                                                                              \
+    }
+#define GRANNE_FOR_STEPS(X)                                                                            \
+    X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19)   \
+    X(20) X(21) X(22) X(23) X(24)
+            static_assert(NSTEP <= 25, "extend GRANNE_FOR_STEPS");
+            GRANNE_FOR_STEPS(GRANNE_ROW_LOAD)
+            GRANNE_ASPEC(0, a0) GRANNE_ASPEC(1, a1) GRANNE_ASPEC(2, a2) GRANNE_ASPEC(3, a3)
+            // Pin the loads above this point: an (empty) asm consumes a value derived from every
+            // row load, so the compiler cannot sink them into the guarded LDS writes below (which
+            // would serialise them, one HBM round trip each).
+            {
+                uint32_t chk = 0;
+#define GRANNE_ROW_CHK(U) chk ^= v##U.x;
+                GRANNE_FOR_STEPS(GRANNE_ROW_CHK)
+#undef GRANNE_ROW_CHK
+                asm volatile("" ::"v"(chk));
+            }
+            GRANNE_FOR_STEPS(GRANNE_ROW_STORE)
+#undef GRANNE_FOR_STEPS
+#undef GRANNE_ROW_LOAD
+#undef GRANNE_ROW_STORE
+            park_spec(au, a0, a1, a2, a3);
+            __syncthreads();
+            if (lane < m) {
+                const float* x = reinterpret_cast<const float*>(stage + (size_t)lane * p.lrow_bytes);
+                d = angular_from_dot(dot_f32_exact_qreg<DIM>(x, qv));
+            }
+            __syncthreads();
+        } else {
+            GRANNE_ASPEC(0, a0) GRANNE_ASPEC(1, a1) GRANNE_ASPEC(2, a2) GRANNE_ASPEC(3, a3)
+            asm volatile("" ::: "memory"); // the loads above may not sink below this line
+            d = distances(m);               // its own row loads overlap with the ones in flight
+            park_spec(au, a0, a1, a2, a3);
+            __syncthreads();
+        }
+#undef GRANNE_ASPEC
+        return d;
+    }
+
+    // park the speculative adjacency rows in LDS: row c at adjspec[c*32 ..] = linear in the unit
+    // index f; every lane stores (out-of-range lanes into the dump slot) so that the stores -- and
+    // with them the loads -- stay in straight-line code
+    __device__ __forceinline__ void park_spec(uint32_t au, uint4 a0, uint4 a1, uint4 a2, uint4 a3) {
+        uint4* as4 = reinterpret_cast<uint4*>(adjspec);
+        const uint32_t dump = 256u; // the 16 bytes after the 32x32 table
+        as4[lane < au ? lane : dump] = a0;
+        as4[64u + lane < au ? 64u + lane : dump] = a1;
+        as4[128u + lane < au ? 128u + lane : dump] = a2;
+        as4[192u + lane < au ? 192u + lane : dump] = a3;
+    }
+
+    // mod.rs:1029-1031 + pq.push for the candidates of one expansion (lane c < m holds d, cid)
+    __device__ __forceinline__ void offer_candidates(uint32_t m, float d, uint32_t cid, bool full, float worst,
+                                                     uint32_t ef) {
+        uint64_t ck = make_key(d, cid);
+        // `res` is frozen during an expansion, so the filter is too
+        bool pass = (lane < m) && (!full || d < worst);
+        // entries that cannot enter a full queue are dropped right here
+        uint64_t last = pq.get(64u * S - 1);
+        if (last != KEY_INF) {
+            bool dropnow = pass && ck > last;
+            if (wave_ballot(dropnow && d == key_dist(pq.get(ef - 1)))) bail = true;
+            pass = pass && !dropnow;
+        }
+        uint64_t pm = wave_ballot(pass);
+        while (pm) {
+            uint32_t src = (uint32_t)__builtin_ctzll(pm);
+            pm &= pm - 1;
+            pq_push(readlane64(ck, src), ef);
+        }
+    }
+
     // search_for_neighbors (mod.rs:999-1037) on one layer. Result: `res` (ascending).
     __device__ __forceinline__ void search_layer(const LayerDev& L, uint32_t entrypoint, uint32_t ef,
                                                  uint32_t slots) {
@@ -246,6 +370,11 @@ struct Walker {
             uint64_t k0 = readlane64(make_key(d0, entrypoint), 0);
             pq.insert_at(0, k0, lane);
         }
+
+        const bool narrow = p.spec && L.width == 32 && (DT == DT_I8 || p.maxc >= 32);
+        // speculative adjacency state (narrow layers)
+        uint32_t specA_id = ID_EMPTY, specA_nb = ID_EMPTY; // row of the queue head, one id per lane
+        uint32_t specB_m = 0, specB_cid = ID_EMPTY;        // last expansion's candidates (rows in adjspec)
 
         for (;;) {
             uint64_t x = pq.get(0); // pq.pop(), mod.rs:1018
@@ -268,46 +397,69 @@ struct Walker {
 
             // layer.get_neighbors(idx), mod.rs:1025 / 540-552: row prefix until UNUSED
             const uint32_t xid = key_id(x);
-            const uint32_t* row = L.adj + (size_t)xid * L.width;
+            const gptr_u32 adjg = (gptr_u32)L.adj;
+            const gptr_u32 row = adjg + (size_t)xid * L.width;
             st.n_expand += 1;
-            for (uint32_t base = 0; base < L.width; base += 64) {
-                uint32_t nb = (base + lane < L.width) ? row[base + lane] : ID_EMPTY;
+
+            if (narrow) {
+                uint32_t nb;
+                const uint64_t hitB = wave_ballot(lane < specB_m && specB_cid == xid);
+                if (specA_id == xid) {
+                    nb = specA_nb;
+                } else if (hitB) {
+                    const uint32_t c = (uint32_t)__builtin_ctzll(hitB);
+                    nb = (lane < 32) ? adjspec[c * 32u + lane] : ID_EMPTY;
+                } else {
+                    nb = (lane < 32) ? row[lane] : ID_EMPTY;
+                }
+                // prefetch the adjacency of the queue's new head for the next iteration
+                const uint64_t head = pq.get(0);
+                specA_id = (head != KEY_INF) ? key_id(head) : ID_EMPTY;
+                if (specA_id != ID_EMPTY) specA_nb = (lane < 32) ? adjg[(size_t)specA_id * 32u + lane] : ID_EMPTY;
+
                 uint64_t unused = wave_ballot(nb == ID_EMPTY);
                 uint32_t nvalid = unused ? (uint32_t)__builtin_ctzll(unused) : 64u;
                 st.n_adj += nvalid;
-                bool valid = lane < nvalid;
-
-                bool fresh = vis.insert(nb, valid); // visited.insert(neighbor_idx), mod.rs:1026
+                bool fresh = vis.insert(nb, lane < nvalid); // visited.insert(neighbor_idx), mod.rs:1026
                 uint64_t fm = wave_ballot(fresh);
                 uint32_t m = (uint32_t)__popcll(fm);
                 if (m) {
                     vis.count += m;
                     uint32_t pos = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+                    __syncthreads(); // adjspec / cand of the previous expansion are dead from here on
                     if (fresh) cand[pos] = nb;
                     __syncthreads();
-                    float d = distances(m); // mod.rs:1027
+                    float d = distances_narrow(m, adjg); // mod.rs:1027
                     st.n_dist += m;
-                    uint32_t cid = (lane < m) ? cand[lane] : 0u;
-                    uint64_t ck = make_key(d, cid);
-                    // mod.rs:1029-1031: `res` is frozen during an expansion, so the filter is too
-                    bool pass = (lane < m) && (!full || d < worst);
-                    // entries that cannot enter a full queue are dropped right here
-                    uint64_t last = pq.get(64u * S - 1);
-                    if (last != KEY_INF) {
-                        bool dropnow = pass && ck > last;
-                        if (wave_ballot(dropnow && d == key_dist(pq.get(ef - 1)))) bail = true;
-                        pass = pass && !dropnow;
-                    }
-                    uint64_t pm = wave_ballot(pass);
-                    while (pm) {
-                        uint32_t src = (uint32_t)__builtin_ctzll(pm);
-                        pm &= pm - 1;
-                        pq_push(readlane64(ck, src), ef);
-                    }
-                    __syncthreads();
+                    uint32_t cid = (lane < m) ? cand[lane] : ID_EMPTY;
+                    specB_m = m;
+                    specB_cid = cid;
+                    offer_candidates(m, d, cid, full, worst, ef);
                 }
                 if (vis.count > vis.limit) bail = true;
-                if (nvalid < 64u) break;
+            } else {
+                for (uint32_t base = 0; base < L.width; base += 64) {
+                    uint32_t nb = (base + lane < L.width) ? row[base + lane] : ID_EMPTY;
+                    uint64_t unused = wave_ballot(nb == ID_EMPTY);
+                    uint32_t nvalid = unused ? (uint32_t)__builtin_ctzll(unused) : 64u;
+                    st.n_adj += nvalid;
+                    bool fresh = vis.insert(nb, lane < nvalid); // visited.insert(neighbor_idx), mod.rs:1026
+                    uint64_t fm = wave_ballot(fresh);
+                    uint32_t m = (uint32_t)__popcll(fm);
+                    if (m) {
+                        vis.count += m;
+                        uint32_t pos = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+                        if (fresh) cand[pos] = nb;
+                        __syncthreads();
+                        float d = distances(m); // mod.rs:1027
+                        st.n_dist += m;
+                        uint32_t cid = (lane < m) ? cand[lane] : 0u;
+                        offer_candidates(m, d, cid, full, worst, ef);
+                        __syncthreads();
+                    }
+                    if (vis.count > vis.limit) bail = true;
+                    if (nvalid < 64u) break;
+                }
             }
             if (bail) return;
         }

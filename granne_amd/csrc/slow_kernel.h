@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
                 const bool full = n_res >= ef;
                 const float worst = __uint_as_float(worst_bits);
 
-                const uint32_t* row = L.adj + (size_t)key_id(x) * L.width;
+                const gptr_u32 row = (gptr_u32)L.adj + (size_t)key_id(x) * L.width;
                 n_expand += 1;
                 for (uint32_t base = 0; base < L.width; base += 64) {
                     uint32_t nb = (base + lane < L.width) ? row[base + lane] : ID_EMPTY;

@@ -16,6 +16,17 @@
 
 namespace granne_hip {
 
+// Pointers that were themselves loaded from memory (e.g. LayerDev::adj) reach the compiler as
+// generic pointers and compile to flat_load; these typedefs keep them in the global address
+// space (global_load: vmcnt only, no LDS aperture check).
+typedef const uint32_t __attribute__((address_space(1))) * gptr_u32;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef const u32x4_t __attribute__((address_space(1))) * gptr_v4;
+__device__ __forceinline__ uint4 load_global_u4(gptr_u32 p) { // one global_load_dwordx4
+    u32x4_t t = *(gptr_v4)p;
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
 constexpr uint64_t KEY_INF = ~0ull;      // sorts after every real key (dist bits <= 0x40000000)
 constexpr uint32_t ID_EMPTY = 0xFFFFFFFFu; // == UNUSED (src/index/mod.rs:27-28): never a node id
 
@@ -117,7 +128,8 @@ struct SortedList {
     }
 };
 
-// Exact visited set in LDS (HashSet<usize>, src/index/mod.rs:1009-1010,1016,1026).
+// Exact visited set in LDS (HashSet<usize>, src/index/mod.rs:1009-1010,1016,1026): open
+// addressing with double hashing (no primary clustering, so the table can run at 7/8 load).
 struct VisitedSet {
     uint32_t* tab;  // LDS
     uint32_t mask;  // slots - 1
@@ -128,23 +140,27 @@ struct VisitedSet {
         tab = lds;
         mask = slots - 1;
         count = 0;
-        limit = slots - (slots >> 2) - (slots >> 3); // 62.5 % load
+        // 87.5 % load, and never fewer than 72 free slots: one expansion adds up to 64 ids before
+        // the limit is checked, so probing always terminates
+        limit = slots - ((slots >> 3) > 72u ? (slots >> 3) : 72u);
         uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
         uint4* t4 = reinterpret_cast<uint4*>(lds);
         for (uint32_t i = lane; i < (slots >> 2); i += 64) t4[i] = e;
     }
     __device__ __forceinline__ static uint32_t hash(uint32_t id) { return (id * 0x9E3779B1u) >> 7; }
+    __device__ __forceinline__ static uint32_t step(uint32_t id) { return ((id * 0x85EBCA6Bu) >> 9) | 1u; }
 
     // HashSet::insert: true iff id was not present. Lanes with active==false do nothing.
     __device__ __forceinline__ bool insert(uint32_t id, bool active) {
         bool fresh = false;
         if (active) {
             uint32_t slot = hash(id) & mask;
+            const uint32_t st = step(id); // odd: visits every slot of the power-of-two table
             for (;;) {
                 uint32_t old = atomicCAS(&tab[slot], ID_EMPTY, id);
                 if (old == ID_EMPTY) { fresh = true; break; }
                 if (old == id) break;
-                slot = (slot + 1) & mask;
+                slot = (slot + st) & mask;
             }
         }
         return fresh;
