@@ -1,0 +1,39 @@
+"""Summarise rocprofv3 CSV outputs (kernel stats + PMC counters per kernel) into profiles/."""
+import csv, glob, os, sys, collections, statistics
+root = sys.argv[1]; out = sys.argv[2]
+lines = []
+# kernel trace
+for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    agg = collections.defaultdict(list)
+    bench = []
+    for r in rows:
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        agg[r["Kernel_Name"]].append(dur)
+        if "search_kernel" in r["Kernel_Name"] and int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0)) == 65536:
+            bench.append(dur)
+    tot = sum(sum(v) for v in agg.values())
+    lines.append("# kernel trace: kernel, calls, total_ms, avg_us, min_us, max_us, pct")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        lines.append("%s,%d,%.3f,%.2f,%.2f,%.2f,%.2f" % (k[:100], len(v), sum(v) / 1e3, statistics.mean(v), min(v), max(v), 100 * sum(v) / tot))
+    if bench:
+        t = bench[3:] if len(bench) > 3 else bench
+        lines.append("# search_kernel launches of the timed steps (grid 1024x64): n=%d mean %.1f us min %.1f us max %.1f us" % (len(t), statistics.mean(t), min(t), max(t)))
+# pmc
+for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows:
+            if "search_kernel" not in r["Kernel_Name"]:
+                continue
+            gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
+            if gs != 65536:
+                continue
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, cs in agg.items():
+            lines.append("# PMC (%s) %s, per launch of the benchmark's search_kernel (mean over %d launches)" % (os.path.basename(d), k[:80], len(next(iter(cs.values())))))
+            for c, v in sorted(cs.items()):
+                lines.append("%s,%.1f" % (c, statistics.mean(v)))
+open(out, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
