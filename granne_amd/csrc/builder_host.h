@@ -402,7 +402,10 @@ extern "C" int granne_hip_builder_build(granne_hip_builder* b, uint64_t num_elem
             const BuilderLayer& pl = b->layers.back();
             size_t bytes = (size_t)pl.len * b->W * 4;
             hipError_t e = hipMalloc((void**)&nl.d_adj, bytes ? bytes : 16);
-            if (e == hipSuccess && bytes) e = hipMemcpy(nl.d_adj, pl.d_adj, bytes, hipMemcpyDeviceToDevice);
+            // on the builder's own stream: a device-to-device hipMemcpy on the null stream is
+            // asynchronous and a non-blocking stream would not wait for it
+            if (e == hipSuccess && bytes) e = hipMemcpyAsync(nl.d_adj, pl.d_adj, bytes, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) {
                 rc = fail(GRANNE_HIP_ERR_HIP, "layer clone failed: %s", hipGetErrorString(e));
                 break;

@@ -13,5 +13,10 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INST_CYCLES_VMEM -d $OUT/pmc2 -o p -- $BENCH > $OUT/bench_pmc2.json 2> $OUT/pmc2.err
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc3 -o p -- $BENCH > $OUT/bench_pmc3.json 2> $OUT/pmc3.err
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc4 -o p -- $BENCH > $OUT/bench_pmc4.json 2> $OUT/pmc4.err
-find $OUT -name "*.csv" | head -30
-ls -la $OUT/*
+cd "$(dirname "$0")/.." 2>/dev/null || cd /root/repo
+for d in $OUT/trace $OUT/pmc1; do head -2 $(ls $d/*.csv | head -3) 2>/dev/null | cut -c1-400; done
+python tools/prof_summary.py $OUT $OUT/summary.csv | tail -60
+cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats_full.csv 2>/dev/null
+# raw traces are far beyond the 64 MiB return limit: keep the summaries only
+rm -rf $OUT/trace $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4
+ls -la $OUT
