@@ -67,6 +67,7 @@ SIGNATURES = {
     "granne_hip_quantize_f32": (i32, [vp, vp, u64, u32, i32]),
     "granne_hip_dist_pairs": (i32, [vp, vp, u32, vp, vp, u64, vp]),
     "granne_hip_synth_rows_device": (i32, [vp, u64, u64, u64, u32, i32, vp]),
+    "granne_hip_merge_topk_device": (i32, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, i32, vp]),
     "granne_hip_build_config_default": (None, [vp]),
     "granne_hip_builder_create": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, i32]),
     "granne_hip_builder_create_device": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, i32, vp]),

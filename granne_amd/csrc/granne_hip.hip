@@ -726,6 +726,35 @@ extern "C" int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_
     return GRANNE_HIP_OK;
 }
 
+extern "C" int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, const uint32_t* d_counts,
+                                            const uint64_t* shard_offsets, uint32_t n_shards, uint32_t nq, uint32_t k,
+                                            uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                                            int device_id, void* stream) {
+    if (nq == 0) return GRANNE_HIP_OK;
+    if (!d_ids || !d_dists || !d_counts || !shard_offsets || !d_out_ids || !d_out_dists || !d_out_counts)
+        return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (n_shards == 0 || n_shards > 64) return fail(GRANNE_HIP_ERR_INVALID, "n_shards must be in [1, 64]");
+    if (k == 0 || (uint64_t)n_shards * k > 4096) return fail(GRANNE_HIP_ERR_INVALID, "n_shards * k must be in [1, 4096]");
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    MergeParams P;
+    P.ids = d_ids;
+    P.dists = d_dists;
+    P.counts = d_counts;
+    for (uint32_t s = 0; s < 64; ++s) P.offsets[s] = s < n_shards ? shard_offsets[s] : 0;
+    P.n_shards = n_shards;
+    P.nq = nq;
+    P.k = k;
+    P.out_ids = d_out_ids;
+    P.out_dists = d_out_dists;
+    P.out_counts = d_out_counts;
+    uint32_t C = n_shards * k;
+    uint32_t lds = ((C * 4 + 7) & ~7u) + C * 8;
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(64), lds, (hipStream_t)stream, P);
+    HIP_TRY(hipGetLastError());
+    return GRANNE_HIP_OK;
+}
+
 // host conveniences -------------------------------------------------------------------------------
 extern "C" int granne_hip_normalize_f32(float* rows, uint64_t n, uint32_t dim, int device_id) {
     if (!rows && n) return fail(GRANNE_HIP_ERR_INVALID, "rows is null");

@@ -154,4 +154,58 @@ __global__ void dist_pairs_kernel(const uint8_t* __restrict__ elements, uint32_t
     }
 }
 
+struct MergeParams {
+    const uint64_t* ids;
+    const float* dists;
+    const uint32_t* counts;
+    uint64_t offsets[64];
+    uint32_t n_shards, nq, k;
+    uint64_t* out_ids;
+    float* out_dists;
+    uint32_t* out_counts;
+};
+
+// one wave per query: rank every candidate among all candidates of the query by (dist, global id)
+__global__ __launch_bounds__(64) void merge_topk_kernel(const MergeParams P) {
+    extern __shared__ __align__(16) uint8_t smem_m[];
+    uint32_t* kd = reinterpret_cast<uint32_t*>(smem_m); // [C] distance bits
+    uint64_t* ki = reinterpret_cast<uint64_t*>(smem_m + (size_t)((P.n_shards * P.k * 4 + 7) & ~7u)); // [C] global ids
+    const uint32_t lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    if (q >= P.nq) return;
+    const uint32_t C = P.n_shards * P.k;
+    for (uint32_t c = lane; c < C; c += 64) {
+        uint32_t s = c / P.k, j = c - s * P.k;
+        bool ok = j < P.counts[(size_t)s * P.nq + q];
+        size_t src = ((size_t)s * P.nq + q) * P.k + j;
+        kd[c] = ok ? __float_as_uint(P.dists[src]) : 0xFFFFFFFFu;
+        ki[c] = ok ? P.ids[src] + P.offsets[s] : ~0ull;
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    for (uint32_t c = lane; c < C; c += 64) total += (kd[c] != 0xFFFFFFFFu) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    const uint32_t count = total < P.k ? total : P.k;
+    for (uint32_t c = lane; c < C; c += 64) {
+        const uint32_t d = kd[c];
+        const uint64_t id = ki[c];
+        if (d == 0xFFFFFFFFu) continue;
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < C; ++o) {
+            uint32_t od = kd[o];
+            uint64_t oi = ki[o];
+            rank += (od < d || (od == d && oi < id)) ? 1u : 0u;
+        }
+        if (rank < P.k) {
+            P.out_ids[(size_t)q * P.k + rank] = id;
+            P.out_dists[(size_t)q * P.k + rank] = __uint_as_float(d);
+        }
+    }
+    for (uint32_t e = count + lane; e < P.k; e += 64) {
+        P.out_ids[(size_t)q * P.k + e] = ~0ull;
+        P.out_dists[(size_t)q * P.k + e] = __builtin_inff();
+    }
+    if (lane == 0) P.out_counts[q] = count;
+}
+
 } // namespace granne_hip

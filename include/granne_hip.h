@@ -154,6 +154,18 @@ int granne_hip_dist_pairs(const granne_hip_index* index, const void* queries, ui
 int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
                                  int device_id, void* stream);
 
+/* ---- partitioned indexes: merge of per-shard results --------------------------------------------
+ * The element set partitions into independent indexes (how the reference's own shard helper is
+ * meant to be used, src/elements/embeddings/parsing.rs:63-100). Every shard answers the same
+ * query batch; this call merges the n_shards x k candidates of each query into the k best by
+ * (dist, global id). d_ids/d_dists: [n_shards][nq][k] (the layout an all-gather of per-rank
+ * [nq][k] results produces), d_counts: [n_shards][nq]; shard_offsets (HOST array, n_shards
+ * entries) are added to the local ids. n_shards <= 64, n_shards * k <= 4096.               */
+int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, const uint32_t* d_counts,
+                                 const uint64_t* shard_offsets, uint32_t n_shards, uint32_t nq, uint32_t k,
+                                 uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                                 int device_id, void* stream);
+
 /* ---- GranneBuilder on the GPU ------------------------------------------------------------------
  * Mirrors GranneBuilder / BuildConfig / Builder (src/index/mod.rs:198-531): the same layer
  * pyramid (compute_num_elements_in_layer :634-643), the same per-element work (index_element

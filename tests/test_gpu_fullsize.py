@@ -1,0 +1,110 @@
+"""BASELINE.json's full sizes (configs[1]/[2]: 10M x 100-d, f32 and int8), checked through
+size-independent properties -- the CPU oracle cannot walk 10M-point graphs built here within a
+test budget, but it can check everything the GPU returns:
+  * every returned distance equals the oracle's distance for that (query, id) pair, bit for bit;
+  * results are ascending by (dist, id), ids are distinct and < n, counts == k;
+  * the walk is repeatable and independent of batch composition (idempotence);
+  * elements of the set, used as queries, find themselves (the reference's verify_search,
+    src/index/tests.rs:50-62);
+  * a larger max_search never returns a worse k-th distance on the same query.
+Set GRANNE_FULLSIZE_N to run on fewer points (default 10,000,000)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = int(os.environ.get("GRANNE_FULLSIZE_N", "10000000"))
+DIM = 100
+SEED = 0x6772616E6E65
+
+
+@pytest.fixture(scope="module", params=["f32", "i8"])
+def built(request):
+    import torch
+    import granne_amd
+    from granne_amd import _lib
+    lib = _lib.lib()
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def synth(seed, rows):
+        raw = torch.empty((rows, DIM), dtype=torch.float32, device="cuda")
+        _lib.check(lib.granne_hip_synth_rows_device(C.c_void_p(raw.data_ptr()), seed, 0, rows, DIM, 0, sp))
+        if request.param == "f32":
+            _lib.check(lib.granne_hip_normalize_f32_device(C.c_void_p(raw.data_ptr()), rows, DIM, 0, sp))
+            return raw
+        q = torch.empty((rows, DIM), dtype=torch.int8, device="cuda")
+        _lib.check(lib.granne_hip_quantize_f32_device(C.c_void_p(raw.data_ptr()), C.c_void_p(q.data_ptr()), rows, DIM, 0, sp))
+        return q
+
+    el = synth(SEED, N)
+    q = synth(SEED + 1, 1024)
+    torch.cuda.synchronize()
+    et = "angular" if request.param == "f32" else "angular_int"
+    b = granne_amd.GranneBuilder.from_device(et, el.data_ptr(), N, DIM, num_neighbors=30, max_search=50,
+                                             reinsert_elements=False)
+    b.build()
+    ix = b.get_index()
+    sizes = [b.layer_len(l) for l in range(b.num_layers())]
+    b.close()
+    return request.param, el, q.cpu().numpy(), ix, sizes
+
+
+def test_layer_pyramid(built, oracle):
+    _, _, _, ix, sizes = built
+    assert sizes == [oracle.num_elements_in_layer(N, 15.0, l) for l in range(len(sizes))]
+    assert len(ix) == N
+
+
+def test_results_are_wellformed_and_distances_are_the_oracles(built, oracle):
+    kind, el, q, ix, _ = built
+    ids, ds, cnt, st = ix.search_batch(q, 50, 10, stats=True)
+    assert (cnt == 10).all()
+    assert (ids < N).all()
+    for i in range(len(q)):
+        assert len(set(ids[i].tolist())) == 10
+        keys = list(zip(ds[i].tolist(), ids[i].tolist()))
+        assert keys == sorted(keys)
+    # oracle distance for every returned pair (rows fetched from the device copy)
+    flat = ids.reshape(-1).astype(np.int64)
+    import torch
+    rows = el[torch.from_numpy(flat).cuda()].cpu().numpy()
+    want = np.array([oracle.dist(rows[j], q[j // 10]) for j in range(len(flat))], np.float32)
+    assert want.tobytes() == ds.reshape(-1).tobytes()
+    assert (st[:, 0] >= st[:, 1]).all() and (st[:, 1] >= 50).all()  # >= max_search expansions at the bottom
+
+
+def test_idempotent_and_batch_independent(built):
+    _, _, q, ix, _ = built
+    a = ix.search_batch(q, 50, 10)
+    b = ix.search_batch(q, 50, 10)
+    assert (a[0] == b[0]).all() and a[1].tobytes() == b[1].tobytes()
+    perm = np.random.default_rng(0).permutation(len(q))
+    c = ix.search_batch(q[perm], 50, 10)
+    assert (c[0] == a[0][perm]).all() and c[1].tobytes() == a[1][perm].tobytes()
+    d = ix.search_batch(q[:7], 50, 10)
+    assert (d[0] == a[0][:7]).all()
+
+
+def test_members_find_themselves(built):
+    kind, el, _, ix, _ = built
+    rng = np.random.default_rng(1)
+    pick = np.sort(rng.choice(N, 512, replace=False))
+    import torch
+    rows = el[torch.from_numpy(pick).cuda()].cpu().numpy()
+    ids, ds, cnt = ix.search_batch(rows, 50, 1)
+    hit = (ids[:, 0] == pick.astype(np.uint64))
+    # int8 rows can collide exactly (distance 0 ties broken by id), so allow distance-0 matches
+    ok = hit | (ds[:, 0] <= 1e-6)
+    print("self-query hit rate at n=%d (%s): %.3f" % (N, kind, ok.mean()))
+    assert ok.mean() > 0.5, ok.mean()
+
+
+def test_larger_max_search_is_never_worse(built):
+    _, _, q, ix, _ = built
+    d50 = ix.search_batch(q[:256], 50, 10)[1]
+    d200 = ix.search_batch(q[:256], 200, 10)[1]
+    assert (d200[:, 0] <= d50[:, 0]).mean() > 0.99
+    assert (d200[:, 9] <= d50[:, 9]).mean() > 0.99

@@ -1,0 +1,108 @@
+"""The N > 1 path on CPU: two processes, gloo backend, world_size 2.
+
+Partitioned mode: each rank owns an id range and its own index; every rank answers
+the same query batch; ONE all-gather of the per-shard top-k; merge by (dist, global id). The local
+search and the merge are injected here (the CPU oracle and a numpy merge) because there is no GPU:
+what is under test is granne_amd.sharded's exchange logic -- offsets, all-gather layout, ordering,
+identical results on every rank -- against a single-process recomputation.
+Also covers the replica-mode work split bench.py uses (disjoint query rows per rank).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data():
+    from oracle import oracle as orc
+    rng = np.random.default_rng(123)
+    n, dim = 900, 16
+    el = orc.normalize_f32((rng.random((n, dim), dtype=np.float32) - np.float32(0.5)))
+    q = orc.normalize_f32((rng.random((24, dim), dtype=np.float32) - np.float32(0.5)))
+    return el, q
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from granne_amd import sharded
+    el, q = _data()
+    lo, hi = sharded.shard_bounds(len(el), world)[rank]
+    local = orc.build_index(np.ascontiguousarray(el[lo:hi]), num_neighbors=8, max_search=20)
+
+    def local_search(queries, max_search, k):  # CPU stand-in for the HIP search: same outputs
+        ids, ds, cnt, _ = local.search_batch(np.asarray(queries), max_search, k)
+        return (torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(ds), torch.from_numpy(cnt.astype(np.int32)))
+
+    def merge(g_ids, g_ds, g_cnt, offsets, k):
+        i, d, c = sharded.merge_topk_numpy(g_ids.numpy().astype(np.uint64), g_ds.numpy(), g_cnt.numpy(), offsets, k)
+        return torch.from_numpy(i.astype(np.int64)), torch.from_numpy(d), torch.from_numpy(c.astype(np.int32))
+
+    sg = sharded.ShardedGranne(None, lo, local_search=local_search, merge=merge)
+    ids, ds, cnt = sg.search_batch(q, 20, 5)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ids=ids.numpy(), ds=ds.numpy(), cnt=cnt.numpy(),
+             offsets=np.array(sg._offsets))
+    # replica mode: disjoint query rows, all rows covered
+    r0, per = sharded.replica_query_rows(rank, world, 3, 8)
+    t = torch.tensor([r0, per], dtype=torch.int64)
+    allv = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(allv, t)
+    starts = sorted(int(v[0]) for v in allv)
+    assert starts == [g * 24 for g in range(world)] and all(int(v[1]) == 24 for v in allv)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_search_two_ranks_gloo(tmp_path, oracle):
+    world = 2
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r = [np.load(os.path.join(tmp_path, "rank%d.npz" % i)) for i in range(world)]
+    # identical on every rank
+    assert (r[0]["ids"] == r[1]["ids"]).all() and r[0]["ds"].tobytes() == r[1]["ds"].tobytes()
+    assert (r[0]["cnt"] == r[1]["cnt"]).all()
+    # equals a single-process recomputation: per-shard CPU search + merge
+    from granne_amd import sharded
+    el, q = _data()
+    bounds = sharded.shard_bounds(len(el), world)
+    assert r[0]["offsets"].tolist() == [b[0] for b in bounds]
+    per_shard = []
+    for lo, hi in bounds:
+        ix = oracle.build_index(np.ascontiguousarray(el[lo:hi]), num_neighbors=8, max_search=20)
+        per_shard.append(ix.search_batch(q, 20, 5))
+    ids = np.stack([p[0] for p in per_shard])
+    ds = np.stack([p[1] for p in per_shard])
+    cnt = np.stack([p[2] for p in per_shard])
+    want = sharded.merge_topk_numpy(ids, ds, cnt, [b[0] for b in bounds], 5)
+    assert (r[0]["ids"].astype(np.uint64) == want[0]).all()
+    assert r[0]["ds"].tobytes() == want[1].tobytes()
+    # global ids really point at the right elements: distances recomputed from the full set
+    for qi in range(len(q)):
+        for j in range(int(want[2][qi])):
+            assert oracle.dist(el[int(want[0][qi, j])], q[qi]) == float(want[1][qi, j])
+    # and the merged list is at least as good as any single shard's
+    assert (want[1][:, 0] <= ds[:, :, 0].min(axis=0)).all()
+
+
+def test_shard_bounds():
+    from granne_amd import sharded
+    assert sharded.shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert sharded.shard_bounds(100_000_000, 8)[7] == (87_500_000, 100_000_000)
+    assert sharded.shard_bounds(3, 8)[5] == (3, 3)
