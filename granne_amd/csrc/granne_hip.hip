@@ -570,7 +570,8 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     if (const char* e = getenv("GRANNE_HIP_SPEC")) p.spec = atoi(e) ? 1 : 0;
 
     search_fn fn = pick_kernel(ix->dtype, ix->dim, ef > 256 ? 256 : ef);
-    if (plan.lds_bytes > 48u * 1024u)
+    if (const char* e = getenv("GRANNE_HIP_LDS_PAD")) plan.lds_bytes += (uint32_t)atoi(e); // occupancy experiments
+    if (plan.lds_bytes > 32u * 1024u)
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes));
     hipLaunchKernelGGL(fn, dim3(nq), dim3(64), plan.lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
