@@ -172,7 +172,7 @@ static BuildKernels pick_build_kernels(int dtype, uint32_t dim) {
 struct BuildScratch {
     uint64_t *s_ids = nullptr, *op_keys = nullptr, *op_vals = nullptr, *sorted_keys = nullptr, *sorted_vals = nullptr;
     float* s_dists = nullptr;
-    uint32_t *s_counts = nullptr, *seg_start = nullptr, *counters = nullptr; // counters: [0]=n_seg [1]=status
+    uint32_t *s_counts = nullptr, *seg_start = nullptr, *counters = nullptr; // counters: [0]=n_seg [1]=status [2]=slow count
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     LayerDev* d_layers = nullptr;

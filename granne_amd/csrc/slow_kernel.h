@@ -20,7 +20,7 @@ struct SlowParams {
     uint64_t* res;   // [blocks][ef]      max-heap of keys
     uint32_t slots;  // power of two
     uint32_t* status;// set to 1 when a walk exhausts `slots`
-    uint32_t* status2; // caller's copy of the same flag (optional)
+    uint32_t* status2; // caller's u32[2] (optional): [0] same flag, [1] += queries that took this path
 };
 
 // binary heaps over u64 keys, run by one lane
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
     uint64_t* pq = P.pq + (size_t)blockIdx.x * P.slots;
     uint64_t* res = P.res + (size_t)blockIdx.x * p.ef;
     const uint32_t n_slow = *p.slow_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.status2 && n_slow) atomicAdd(P.status2 + 1, n_slow);
 
     for (uint32_t si = blockIdx.x; si < n_slow; si += gridDim.x) {
         const uint32_t qi = p.slow_list[si];
