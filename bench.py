@@ -133,7 +133,7 @@ def main():
     dists = torch.empty((n_batches, nq, k), dtype=torch.float32, device="cuda")
     counts = torch.empty((n_batches, nq), dtype=torch.int32, device="cuda")
     stats = torch.zeros((n_batches, nq, 3), dtype=torch.int64, device="cuda")
-    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
 
     def step(b, ef_=None, out=None, on=None):
         o_ids, o_d, o_c, o_s = out if out is not None else (ids[b], dists[b], counts[b], stats[b])
@@ -204,7 +204,7 @@ def main():
         "metric": "queries/sec (recall@10 alongside), 10M x 100-d angular, batch=1024",
         "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "inflight_batches": inflight, "slow_path_queries": slow_timed,
+        "inflight_batches": inflight, "slow_path_queries": slow_timed, "lds_retry_queries": int(status[2].item()),
         "sequential": {"value": round(args.steps * nq / seq_elapsed, 1), "ms_per_step": round(seq_elapsed / args.steps * 1e3, 4),
                        "note": "same K steps, one stream, one batch at a time (rank-local)"},
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

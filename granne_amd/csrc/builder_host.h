@@ -342,8 +342,8 @@ static int index_elements_in_last_layer(granne_hip_builder* b, uint64_t max_num_
         HIP_TRY(hipMalloc((void**)&S.sorted_keys, n_ops_max * 8));
         HIP_TRY(hipMalloc((void**)&S.sorted_vals, n_ops_max * 8));
         HIP_TRY(hipMalloc((void**)&S.seg_start, n_ops_max * 4));
-        HIP_TRY(hipMalloc((void**)&S.counters, 16));
-        HIP_TRY(hipMemsetAsync(S.counters, 0, 16, s));
+        HIP_TRY(hipMalloc((void**)&S.counters, 32));
+        HIP_TRY(hipMemsetAsync(S.counters, 0, 32, s));
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, S.sort_tmp_bytes, S.op_keys, S.sorted_keys, S.op_vals,
                                                    S.sorted_vals, (int)n_ops_max, 0, OP_KEY_BITS, s));
         HIP_TRY(hipMalloc(&S.sort_tmp, S.sort_tmp_bytes ? S.sort_tmp_bytes : 16));

@@ -543,17 +543,20 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     LaunchPlan plan = plan_launch(ix, ef > 256 ? 256 : ef);
     if (plan.lds_bytes > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
 
-    // stream-ordered scratch: slow list + slow-path containers
+    // stream-ordered scratch: hand-over lists + slow-path containers.
+    // header words: [0] count of list 1 (main launch), [1] overflow flag, [2] count of list 2 (retry)
     const uint32_t slow_blocks = (uint32_t)ix->opt_slow_blocks;
     const uint32_t slots = (uint32_t)ix->opt_slow_slots;
+    const size_t list_bytes = ((size_t)nq * 4 + 15) & ~(size_t)15;
     size_t off_list = 16;
-    size_t off_vis = off_list + (((size_t)nq * 4 + 15) & ~(size_t)15);
+    size_t off_list2 = off_list + list_bytes;
+    size_t off_vis = off_list2 + list_bytes;
     size_t off_pq = off_vis + (size_t)slow_blocks * slots * 4;
     size_t off_res = off_pq + (size_t)slow_blocks * slots * 8;
     size_t total = off_res + (size_t)slow_blocks * ef * 8;
     uint8_t* scratch = nullptr;
     HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
-    HIP_TRY(hipMemsetAsync(scratch, 0, 16, s)); // [0]=slow_count, [1]=status
+    HIP_TRY(hipMemsetAsync(scratch, 0, 16, s));
 
     SearchParams p;
     p.elements = ix->d_elements;
@@ -582,16 +585,44 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.force_slow = all_slow ? 1 : 0;
     p.spec = 1;
     if (const char* e = getenv("GRANNE_HIP_SPEC")) p.spec = atoi(e) ? 1 : 0;
+    p.qlist = nullptr;
+    p.qcount = nullptr;
+    p.retry_total = nullptr;
 
     search_fn fn = pick_kernel(ix->dtype, ix->dim, ef > 256 ? 256 : ef);
     if (const char* e = getenv("GRANNE_HIP_LDS_PAD")) plan.lds_bytes += (uint32_t)atoi(e); // occupancy experiments
-    if (plan.lds_bytes > 32u * 1024u)
-        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes));
+    // the retry launch (below) needs up to 4x the visited table: raise the limit once for both
+    const bool retry = !all_slow && !ix->opt_visited_slots && plan.visited_slots < 32768;
+    const uint32_t retry_slots = plan.visited_slots * 4 > 32768 ? 32768 : plan.visited_slots * 4;
+    const uint32_t retry_lds = plan.lds_bytes + (retry ? (retry_slots - plan.visited_slots) * 4u : 0u);
+    if (retry_lds > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
+    if (retry_lds > 32u * 1024u)
+        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)retry_lds));
     hipLaunchKernelGGL(fn, dim3(nq), dim3(64), plan.lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
 
+    // second chance in LDS for walks whose visited table filled: same kernel, 4x the table
+    uint32_t* final_count = p.slow_count;
+    uint32_t* final_list = p.slow_list;
+    if (retry) {
+        SearchParams r = p;
+        r.qlist = p.slow_list;
+        r.qcount = p.slow_count;
+        r.visited_slots = retry_slots;
+        r.slow_count = ((uint32_t*)scratch) + 2;
+        r.slow_list = (uint32_t*)(scratch + off_list2);
+        r.retry_total = d_status ? d_status + 2 : nullptr;
+        uint32_t grid = nq < 128 ? nq : 128;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(64), retry_lds, s, r);
+        HIP_TRY(hipGetLastError());
+        final_count = r.slow_count;
+        final_list = r.slow_list;
+    }
+
     SlowParams sp;
     sp.sp = p;
+    sp.sp.slow_count = final_count;
+    sp.sp.slow_list = final_list;
     sp.vis = (uint32_t*)(scratch + off_vis);
     sp.pq = (uint64_t*)(scratch + off_pq);
     sp.res = (uint64_t*)(scratch + off_res);
@@ -606,10 +637,10 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     HIP_TRY(hipGetLastError());
 
     if (h_slow_count) {
-        uint32_t hs[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(hs, scratch, 8, hipMemcpyDeviceToHost, s));
+        uint32_t hs[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(hs, scratch, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        h_slow_count[0] = hs[0];
+        h_slow_count[0] = retry ? hs[2] : hs[0]; // queries served by the global-memory walker
         h_slow_count[1] = hs[1];
     }
     HIP_TRY(hipFreeAsync(scratch, s));

@@ -60,6 +60,9 @@ struct SearchParams {
     uint32_t* slow_list;     // [nq]
     uint32_t force_slow;
     uint32_t spec;           // 1: speculative adjacency prefetch (narrow layers)
+    const uint32_t* qlist;   // retry launch: walk queries qlist[0..*qcount) instead of 0..nq
+    const uint32_t* qcount;
+    uint32_t* retry_total;   // optional: += *qcount (statistics)
 };
 
 struct WalkStats {
@@ -531,12 +534,8 @@ struct Walker {
 };
 
 template <int DT, int DIM, int S>
-__global__ __launch_bounds__(64) void search_kernel(const SearchParams p) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    const uint32_t qi = blockIdx.x;
-    if (qi >= p.nq) return;
+__device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t qi, uint8_t* smem) {
     const uint32_t lane = threadIdx.x;
-
     if (p.force_slow) {
         if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
         return;
@@ -586,6 +585,25 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchParams p) {
             p.out_stats[(size_t)qi * 3 + 1] = w.st.n_expand;
             p.out_stats[(size_t)qi * 3 + 2] = w.st.n_adj;
         }
+    }
+}
+
+
+// Main launch: block b walks query b. Retry launch (qlist != null): the blocks share the queries
+// the main launch handed over because their LDS visited table filled; they rerun them, untouched,
+// with a larger table -- same code, same results -- before the global-memory walker is considered.
+template <int DT, int DIM, int S>
+__global__ __launch_bounds__(64) void search_kernel(const SearchParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    if (p.qlist) {
+        const uint32_t n = *p.qcount;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && p.retry_total && n) atomicAdd(p.retry_total, n);
+        for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+            __syncthreads();
+            walk_one<DT, DIM, S>(p, p.qlist[i], smem);
+        }
+    } else if (blockIdx.x < p.nq) {
+        walk_one<DT, DIM, S>(p, blockIdx.x, smem);
     }
 }
 

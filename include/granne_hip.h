@@ -121,10 +121,10 @@ int granne_hip_search_batch(const granne_hip_index* index, const void* queries, 
                             float* out_dists, uint32_t* out_counts, uint64_t* out_stats);
 
 /* Device-resident variant: all pointers are device memory on the index's device; the work is
- * enqueued on `stream` (a hipStream_t) and NOT synchronised. d_status (u32[2], optional, zeroed by
+ * enqueued on `stream` (a hipStream_t) and NOT synchronised. d_status (u32[4], optional, zeroed by
  * the caller): [0] is set to 1 if any query exhausted the exact-search scratch
- * (GRANNE_HIP_ERR_OVERFLOW); [1] accumulates the number of queries served by the exact
- * global-memory walker instead of the LDS walker.          */
+ * (GRANNE_HIP_ERR_OVERFLOW); [1] accumulates the queries served by the exact global-memory
+ * walker; [2] accumulates the queries that needed the second LDS pass (4x visited table).          */
 int granne_hip_search_batch_device(const granne_hip_index* index, const void* d_queries, uint32_t nq,
                                    uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
                                    float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,

@@ -360,7 +360,7 @@ def test_device_resident_api(ga, oracle):
     ds = torch.empty((256, 10), dtype=torch.float32, device="cuda")
     cnt = torch.empty(256, dtype=torch.int32, device="cuda")
     st = torch.empty((256, 3), dtype=torch.int64, device="cuda")
-    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
     gix.search_batch_device(dq.data_ptr(), 256, 50, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(),
                             st.data_ptr(), status.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -369,4 +369,4 @@ def test_device_resident_api(ga, oracle):
     assert ds.cpu().numpy().tobytes() == od.tobytes()
     assert (cnt.cpu().numpy().astype(np.uint32) == oc).all()
     assert (st.cpu().numpy().astype(np.uint64) == octr).all()
-    assert status.tolist() == [0, 0]
+    assert status.tolist() == [0, 0, 0, 0]
