@@ -67,6 +67,13 @@ SIGNATURES = {
     "granne_hip_quantize_f32": (i32, [vp, vp, u64, u32, i32]),
     "granne_hip_dist_pairs": (i32, [vp, vp, u32, vp, vp, u64, vp]),
     "granne_hip_synth_rows_device": (i32, [vp, u64, u64, u64, u32, i32, vp]),
+    "granne_hip_index_load": (i32, [C.POINTER(vp), vp, u64, vp, u64, i32, i32]),
+    "granne_hip_index_load_files": (i32, [C.POINTER(vp), C.c_char_p, C.c_char_p, i32, i32]),
+    "granne_hip_write_index_file": (i32, [C.c_char_p, u32, vp, vp, vp]),
+    "granne_hip_write_elements_file": (i32, [C.c_char_p, vp, u64, u32, i32]),
+    "granne_hip_index_save": (i32, [vp, C.c_char_p, C.c_char_p]),
+    "granne_hip_index_file_info": (i32, [vp, u64, C.POINTER(u32), vp, vp, u32]),
+    "granne_hip_index_file_decode_layer": (i32, [vp, u64, u32, vp, vp]),
     "granne_hip_merge_topk_device": (i32, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, i32, vp]),
     "granne_hip_build_config_default": (None, [vp]),
     "granne_hip_builder_create": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, i32]),

@@ -139,6 +139,24 @@ class GranneBuilder:
         ix.dim = self.dim
         return ix
 
+    def save_index(self, path):
+        """GranneBuilder.save_index (py/src/lib.rs:509-521): the compressed on-disk form."""
+        import os
+        layers = self.layers()
+        n = len(layers)
+        lens = (C.c_uint64 * max(n, 1))(*[l.shape[0] for l in layers])
+        widths = (C.c_uint32 * max(n, 1))(*[l.shape[1] for l in layers])
+        rows = (C.c_void_p * max(n, 1))(*[l.ctypes.data for l in layers])
+        check(lib().granne_hip_write_index_file(os.fsencode(path), n, lens, rows, widths))
+
+    def save_elements(self, path):
+        """GranneBuilder.save_elements (py/src/lib.rs:523-535)."""
+        ix = self.get_index()
+        try:
+            ix.save_elements(path)
+        finally:
+            ix.close()
+
     def close(self):
         if getattr(self, "_h", None):
             lib().granne_hip_builder_destroy(self._h)

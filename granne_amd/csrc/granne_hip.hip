@@ -880,3 +880,8 @@ extern "C" int granne_hip_dist_pairs(const granne_hip_index* ix, const void* que
 // GranneBuilder on the GPU
 // ------------------------------------------------------------------------------------------------
 #include "builder_host.h"
+
+// ------------------------------------------------------------------------------------------------
+// granne's file formats
+// ------------------------------------------------------------------------------------------------
+#include "fileformat_host.h"

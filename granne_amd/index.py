@@ -8,6 +8,7 @@ callers loop or par_iter over `search`). Elements are prepared like the referenc
 angular_int::Vector::from (src/elements/angular_int.rs:19-45), both executed on the device.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -98,6 +99,50 @@ class Granne:
         self._h = h
         self.dim = el.shape[1]
         return self
+
+    @classmethod
+    def from_files(cls, index_path, element_type, elements_path, device=0):
+        """Granne(index_path, element_type, elements_path) of the reference's binding
+        (py/src/lib.rs:177-214): an index file written by write_index + a Vectors file."""
+        self = cls.__new__(cls)
+        et = element_type.lower()
+        if et not in _ELEMENT_TYPES:
+            raise ValueError("Invalid element type")
+        self.element_type = et
+        self.dtype_code, self.np_dtype = _ELEMENT_TYPES[et]
+        self.device = device
+        h = C.c_void_p()
+        check(lib().granne_hip_index_load_files(C.byref(h), os.fsencode(index_path), os.fsencode(elements_path),
+                                                self.dtype_code, device))
+        self._h = h
+        self.dim = int(lib().granne_hip_index_dim(h))
+        return self
+
+    @classmethod
+    def from_bytes(cls, index_bytes, element_type, elements_bytes, device=0):
+        """Granne::from_bytes (src/index/mod.rs:106-113) over Vectors::from_bytes."""
+        self = cls.__new__(cls)
+        et = element_type.lower()
+        if et not in _ELEMENT_TYPES:
+            raise ValueError("Invalid element type")
+        self.element_type = et
+        self.dtype_code, self.np_dtype = _ELEMENT_TYPES[et]
+        self.device = device
+        ib = np.frombuffer(index_bytes, np.uint8)
+        eb = np.frombuffer(elements_bytes, np.uint8)
+        h = C.c_void_p()
+        check(lib().granne_hip_index_load(C.byref(h), _p(ib), ib.size, _p(eb), eb.size, self.dtype_code, device))
+        self._h = h
+        self.dim = int(lib().granne_hip_index_dim(h))
+        return self
+
+    def save_index(self, path):
+        """py/src/lib.rs:318-330."""
+        check(lib().granne_hip_index_save(self._h, os.fsencode(path), None))
+
+    def save_elements(self, path):
+        """py/src/lib.rs:332-343."""
+        check(lib().granne_hip_index_save(self._h, None, os.fsencode(path)))
 
     @classmethod
     def from_device(cls, element_type, d_elements_ptr, n_elements, dim, layer_lens, d_layer_ptrs, layer_widths,

@@ -156,6 +156,36 @@ int granne_hip_dist_pairs(const granne_hip_index* index, const void* queries, ui
 int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
                                  int device_id, void* stream);
 
+/* ---- granne's files ------------------------------------------------------------------------------
+ * granne_hip_index_load: Granne::from_bytes(index, Vectors::from_bytes(elements))
+ * (src/index/mod.rs:106-113, src/elements/dense_vector.rs:49-51). `index_bytes` is an index file
+ * as written by Index::write_index (src/index/io.rs:11-70: 1 KiB "granne"+JSON header, then one
+ * compressed MultiSetVector blob per layer); `elements_bytes` is a Vectors file ([u64 dim][raw
+ * scalars], src/slice_vector/mod.rs:213-221, 460-466). Every neighbor list is decoded once on
+ * the host (stream-vbyte / raw, delta, src/slice_vector/set_vector.rs:91-162) and uploaded; the
+ * buffers may be unmapped afterwards. _load_files maps the two files itself
+ * (Granne::from_file, src/index/mod.rs:122-135).                                              */
+int granne_hip_index_load(granne_hip_index** out, const void* index_bytes, uint64_t index_len,
+                          const void* elements_bytes, uint64_t elements_len, int dtype, int device_id);
+int granne_hip_index_load_files(granne_hip_index** out, const char* index_path, const char* elements_path,
+                                int dtype, int device_id);
+/* Index::write_index for fixed-width layers (what a builder holds) and Writeable::write for
+ * Vectors: files the reference (and granne_hip_index_load) reads. */
+int granne_hip_write_index_file(const char* path, uint32_t n_layers, const uint64_t* layer_len,
+                                const uint32_t* const* layer_rows, const uint32_t* layer_width);
+int granne_hip_write_elements_file(const char* path, const void* elements, uint64_t n_elements, uint32_t dim,
+                                   int dtype);
+/* save_index / save_elements of a device-resident index (py/src/lib.rs:318-343); either path may
+ * be NULL. */
+int granne_hip_index_save(const granne_hip_index* index, const char* index_path, const char* elements_path);
+/* Host-only inspection of an index file (no device involved): layer count, nodes and ids per
+ * layer (arrays of `cap` entries), and the decoded CSR form of one layer
+ * (out_offsets[layer_len + 1], out_ids[ids of that layer], ascending within a node). */
+int granne_hip_index_file_info(const void* index_bytes, uint64_t index_len, uint32_t* out_n_layers,
+                               uint64_t* out_layer_len, uint64_t* out_layer_ids, uint32_t cap);
+int granne_hip_index_file_decode_layer(const void* index_bytes, uint64_t index_len, uint32_t layer,
+                                       uint64_t* out_offsets, uint32_t* out_ids);
+
 /* ---- partitioned indexes: merge of per-shard results --------------------------------------------
  * The element set partitions into independent indexes (how the reference's own shard helper is
  * meant to be used, src/elements/embeddings/parsing.rs:63-100). Every shard answers the same
