@@ -52,8 +52,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--ef", type=int, default=50)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--build-max-search", type=int, default=50)
-    ap.add_argument("--build-reinsert", type=int, default=0)
+    # graph: BuildConfig::default() of the reference (src/index/mod.rs:220-231)
+    ap.add_argument("--build-max-search", type=int, default=200)
+    ap.add_argument("--build-reinsert", type=int, default=1)
     ap.add_argument("--num-neighbors", type=int, default=30)
     ap.add_argument("--batch-max", type=int, default=65536)
     ap.add_argument("--inflight", type=int, default=2,
@@ -191,9 +192,21 @@ def main():
     alg_bytes_per_launch = alg_bytes_total / args.steps
     mean_launch_ms = float(np.mean(step_ms))
     achieved = alg_bytes_per_launch / (mean_launch_ms * 1e-3) / 1e9
+    # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, see
+    # profiles/README.md): measured offline with tools/gpu_prof.sh on this exact workload and
+    # committed in profiles/pmc_traffic.json; null when no measurement matches this configuration
+    traffic = None
+    wl_key = "%d|%d|%s|nq%d|ef%d|k%d|nn%d|ms%d|re%d" % (n, dim, args.dtype, nq, ef, k, args.num_neighbors,
+                                                     args.build_max_search, args.build_reinsert)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get(wl_key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
     roofline = {
         "bound": "hbm", "kernel": "search_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "aggregate_achieved_with_inflight": round(alg_bytes_per_launch * (value / world / nq) / 1e9, 1),
         "alg_bytes_per_launch": int(alg_bytes_per_launch), "launch_ms_mean": round(mean_launch_ms, 4),
         "launch_ms_min": round(float(np.min(step_ms)), 4),
         "per_query": {"n_dist": round(st[0] / (args.steps * nq), 1), "n_expand": round(st[1] / (args.steps * nq), 1),
