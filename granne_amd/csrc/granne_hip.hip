@@ -493,16 +493,15 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef) {
     P.visited_slots = want;
     P.upper_slots = want < 1024 ? want : 1024;
     const bool reg_spec = ix->dtype == GRANNE_HIP_F32 && (ix->dim == 100 || ix->dim == 200); // templated f32 kernels
-    P.adjspec_bytes = reg_spec ? 0u : LDS_ADJSPEC_BYTES;
+    P.adjspec_bytes = (reg_spec || ix->dtype == GRANNE_HIP_I8) ? 0u : LDS_ADJSPEC_BYTES; // Walker::REGSPEC
     uint32_t fixed = lds_query_bytes(ix->row_bytes) + LDS_FIXED_BYTES + P.adjspec_bytes;
     if (ix->dtype == GRANNE_HIP_F32) {
         uint32_t row16 = ix->row_bytes / 16;
         P.lrow_bytes = (row16 | 1u) * 16u; // odd number of 16-byte units: conflict-free ds_read_b128
         if (reg_spec) {
-            // column-streamed stage (search_kernel.h): 32 rows x 144 B; the whole-row path (entry
-            // point, layers wider than 32) uses the same bytes for as many full rows as fit
-            P.stage_bytes = COLSTAGE_BYTES;
-            while (P.stage_bytes < P.lrow_bytes) P.stage_bytes += COLSTAGE_BYTES;
+            // the fast expansion (search_kernel.h, fast_rows) keeps rows in registers; an LDS stage
+            // is only needed by the whole-row path that serves layers wider than 32 ids
+            P.stage_bytes = ix->max_dev_width > 32 ? 8u * P.lrow_bytes : 0u;
             P.maxc = P.stage_bytes / P.lrow_bytes;
         } else {
             uint32_t wmax = ix->max_dev_width < 64 ? ix->max_dev_width : 64;
@@ -584,7 +583,6 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.slow_list = (uint32_t*)(scratch + off_list);
     p.force_slow = all_slow ? 1 : 0;
     p.spec = 1;
-    if (const char* e = getenv("GRANNE_HIP_SPEC")) p.spec = atoi(e) ? 1 : 0;
     p.qlist = nullptr;
     p.qcount = nullptr;
     p.retry_total = nullptr;

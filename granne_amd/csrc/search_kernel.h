@@ -89,8 +89,15 @@ struct Walker {
     uint8_t* stage;
     uint32_t* vis_tab;
     int dy; // i8: sum of squares of the query
-    float qv[(DT == DT_F32 && DIM > 0) ? DIM : 1]; // f32, known dim: the query lives in registers
-    uint4 sa0, sa1, sa2, sa3; // f32, known dim: speculative adjacency rows stay in registers
+    // paths whose speculative adjacency rows stay in registers (everything but runtime-dim f32)
+    static constexpr bool REGSPEC = (DT == DT_I8) || (DIM > 0);
+    static constexpr bool FASTF32 = (DT == DT_F32) && (DIM > 0);
+    static constexpr int NB = FASTF32 ? DIM / 32 : 0;          // full 32-float blocks of a row
+    static constexpr int TAILU = FASTF32 ? (DIM % 32) / 4 : 0; // 16-byte units of the tail
+    static_assert(TAILU <= 2, "fast f32 path: tail of at most 8 floats (dims 100, 200, multiples of 32)");
+    float qpc[FASTF32 ? (NB + (TAILU ? 1 : 0)) * 4 : 1]; // fast path: this lane's pieces of the query
+    uint4 qpiece;                                  // i8, 128-byte rows: this lane's 16 bytes of the query
+    uint4 sa0, sa1, sa2, sa3; // REGSPEC: speculative adjacency rows stay in registers
     // ---- per-walk state
     VisitedSet vis;
     SortedList<S> res; // `res`, capped at ef entries
@@ -120,8 +127,17 @@ struct Walker {
             float* l = reinterpret_cast<float*>(lds_q);
             for (uint32_t i = lane; i < p.row_bytes / 4; i += 64) l[i] = (i < p.dim) ? q[i] : 0.0f;
             if constexpr (DT == DT_F32 && DIM > 0) {
+                // fast path pieces: block b -> q[32b + 4*(lane&7) ..+3]; tail -> q[32NB + 4*part ..+3]
+                const uint32_t sub = lane & 7u;
 #pragma unroll
-                for (int k = 0; k < DIM; ++k) qv[k] = q[k];
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qpc[b * 4 + j] = q[b * 32 + sub * 4 + j];
+                if constexpr (TAILU > 0) {
+                    const uint32_t part = (TAILU == 2) ? (lane & 1u) : 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qpc[NB * 4 + j] = q[NB * 32 + part * 4 + j];
+                }
             }
         } else {
             const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
@@ -136,6 +152,7 @@ struct Walker {
             dy = part; // exact i32, identical in every lane
         }
         __syncthreads();
+        if constexpr (DT == DT_I8) qpiece = *reinterpret_cast<const uint4*>(lds_q + (size_t)(lane & 7u) * 16u);
     }
 
     // distances of candidates cand[0..m) (m <= 64) to the query; lane c < m returns d(c)
@@ -186,7 +203,7 @@ struct Walker {
                     const float* x = reinterpret_cast<const float*>(stage + (size_t)(lane - g0) * p.lrow_bytes);
                     const float* q = reinterpret_cast<const float*>(lds_q);
                     float r;
-                    if constexpr (DIM > 0) r = dot_f32_exact_qreg<DIM>(x, qv);
+                    if constexpr (DIM > 0) r = dot_f32_exact<DIM>(x, q);
                     else r = dot_f32_exact_rt(x, q, p.dim);
                     d = angular_from_dot(r);
                 }
@@ -244,15 +261,12 @@ struct Walker {
         }
     }
 
-    // ---- narrow layers (device row width 32, the default 30/15-neighbor graphs) --------------------
-    // Everything one expansion needs from HBM is requested in ONE round trip: the candidates'
-    // element rows AND, speculatively, their adjacency rows (the next node to expand is either
-    // the queue's current head -- prefetched into registers at the start of the expansion -- or
-    // one of these candidates). Speculation only moves loads of immutable data earlier; the
-    // walk's logic, and so its result, is unchanged.
-    static constexpr int NSTEP = (DT == DT_F32 && DIM > 0) ? (32 * (DIM / 4) + 63) / 64 : 1;
-
-    // distances of cand[0..m), m <= 32 <= maxc, plus the speculative adjacency fetch
+    // ---- narrow layers (device row width 32) on the paths without a fast expansion -----------------
+    // (f32 with a runtime dim, i8 rows other than 128 bytes): candidates are compacted through LDS
+    // and `distances` gathers their rows; the candidates' adjacency rows are still fetched
+    // speculatively in the same round trip (the next node to expand is either the queue's current
+    // head -- prefetched into registers at the start of the expansion -- or one of these
+    // candidates). Speculation only moves loads of immutable data earlier.
     __device__ __forceinline__ float distances_narrow(uint32_t m, gptr_u32 adj) {
         float d = 0.0f;
         // adjacency rows of the candidates: 8 lanes x 16 bytes per row, 8 rows per step
@@ -264,110 +278,17 @@ struct Walker {
         uint32_t fc = f < au ? f : au - 1u;                                                           \
         A = load_global_u4(adj + (size_t)cand[fc >> 3] * 32u + (fc & 7u) * 4u);                        \
     }
-        if constexpr (DT == DT_F32 && DIM > 0) {
-            // Column-streamed: the 32 x DIM rows never sit in LDS as a whole. All loads are issued
-            // at once into named registers, instruction (b, i) covering the b-th 32-float column
-            // block of rows 8i..8i+7 (8 lanes x 16 B per row); then block after block goes through
-            // a 32 x 144 B stage and one lane per candidate folds it into the reference's 32
-            // accumulators -- chunk order and accumulator assignment exactly as src/math.rs:17-42.
-            constexpr int NB = DIM / 32;         // full 32-float blocks
-            constexpr int TAILU = (DIM % 32) / 4; // 16-byte units of the tail (DIM % 4 == 0)
-            static_assert(NB <= 8 && TAILU * 32 <= 64 * 4, "extend the register lists");
-            const uint32_t r0 = min(lane >> 3, m - 1), r1 = min(8u + (lane >> 3), m - 1), r2 = min(16u + (lane >> 3), m - 1),
-                           r3 = min(24u + (lane >> 3), m - 1);
-            const uint8_t* e0 = p.elements + (size_t)cand[r0] * p.row_bytes + (lane & 7u) * 16u;
-            const uint8_t* e1 = p.elements + (size_t)cand[r1] * p.row_bytes + (lane & 7u) * 16u;
-            const uint8_t* e2 = p.elements + (size_t)cand[r2] * p.row_bytes + (lane & 7u) * 16u;
-            const uint8_t* e3 = p.elements + (size_t)cand[r3] * p.row_bytes + (lane & 7u) * 16u;
-#define GRANNE_BLK_LOAD(B)                                                                             \
-    uint4 v##B##_0 = make_uint4(0, 0, 0, 0), v##B##_1 = v##B##_0, v##B##_2 = v##B##_0, v##B##_3 = v##B##_0; \
-    if constexpr ((B) < NB) {                                                                          \
-        v##B##_0 = *reinterpret_cast<const uint4*>(e0 + (B) * 128);                                    \
-        v##B##_1 = *reinterpret_cast<const uint4*>(e1 + (B) * 128);                                    \
-        v##B##_2 = *reinterpret_cast<const uint4*>(e2 + (B) * 128);                                    \
-        v##B##_3 = *reinterpret_cast<const uint4*>(e3 + (B) * 128);                                    \
-    }
-#define GRANNE_FOR_BLOCKS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-            GRANNE_FOR_BLOCKS(GRANNE_BLK_LOAD)
-            // tail units: unit g = i*64 + lane -> row g / TAILU, part g % TAILU
-#define GRANNE_TAIL_LOAD(I)                                                                            \
-    uint4 vt##I = make_uint4(0, 0, 0, 0);                                                              \
-    if constexpr (TAILU > 0 && (I) * 64 < 32 * TAILU) {                                                \
-        uint32_t g = (I) * 64u + lane;                                                                 \
-        uint32_t row = min(g / (uint32_t)(TAILU > 0 ? TAILU : 1), m - 1);                              \
-        uint32_t part = g % (uint32_t)(TAILU > 0 ? TAILU : 1);                                         \
-        vt##I = *reinterpret_cast<const uint4*>(p.elements + (size_t)cand[row] * p.row_bytes + NB * 128 + part * 16u); \
-    }
-            GRANNE_TAIL_LOAD(0) GRANNE_TAIL_LOAD(1) GRANNE_TAIL_LOAD(2) GRANNE_TAIL_LOAD(3)
-            GRANNE_ASPEC(0, a0) GRANNE_ASPEC(1, a1) GRANNE_ASPEC(2, a2) GRANNE_ASPEC(3, a3)
-            // Pin every load above this point (an empty asm consumes a value derived from all of
-            // them): otherwise hipcc sinks them into the guarded LDS writes below and they serialise.
-            {
-                uint32_t chk = vt0.x ^ vt1.x ^ vt2.x ^ vt3.x;
-#define GRANNE_BLK_CHK(B) chk ^= v##B##_0.x ^ v##B##_1.x ^ v##B##_2.x ^ v##B##_3.x;
-                GRANNE_FOR_BLOCKS(GRANNE_BLK_CHK)
-#undef GRANNE_BLK_CHK
-                asm volatile("" ::"v"(chk));
-            }
-            sa0 = a0; sa1 = a1; sa2 = a2; sa3 = a3; // stay in registers until the next expansion
-
-            float acc[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) acc[i] = 0.0f;
-            const uint32_t wrow = lane >> 3, wpart = lane & 7u; // this lane's slot in a block write
-            uint8_t* wdst = stage + (size_t)wrow * COLSTAGE_ROW_BYTES + wpart * 16u;
-            const float* x = reinterpret_cast<const float*>(stage + (size_t)lane * COLSTAGE_ROW_BYTES);
-#define GRANNE_BLK_FOLD(B)                                                                             \
-    if constexpr ((B) < NB) {                                                                          \
-        if (wrow < m) *reinterpret_cast<uint4*>(wdst) = v##B##_0;                                      \
-        if (8u + wrow < m) *reinterpret_cast<uint4*>(wdst + 8 * COLSTAGE_ROW_BYTES) = v##B##_1;        \
-        if (16u + wrow < m) *reinterpret_cast<uint4*>(wdst + 16 * COLSTAGE_ROW_BYTES) = v##B##_2;      \
-        if (24u + wrow < m) *reinterpret_cast<uint4*>(wdst + 24 * COLSTAGE_ROW_BYTES) = v##B##_3;      \
-        __syncthreads();                                                                               \
-        if (lane < m) {                                                                                \
-            _Pragma("unroll") for (int k = 0; k < 32; k += 4) {                                        \
-                float4 xa = *reinterpret_cast<const float4*>(x + k);                                   \
-                acc[k + 0] = __builtin_fmaf(xa.x, qv[(B) * 32 + k + 0], acc[k + 0]);                   \
-                acc[k + 1] = __builtin_fmaf(xa.y, qv[(B) * 32 + k + 1], acc[k + 1]);                   \
-                acc[k + 2] = __builtin_fmaf(xa.z, qv[(B) * 32 + k + 2], acc[k + 2]);                   \
-                acc[k + 3] = __builtin_fmaf(xa.w, qv[(B) * 32 + k + 3], acc[k + 3]);                   \
-            }                                                                                          \
-        }                                                                                              \
-        __syncthreads();                                                                               \
-    }
-            GRANNE_FOR_BLOCKS(GRANNE_BLK_FOLD)
-            float r = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) r = r + acc[i]; // ordered sum, src/math.rs:27-30
-            if constexpr (TAILU > 0) {
-#define GRANNE_TAIL_STORE(I)                                                                           \
-    if constexpr ((I) * 64 < 32 * TAILU) {                                                             \
-        uint32_t g = (I) * 64u + lane;                                                                 \
-        uint32_t row = g / (uint32_t)TAILU, part = g % (uint32_t)TAILU;                                \
-        if (row < m) *reinterpret_cast<uint4*>(stage + (size_t)row * COLSTAGE_ROW_BYTES + part * 16u) = vt##I; \
-    }
-                GRANNE_TAIL_STORE(0) GRANNE_TAIL_STORE(1) GRANNE_TAIL_STORE(2) GRANNE_TAIL_STORE(3)
-#undef GRANNE_TAIL_STORE
-                __syncthreads();
-                if (lane < m) {
-#pragma unroll
-                    for (int k = 0; k < TAILU * 4; ++k) r = __builtin_fmaf(x[k], qv[NB * 32 + k], r); // :32-39
-                }
-                __syncthreads();
-            }
-            if (lane < m) d = angular_from_dot(r);
-#undef GRANNE_BLK_LOAD
-#undef GRANNE_BLK_FOLD
-#undef GRANNE_FOR_BLOCKS
-#undef GRANNE_TAIL_LOAD
+        GRANNE_ASPEC(0, a0) GRANNE_ASPEC(1, a1) GRANNE_ASPEC(2, a2) GRANNE_ASPEC(3, a3)
+#undef GRANNE_ASPEC
+        asm volatile("" ::: "memory"); // the loads above may not sink below this line
+        if constexpr (REGSPEC) {
+            sa0 = a0; sa1 = a1; sa2 = a2; sa3 = a3;
+            d = distances(m); // its own row loads overlap with the ones in flight
         } else {
-            GRANNE_ASPEC(0, a0) GRANNE_ASPEC(1, a1) GRANNE_ASPEC(2, a2) GRANNE_ASPEC(3, a3)
-            asm volatile("" ::: "memory"); // the loads above may not sink below this line
-            d = distances(m);               // its own row loads overlap with the ones in flight
+            d = distances(m);
             park_spec(au, a0, a1, a2, a3);
             __syncthreads();
         }
-#undef GRANNE_ASPEC
         return d;
     }
 
@@ -381,6 +302,186 @@ struct Walker {
         as4[64u + lane < au ? 64u + lane : dump] = a1;
         as4[128u + lane < au ? 128u + lane : dump] = a2;
         as4[192u + lane < au ? 192u + lane : dump] = a3;
+    }
+
+    // ---- the fast expansion (layers of device width 32; f32 with a known dim, or i8 with 128-B rows) --
+    // Lane layout: lane = 8*rip + sub. Row set i (0..3) is neighbor slot 8i + rip, and the eight lanes
+    // of a group hold that row 16 bytes each (per 128-byte block). Nothing is transposed through LDS:
+    //  f32: lane (row, sub) owns accumulators 4*sub..4*sub+3 of the reference's 32 (src/math.rs:17-26):
+    //       acc[j] = fma(x[64+j], q[64+j], fma(x[32+j], q[32+j], fma(x[j], q[j], 0))) -- chunk order kept;
+    //       the ordered sum ((0 + acc[0]) + acc[1]) + ... + acc[31] (math.rs:27-30) walks the group's
+    //       lanes with DPP row_shr:1, four adds per lane; the tail FMAs (math.rs:32-39) follow in order.
+    //  i8:  exact integer partial sums per lane (v_dot4_i32_i8), xor-shuffle reduction.
+    // All loads (rows of every valid neighbor, their adjacency rows speculatively) are issued from
+    // the neighbor ids alone, BEFORE the visited set is consulted, so the LDS compare-and-swap
+    // latency hides under the HBM round trip; distances of already visited neighbors are simply
+    // discarded (4 % of the rows on the benchmark graph).
+    __device__ __forceinline__ static float row_shr1(float v) {
+#if GRANNE_HIP_USE_DPP
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+#else
+        return __shfl_up(v, 1, 64);
+#endif
+    }
+
+    // returns d(neighbor slot `lane`) for lane < nvalid; sets `fresh`
+    __device__ __forceinline__ float fast_rows(uint32_t nb, uint32_t nvalid, gptr_u32 adj, bool& fresh) {
+        const uint32_t sub = lane & 7u, rip = lane >> 3;
+        const uint32_t last = nvalid - 1;
+        const uint32_t id0 = (uint32_t)__shfl((int)nb, (int)min(rip, last), 64);
+        const uint32_t id1 = (uint32_t)__shfl((int)nb, (int)min(8u + rip, last), 64);
+        const uint32_t id2 = (uint32_t)__shfl((int)nb, (int)min(16u + rip, last), 64);
+        const uint32_t id3 = (uint32_t)__shfl((int)nb, (int)min(24u + rip, last), 64);
+        float d = 0.0f;
+        if constexpr (FASTF32) {
+            const uint8_t* e0 = p.elements + (size_t)id0 * p.row_bytes + sub * 16u;
+            const uint8_t* e1 = p.elements + (size_t)id1 * p.row_bytes + sub * 16u;
+            const uint8_t* e2 = p.elements + (size_t)id2 * p.row_bytes + sub * 16u;
+            const uint8_t* e3 = p.elements + (size_t)id3 * p.row_bytes + sub * 16u;
+#define GRANNE_FB_LOAD(B)                                                                              \
+    float4 v##B##_0 = make_float4(0, 0, 0, 0), v##B##_1 = v##B##_0, v##B##_2 = v##B##_0, v##B##_3 = v##B##_0; \
+    if constexpr ((B) < NB) {                                                                          \
+        v##B##_0 = *reinterpret_cast<const float4*>(e0 + (B) * 128);                                   \
+        v##B##_1 = *reinterpret_cast<const float4*>(e1 + (B) * 128);                                   \
+        v##B##_2 = *reinterpret_cast<const float4*>(e2 + (B) * 128);                                   \
+        v##B##_3 = *reinterpret_cast<const float4*>(e3 + (B) * 128);                                   \
+    }
+#define GRANNE_FOR_FB(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+            static_assert(NB <= 8, "extend GRANNE_FOR_FB");
+            GRANNE_FOR_FB(GRANNE_FB_LOAD)
+            // tail: TAILU == 1: lane T holds the tail of row T; TAILU == 2: lane L holds part L&1 of row L>>1
+            float4 vt = make_float4(0, 0, 0, 0);
+            if constexpr (TAILU > 0) {
+                const uint32_t trow = (TAILU == 2) ? (lane >> 1) : lane;
+                const uint32_t tpart = (TAILU == 2) ? (lane & 1u) : 0u;
+                const uint32_t idt = (uint32_t)__shfl((int)nb, (int)min(trow, last), 64);
+                vt = *reinterpret_cast<const float4*>(p.elements + (size_t)idt * p.row_bytes + NB * 128 + tpart * 16u);
+            }
+            const uint4 a0 = load_global_u4(adj + (size_t)id0 * 32u + sub * 4u);
+            const uint4 a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
+            const uint4 a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
+            const uint4 a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
+            fresh = vis.insert(nb, lane < nvalid); // visited.insert(neighbor_idx), mod.rs:1026 -- under the loads
+            {   // pin: everything above is issued (and the set updated) before anything below waits
+                float chk = vt.x;
+#define GRANNE_FB_CHK(B) chk += v##B##_0.x + v##B##_1.x + v##B##_2.x + v##B##_3.x;
+                GRANNE_FOR_FB(GRANNE_FB_CHK)
+#undef GRANNE_FB_CHK
+                asm volatile("" ::"v"(chk) : "memory");
+            }
+            sa0 = a0; sa1 = a1; sa2 = a2; sa3 = a3;
+            // this lane's four accumulators of each of its four rows
+#define GRANNE_FB_ACC(I)                                                                               \
+    float c##I##_0 = 0.0f, c##I##_1 = 0.0f, c##I##_2 = 0.0f, c##I##_3 = 0.0f;
+            GRANNE_FB_ACC(0) GRANNE_FB_ACC(1) GRANNE_FB_ACC(2) GRANNE_FB_ACC(3)
+#undef GRANNE_FB_ACC
+#define GRANNE_FB_FMA(B)                                                                               \
+    if constexpr ((B) < NB) {                                                                          \
+        c0_0 = __builtin_fmaf(v##B##_0.x, qpc[(B) * 4 + 0], c0_0); c0_1 = __builtin_fmaf(v##B##_0.y, qpc[(B) * 4 + 1], c0_1); \
+        c0_2 = __builtin_fmaf(v##B##_0.z, qpc[(B) * 4 + 2], c0_2); c0_3 = __builtin_fmaf(v##B##_0.w, qpc[(B) * 4 + 3], c0_3); \
+        c1_0 = __builtin_fmaf(v##B##_1.x, qpc[(B) * 4 + 0], c1_0); c1_1 = __builtin_fmaf(v##B##_1.y, qpc[(B) * 4 + 1], c1_1); \
+        c1_2 = __builtin_fmaf(v##B##_1.z, qpc[(B) * 4 + 2], c1_2); c1_3 = __builtin_fmaf(v##B##_1.w, qpc[(B) * 4 + 3], c1_3); \
+        c2_0 = __builtin_fmaf(v##B##_2.x, qpc[(B) * 4 + 0], c2_0); c2_1 = __builtin_fmaf(v##B##_2.y, qpc[(B) * 4 + 1], c2_1); \
+        c2_2 = __builtin_fmaf(v##B##_2.z, qpc[(B) * 4 + 2], c2_2); c2_3 = __builtin_fmaf(v##B##_2.w, qpc[(B) * 4 + 3], c2_3); \
+        c3_0 = __builtin_fmaf(v##B##_3.x, qpc[(B) * 4 + 0], c3_0); c3_1 = __builtin_fmaf(v##B##_3.y, qpc[(B) * 4 + 1], c3_1); \
+        c3_2 = __builtin_fmaf(v##B##_3.z, qpc[(B) * 4 + 2], c3_2); c3_3 = __builtin_fmaf(v##B##_3.w, qpc[(B) * 4 + 3], c3_3); \
+    }
+            GRANNE_FOR_FB(GRANNE_FB_FMA)
+#undef GRANNE_FB_FMA
+#undef GRANNE_FB_LOAD
+#undef GRANNE_FOR_FB
+            // ordered sum over the 32 accumulators of a row: lane sub adds its four onto what lane sub-1 had
+            float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
+#pragma unroll
+            for (uint32_t ps = 0; ps < 8; ++ps) {
+                const float i0 = row_shr1(r0), i1 = row_shr1(r1), i2 = row_shr1(r2), i3 = row_shr1(r3);
+                float t0 = (ps == 0) ? 0.0f : i0, t1 = (ps == 0) ? 0.0f : i1, t2 = (ps == 0) ? 0.0f : i2,
+                      t3 = (ps == 0) ? 0.0f : i3;
+                t0 = t0 + c0_0; t0 = t0 + c0_1; t0 = t0 + c0_2; t0 = t0 + c0_3;
+                t1 = t1 + c1_0; t1 = t1 + c1_1; t1 = t1 + c1_2; t1 = t1 + c1_3;
+                t2 = t2 + c2_0; t2 = t2 + c2_1; t2 = t2 + c2_2; t2 = t2 + c2_3;
+                t3 = t3 + c3_0; t3 = t3 + c3_1; t3 = t3 + c3_2; t3 = t3 + c3_3;
+                if (sub == ps) { r0 = t0; r1 = t1; r2 = t2; r3 = t3; }
+            }
+            // row R's sum sits in lane 8*(R&7)+7 of register r[R>>3]; bring it to the lane that holds
+            // the row's tail (or to lane R when there is no tail), then fold the tail in order
+            const uint32_t trow = (TAILU == 2) ? (lane >> 1) : (lane & 31u);
+            const int src = (int)(((trow & 7u) << 3) + 7u);
+            const float s0 = __shfl(r0, src, 64), s1 = __shfl(r1, src, 64), s2 = __shfl(r2, src, 64), s3 = __shfl(r3, src, 64);
+            const uint32_t set = trow >> 3;
+            float rt = set == 0 ? s0 : set == 1 ? s1 : set == 2 ? s2 : s3;
+            if constexpr (TAILU == 1) {
+                rt = __builtin_fmaf(vt.x, qpc[NB * 4 + 0], rt); rt = __builtin_fmaf(vt.y, qpc[NB * 4 + 1], rt);
+                rt = __builtin_fmaf(vt.z, qpc[NB * 4 + 2], rt); rt = __builtin_fmaf(vt.w, qpc[NB * 4 + 3], rt);
+                d = angular_from_dot(rt); // lane T < 32 = row T
+            } else if constexpr (TAILU == 2) {
+                float u = rt; // part 0 lanes (even): floats 0..3 of the tail
+                u = __builtin_fmaf(vt.x, qpc[NB * 4 + 0], u); u = __builtin_fmaf(vt.y, qpc[NB * 4 + 1], u);
+                u = __builtin_fmaf(vt.z, qpc[NB * 4 + 2], u); u = __builtin_fmaf(vt.w, qpc[NB * 4 + 3], u);
+                float w = row_shr1(u); // part 1 lanes (odd) continue from their even neighbor
+                w = __builtin_fmaf(vt.x, qpc[NB * 4 + 0], w); w = __builtin_fmaf(vt.y, qpc[NB * 4 + 1], w);
+                w = __builtin_fmaf(vt.z, qpc[NB * 4 + 2], w); w = __builtin_fmaf(vt.w, qpc[NB * 4 + 3], w);
+                const float full_r = __shfl(w, (int)((lane & 31u) * 2u + 1u), 64); // row T's result -> lane T
+                d = angular_from_dot(full_r);
+            } else {
+                d = angular_from_dot(rt);
+            }
+        } else {
+            // i8, 128-byte rows
+            const uint4 x0 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id0 * 128u + sub * 16u);
+            const uint4 x1 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id1 * 128u + sub * 16u);
+            const uint4 x2 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id2 * 128u + sub * 16u);
+            const uint4 x3 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id3 * 128u + sub * 16u);
+            const uint4 a0 = load_global_u4(adj + (size_t)id0 * 32u + sub * 4u);
+            const uint4 a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
+            const uint4 a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
+            const uint4 a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
+            fresh = vis.insert(nb, lane < nvalid);
+            {
+                uint32_t chk = x0.x ^ x1.x ^ x2.x ^ x3.x;
+                asm volatile("" ::"v"(chk) : "memory");
+            }
+            sa0 = a0; sa1 = a1; sa2 = a2; sa3 = a3;
+            const uint4 y = qpiece;
+#define GRANNE_I8_ROW(X, OUT)                                                                          \
+    float OUT;                                                                                         \
+    {                                                                                                  \
+        int r = dot4_i8(X.x, y.x, 0);                                                                  \
+        r = dot4_i8(X.y, y.y, r); r = dot4_i8(X.z, y.z, r); r = dot4_i8(X.w, y.w, r);                  \
+        int dx = dot4_i8(X.x, X.x, 0);                                                                 \
+        dx = dot4_i8(X.y, X.y, dx); dx = dot4_i8(X.z, X.z, dx); dx = dot4_i8(X.w, X.w, dx);            \
+        r += __shfl_xor(r, 4, 64); dx += __shfl_xor(dx, 4, 64);                                        \
+        r += __shfl_xor(r, 2, 64); dx += __shfl_xor(dx, 2, 64);                                        \
+        r += __shfl_xor(r, 1, 64); dx += __shfl_xor(dx, 1, 64);                                        \
+        OUT = angular_int_from_sums(r, dx, dy);                                                        \
+    }
+            GRANNE_I8_ROW(x0, g0) GRANNE_I8_ROW(x1, g1) GRANNE_I8_ROW(x2, g2) GRANNE_I8_ROW(x3, g3)
+#undef GRANNE_I8_ROW
+            const uint32_t trow = lane & 31u;
+            const int src = (int)((trow & 7u) << 3);
+            const float s0 = __shfl(g0, src, 64), s1 = __shfl(g1, src, 64), s2 = __shfl(g2, src, 64), s3 = __shfl(g3, src, 64);
+            const uint32_t set = trow >> 3;
+            d = set == 0 ? s0 : set == 1 ? s1 : set == 2 ? s2 : s3;
+        }
+        return d;
+    }
+
+    // mod.rs:1029-1031 + pq.push for per-lane candidates (lanes with active hold d, id)
+    __device__ __forceinline__ void offer_lanes(bool active, float d, uint32_t id, bool full, float worst, uint32_t ef) {
+        uint64_t ck = make_key(d, id);
+        bool pass = active && (!full || d < worst);
+        uint64_t lastk = pq.get(64u * S - 1);
+        if (lastk != KEY_INF) {
+            bool dropnow = pass && ck > lastk;
+            if (wave_ballot(dropnow && d == key_dist(pq.get(ef - 1)))) bail = true;
+            pass = pass && !dropnow;
+        }
+        uint64_t pm = wave_ballot(pass);
+        while (pm) {
+            uint32_t src = (uint32_t)__builtin_ctzll(pm);
+            pm &= pm - 1;
+            pq_push(readlane64(ck, src), ef);
+        }
     }
 
     // mod.rs:1029-1031 + pq.push for the candidates of one expansion (lane c < m holds d, cid)
@@ -413,22 +514,35 @@ struct Walker {
         __syncthreads();
         uint32_t n_popped = 0;
 
+        const bool narrow = p.spec && L.width == 32 && (DT == DT_I8 || DIM > 0 || p.maxc >= 32);
+        // the LDS-free fast expansion: f32 with a compile-time dim, or i8 with 128-byte rows
+        const bool fastp = narrow && (FASTF32 || (DT == DT_I8 && p.row_bytes == 128));
+        const gptr_u32 adjg = (gptr_u32)L.adj;
+        // speculative adjacency state (narrow layers)
+        uint32_t specA_id = ID_EMPTY, specA_nb = ID_EMPTY; // row of the queue head, one id per lane
+        uint32_t specB_m = 0, specB_cid = ID_EMPTY;        // last expansion's candidates (rows in sa* / adjspec)
+
         // distance to the entry point (mod.rs:1012-1016)
-        if (lane == 0) cand[0] = entrypoint;
-        vis.insert(entrypoint, lane == 0);
-        vis.count = 1;
-        __syncthreads();
-        {
+        if (fastp) {
+            bool fresh0;
+            const uint32_t nb0 = (lane == 0) ? entrypoint : ID_EMPTY;
+            float d0 = fast_rows(nb0, 1, adjg, fresh0); // also fetches the entry point's adjacency row
+            vis.count = 1;
+            st.n_dist += 1;
+            specB_m = 1;
+            specB_cid = nb0;
+            uint64_t k0 = readlane64(make_key(d0, entrypoint), 0);
+            pq.insert_at(0, k0, lane);
+        } else {
+            if (lane == 0) cand[0] = entrypoint;
+            vis.insert(entrypoint, lane == 0);
+            vis.count = 1;
+            __syncthreads();
             float d0 = distances(1);
             st.n_dist += 1;
             uint64_t k0 = readlane64(make_key(d0, entrypoint), 0);
             pq.insert_at(0, k0, lane);
         }
-
-        const bool narrow = p.spec && L.width == 32 && (DT == DT_I8 || DIM > 0 || p.maxc >= 32);
-        // speculative adjacency state (narrow layers)
-        uint32_t specA_id = ID_EMPTY, specA_nb = ID_EMPTY; // row of the queue head, one id per lane
-        uint32_t specB_m = 0, specB_cid = ID_EMPTY;        // last expansion's candidates (rows in adjspec)
 
         for (;;) {
             uint64_t x = pq.get(0); // pq.pop(), mod.rs:1018
@@ -451,7 +565,6 @@ struct Walker {
 
             // layer.get_neighbors(idx), mod.rs:1025 / 540-552: row prefix until UNUSED
             const uint32_t xid = key_id(x);
-            const gptr_u32 adjg = (gptr_u32)L.adj;
             const gptr_u32 row = adjg + (size_t)xid * L.width;
             st.n_expand += 1;
 
@@ -462,7 +575,7 @@ struct Walker {
                     nb = specA_nb;
                 } else if (hitB) {
                     const uint32_t c = (uint32_t)__builtin_ctzll(hitB);
-                    if constexpr (DT == DT_F32 && DIM > 0) {
+                    if constexpr (REGSPEC) {
                         // row c sits in register sa[c/8], lanes 8*(c%8)..+7, four ids per lane
                         const uint4 sel = (c < 8) ? sa0 : (c < 16) ? sa1 : (c < 24) ? sa2 : sa3;
                         const int src = (int)(((c & 7u) << 3) + ((lane & 31u) >> 2));
@@ -487,21 +600,34 @@ struct Walker {
                 uint64_t unused = wave_ballot(nb == ID_EMPTY);
                 uint32_t nvalid = unused ? (uint32_t)__builtin_ctzll(unused) : 64u;
                 st.n_adj += nvalid;
-                bool fresh = vis.insert(nb, lane < nvalid); // visited.insert(neighbor_idx), mod.rs:1026
-                uint64_t fm = wave_ballot(fresh);
-                uint32_t m = (uint32_t)__popcll(fm);
-                if (m) {
-                    vis.count += m;
-                    uint32_t pos = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
-                    __syncthreads(); // adjspec / cand of the previous expansion are dead from here on
-                    if (fresh) cand[pos] = nb;
-                    __syncthreads();
-                    float d = distances_narrow(m, adjg); // mod.rs:1027
-                    st.n_dist += m;
-                    uint32_t cid = (lane < m) ? cand[lane] : ID_EMPTY;
-                    specB_m = m;
-                    specB_cid = cid;
-                    offer_candidates(m, d, cid, full, worst, ef);
+                if (fastp) {
+                    if (nvalid) {
+                        bool fresh;
+                        float d = fast_rows(nb, nvalid, adjg, fresh); // mod.rs:1026-1027
+                        const uint32_t m = (uint32_t)__popcll(wave_ballot(fresh));
+                        vis.count += m;
+                        st.n_dist += m;
+                        specB_m = nvalid;
+                        specB_cid = (lane < nvalid) ? nb : ID_EMPTY;
+                        offer_lanes(fresh, d, nb, full, worst, ef);
+                    }
+                } else {
+                    bool fresh = vis.insert(nb, lane < nvalid); // visited.insert(neighbor_idx), mod.rs:1026
+                    uint64_t fm = wave_ballot(fresh);
+                    uint32_t m = (uint32_t)__popcll(fm);
+                    if (m) {
+                        vis.count += m;
+                        uint32_t pos = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+                        __syncthreads(); // adjspec / cand of the previous expansion are dead from here on
+                        if (fresh) cand[pos] = nb;
+                        __syncthreads();
+                        float d = distances_narrow(m, adjg); // mod.rs:1027
+                        st.n_dist += m;
+                        uint32_t cid = (lane < m) ? cand[lane] : ID_EMPTY;
+                        specB_m = m;
+                        specB_cid = cid;
+                        offer_candidates(m, d, cid, full, worst, ef);
+                    }
                 }
                 if (vis.count > vis.limit) bail = true;
             } else {
