@@ -294,11 +294,12 @@ def main():
             best = None
             for th in cands:
                 oix.search_batch(h_q[:nq], ef, k, n_threads=th)  # touch pages / spin up threads
-                t1 = time.time()
-                res = oix.search_batch(h_q, ef, k, n_threads=th)
-                dt = time.time() - t1
-                if best is None or dt < best[0]:
-                    best = (dt, th, res)
+                for _rep in range(3):  # best of three: the host is shared and noisy
+                    t1 = time.time()
+                    res = oix.search_batch(h_q, ef, k, n_threads=th)
+                    dt = time.time() - t1
+                    if best is None or dt < best[0]:
+                        best = (dt, th, res)
             cpu_s, threads, (o_ids, o_d, o_c, o_ctr) = best
             t1 = time.time() - cpu_s
             g_ids = ids[b0:b0 + nb].reshape(-1, k).cpu().numpy().astype(np.uint64)
@@ -309,7 +310,7 @@ def main():
                 "value": round(nb * nq / cpu_s, 1), "unit": "queries/s", "cores": threads, "kind": "port",
                 "sample": "%d batches x %d queries of the timed workload, same index; oracle/granne_oracle.c "
                           "(C restatement of the reference's search; Rust toolchain absent), OpenMP dynamic over "
-                          "queries; %.2f s wall; thread counts tried %s, best reported" % (nb, nq, cpu_s, cands),
+                          "queries; %.2f s wall; thread counts tried %s x 3 repeats, best reported" % (nb, nq, cpu_s, cands),
                 "gpu_matches_oracle": {"ids_bit_exact": ids_ok, "dists_bit_exact": bool(d_ok),
                                        "queries_checked": int(nb * nq)},
             }
