@@ -75,8 +75,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # GRANNE_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-reduce) with one rank
+    use_dist = world > 1 or bool(os.environ.get("GRANNE_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0:
         log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
@@ -143,7 +149,7 @@ def main():
                                   on if on is not None else stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,9 +169,9 @@ def main():
         step(args.warmup + i, on=streams[i % inflight].cuda_stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # MAX over ranks
         elapsed = float(t.item())
     if int(status[0].item()) != 0:
         raise RuntimeError("exact-search scratch exhausted during the timed steps")
@@ -317,7 +323,7 @@ def main():
             out["speedup_vs_cpu"] = round(value / (nb * nq / cpu_s), 2)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

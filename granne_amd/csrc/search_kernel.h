@@ -390,18 +390,23 @@ struct Walker {
 #undef GRANNE_FB_FMA
 #undef GRANNE_FB_LOAD
 #undef GRANNE_FOR_FB
-            // ordered sum over the 32 accumulators of a row: lane sub adds its four onto what lane sub-1 had
+            // ordered sum over the 32 accumulators of a row: at step ps the lane with sub == ps adds its
+            // four accumulators onto what lane sub-1 produced at step ps-1. No predication is needed:
+            // every lane recomputes every step, a DPP read at step ps sees the neighbor's value of step
+            // ps-1 (registers are read before they are rewritten), so by induction lane s holds the
+            // correct prefix sum right after step s -- which is exactly when lane s+1 reads it -- and
+            // lane 7's value after the last step is the row's sum. (Lanes compute garbage before and
+            // after "their" step; nobody reads it.)
             float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
 #pragma unroll
             for (uint32_t ps = 0; ps < 8; ++ps) {
-                const float i0 = row_shr1(r0), i1 = row_shr1(r1), i2 = row_shr1(r2), i3 = row_shr1(r3);
-                float t0 = (ps == 0) ? 0.0f : i0, t1 = (ps == 0) ? 0.0f : i1, t2 = (ps == 0) ? 0.0f : i2,
-                      t3 = (ps == 0) ? 0.0f : i3;
+                float t0 = (ps == 0) ? 0.0f : row_shr1(r0), t1 = (ps == 0) ? 0.0f : row_shr1(r1),
+                      t2 = (ps == 0) ? 0.0f : row_shr1(r2), t3 = (ps == 0) ? 0.0f : row_shr1(r3);
                 t0 = t0 + c0_0; t0 = t0 + c0_1; t0 = t0 + c0_2; t0 = t0 + c0_3;
                 t1 = t1 + c1_0; t1 = t1 + c1_1; t1 = t1 + c1_2; t1 = t1 + c1_3;
                 t2 = t2 + c2_0; t2 = t2 + c2_1; t2 = t2 + c2_2; t2 = t2 + c2_3;
                 t3 = t3 + c3_0; t3 = t3 + c3_1; t3 = t3 + c3_2; t3 = t3 + c3_3;
-                if (sub == ps) { r0 = t0; r1 = t1; r2 = t2; r3 = t3; }
+                r0 = t0; r1 = t1; r2 = t2; r3 = t3;
             }
             // row R's sum sits in lane 8*(R&7)+7 of register r[R>>3]; bring it to the lane that holds
             // the row's tail (or to lane R when there is no tail), then fold the tail in order

@@ -1,0 +1,97 @@
+// The reference's own index tests, written against the C++ mirror of its API (include/granne.hpp).
+// Runs on an MI355X (tests/test_gpu_cpp_api.py compiles and executes it).
+//   build_and_search_float / _int8      /root/reference/src/index/tests.rs:41-48, 114-132
+//   with_borrowed_elements (config)     src/index/tests.rs:64-82
+//   incremental build_partial           src/index/tests.rs:134-168
+//   write_and_load                      src/index/tests.rs:337-394
+#include <cstdio>
+#include <random>
+
+#include "granne.hpp"
+
+using namespace granne;
+
+static std::mt19937 rng(12345);
+static std::vector<float> random_floats(size_t dim) { // src/test_helper.rs:3-6
+    std::uniform_real_distribution<float> u(0.0f, 1.0f);
+    std::vector<float> v(dim);
+    for (auto& x : v) x = u(rng) - 0.5f;
+    return v;
+}
+
+template <class Elements, class From>
+static Elements random_vectors(size_t dim, size_t num, From from) { // src/test_helper.rs:12-19
+    Elements e;
+    for (size_t i = 0; i < num; ++i) e.push(from(random_floats(dim)));
+    return e;
+}
+
+template <class Elements>
+static double verify_search(const Granne<Elements>& index, size_t max_search) { // src/index/tests.rs:50-62
+    size_t found = 0;
+    for (size_t i = 0; i < index.len(); ++i)
+        if (index.search(index.get_element(i), max_search, 1)[0].first == i) ++found;
+    return (double)found / (double)index.len();
+}
+
+#define REQUIRE(c)                                                         \
+    do {                                                                   \
+        if (!(c)) {                                                        \
+            std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); \
+            return 1;                                                      \
+        }                                                                  \
+    } while (0)
+
+int main(int argc, char** argv) {
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp";
+    {   // build_and_search_float
+        auto elements = random_vectors<angular::Vectors>(28, 1500, [](std::vector<float> v) { return angular::from(std::move(v)); });
+        GranneBuilder<angular::Vectors> builder(BuildConfig().num_neighbors(20).max_search(20), elements);
+        builder.build();
+        REQUIRE(builder.len() == 1500 && builder.num_elements() == 1500);
+        auto index = builder.get_index();
+        double p1 = verify_search(index, 10);
+        std::printf("build_and_search_float p1 = %.3f\n", p1);
+        REQUIRE(p1 > 0.95);
+        // results are sorted by (dist, id) and at most num_neighbors long
+        auto r = index.search(index.get_element(7), 30, 5);
+        REQUIRE(r.size() == 5);
+        for (size_t i = 1; i < r.size(); ++i) REQUIRE(r[i - 1].second <= r[i].second);
+        // the reference panics on max_search == 0 (src/index/mod.rs:1019)
+        bool threw = false;
+        try { index.search(index.get_element(0), 0, 1); } catch (const std::runtime_error&) { threw = true; }
+        REQUIRE(threw);
+        // write_and_load
+        index.write_index(tmp + "/cpp_index.granne");
+        index.write_elements(tmp + "/cpp_elements.bin");
+        auto loaded = Granne<angular::Vectors>::from_file(tmp + "/cpp_index.granne", tmp + "/cpp_elements.bin");
+        REQUIRE(loaded.len() == index.len() && loaded.num_layers() == index.num_layers());
+        for (size_t i = 0; i < 50; ++i) {
+            auto a = index.search(index.get_element(i * 3), 20, 5), b = loaded.search(index.get_element(i * 3), 20, 5);
+            REQUIRE(a == b);
+        }
+    }
+    {   // build_and_search_int8
+        auto elements = random_vectors<angular_int::Vectors>(32, 500, [](std::vector<float> v) { return angular_int::from(v); });
+        GranneBuilder<angular_int::Vectors> builder(BuildConfig().num_neighbors(20).max_search(20), elements);
+        builder.build();
+        double p1 = verify_search(builder.get_index(), 10);
+        std::printf("build_and_search_int8 p1 = %.3f\n", p1);
+        REQUIRE(p1 > 0.95);
+    }
+    {   // with_borrowed_elements configuration + incremental build
+        auto elements = random_vectors<angular::Vectors>(25, 500, [](std::vector<float> v) { return angular::from(std::move(v)); });
+        GranneBuilder<angular::Vectors> builder(BuildConfig().max_search(5).reinsert_elements(false), elements);
+        builder.build_partial(0);
+        REQUIRE(builder.len() == 0);
+        builder.build_partial(100);
+        REQUIRE(builder.len() == 100);
+        builder.build();
+        REQUIRE(builder.len() == 500);
+        double p1 = verify_search(builder.get_index(), 40);
+        std::printf("with_borrowed_elements p1 = %.3f\n", p1);
+        REQUIRE(p1 > 0.95);
+    }
+    std::printf("ok\n");
+    return 0;
+}

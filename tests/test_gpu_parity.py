@@ -370,3 +370,26 @@ def test_device_resident_api(ga, oracle):
     assert (cnt.cpu().numpy().astype(np.uint32) == oc).all()
     assert (st.cpu().numpy().astype(np.uint64) == octr).all()
     assert status.tolist() == [0, 0, 0, 0]
+
+
+def test_concurrent_searches_on_a_shared_index(ga, oracle):
+    """Granne::search takes &self and is re-entrant (SURVEY 8b); granne_hip_search_batch is
+    documented thread-safe on a shared handle: four host threads, different batches."""
+    import threading
+    rng = np.random.default_rng(19)
+    el = prep(oracle, random_floats(rng, 6000, 100), False)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=20, reinsert_elements=False, n_threads=0)
+    gix = ga.Granne("angular", el, oix.layers)
+    qs = [prep(oracle, random_floats(rng, 300, 100), False) for _ in range(4)]
+    want = [oix.search_batch(q, 40, 10) for q in qs]
+    got = [None] * 4
+
+    def work(i):
+        for _ in range(5):
+            got[i] = gix.search_batch(qs[i], 40, 10)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(4):
+        assert (got[i][0] == want[i][0]).all() and got[i][1].tobytes() == want[i][1].tobytes()
