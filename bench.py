@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--elements", "--n", dest="n", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--dtype", default="f32", choices=["f32", "i8"])
     ap.add_argument("--batch", type=int, default=1024)
