@@ -68,6 +68,11 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): anything libraries print meanwhile (RCCL's version
+    # banner, progress output) is routed to stderr by pointing fd 1 at fd 2 until the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import ctypes as C
@@ -321,7 +326,10 @@ def main():
                                        "queries_checked": int(nb * nq)},
             }
             out["speedup_vs_cpu"] = round(value / (nb * nq / cpu_s), 2)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     if use_dist:
         dist.barrier()
