@@ -5,8 +5,9 @@ bandwidth, over xGMI) and merged by (dist, global id). SURVEY.md 8e; the referen
 sharding helper splits elements the same way (src/elements/embeddings/parsing.rs:63-100).
 
 One process per GPU with torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
-tests). The local search and the merge are injectable so that the exchange logic is testable
-without a GPU: on a GPU box they default to the HIP kernels behind the C ABI.
+tests). The local search and the merge default to the HIP kernels behind the C ABI; they are
+constructor parameters only so that tests/test_sharded_gloo.py can drive the exchange logic on a
+GPU-less box with stand-ins from oracle/ -- this module itself contains no CPU implementation.
 """
 import ctypes as C
 
@@ -17,26 +18,6 @@ def shard_bounds(n_elements, world_size):
     """Shard g owns ids [g*ceil(n/G), min(n, (g+1)*ceil(n/G)))  (SURVEY.md 8e)."""
     per = -(-n_elements // world_size)
     return [(min(n_elements, g * per), min(n_elements, (g + 1) * per)) for g in range(world_size)]
-
-
-def merge_topk_numpy(ids, dists, counts, offsets, k):
-    """Reference merge (numpy): ids/dists [G][nq][k], counts [G][nq] -> top-k by (dist, global id)."""
-    G, nq, _ = ids.shape
-    out_ids = np.full((nq, k), np.iinfo(np.uint64).max, np.uint64)
-    out_d = np.full((nq, k), np.inf, np.float32)
-    out_c = np.zeros(nq, np.uint32)
-    for q in range(nq):
-        cand = []
-        for g in range(G):
-            for j in range(int(counts[g, q])):
-                cand.append((float(dists[g, q, j]), int(ids[g, q, j]) + int(offsets[g])))
-        cand.sort()
-        cand = cand[:k]
-        out_c[q] = len(cand)
-        for j, (d, i) in enumerate(cand):
-            out_ids[q, j] = i
-            out_d[q, j] = d
-    return out_ids, out_d, out_c
 
 
 class ShardedGranne:

@@ -4,6 +4,8 @@ the numpy merge."""
 import numpy as np
 import pytest
 
+from oracle.merge import merge_topk_numpy
+
 pytestmark = pytest.mark.gpu
 
 from tests.conftest import random_floats  # noqa: E402
@@ -34,7 +36,7 @@ def test_sharded_search_and_merge(oracle, int8, shards, k):
     sg = sharded.ShardedGranne(None, 0)
     m_ids, m_ds, m_cnt = sg._gpu_merge(torch.stack(g_ids), torch.stack(g_ds), torch.stack(g_cnt), offsets, k)
     torch.cuda.synchronize()
-    want = sharded.merge_topk_numpy(np.stack(o_ids), np.stack(o_ds), np.stack(o_cnt), offsets, k)
+    want = merge_topk_numpy(np.stack(o_ids), np.stack(o_ds), np.stack(o_cnt), offsets, k)
     assert (m_cnt.cpu().numpy().astype(np.uint32) == want[2]).all()
     assert (m_ids.cpu().numpy().astype(np.uint64) == want[0]).all()
     assert m_ds.cpu().numpy().tobytes() == want[1].tobytes()

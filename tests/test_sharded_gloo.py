@@ -13,6 +13,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from oracle.merge import merge_topk_numpy
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -53,7 +55,7 @@ def _worker(rank, world, port, out_dir):
         return (torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(ds), torch.from_numpy(cnt.astype(np.int32)))
 
     def merge(g_ids, g_ds, g_cnt, offsets, k):
-        i, d, c = sharded.merge_topk_numpy(g_ids.numpy().astype(np.uint64), g_ds.numpy(), g_cnt.numpy(), offsets, k)
+        i, d, c = merge_topk_numpy(g_ids.numpy().astype(np.uint64), g_ds.numpy(), g_cnt.numpy(), offsets, k)
         return torch.from_numpy(i.astype(np.int64)), torch.from_numpy(d), torch.from_numpy(c.astype(np.int32))
 
     sg = sharded.ShardedGranne(None, lo, local_search=local_search, merge=merge)
@@ -90,7 +92,7 @@ def test_partitioned_search_two_ranks_gloo(tmp_path, oracle):
     ids = np.stack([p[0] for p in per_shard])
     ds = np.stack([p[1] for p in per_shard])
     cnt = np.stack([p[2] for p in per_shard])
-    want = sharded.merge_topk_numpy(ids, ds, cnt, [b[0] for b in bounds], 5)
+    want = merge_topk_numpy(ids, ds, cnt, [b[0] for b in bounds], 5)
     assert (r[0]["ids"].astype(np.uint64) == want[0]).all()
     assert r[0]["ds"].tobytes() == want[1].tobytes()
     # global ids really point at the right elements: distances recomputed from the full set
