@@ -741,21 +741,40 @@ extern "C" int granne_hip_quantize_f32_device(const float* d_rows, int8_t* d_out
     return GRANNE_HIP_OK;
 }
 
-extern "C" int granne_hip_dist_pairs_device(const granne_hip_index* ix, const void* d_queries, const uint32_t* d_qidx,
-                                            const uint32_t* d_ids, uint64_t n_pairs, float* d_out, void* stream) {
+static int dists_launch(const granne_hip_index* ix, const void* d_queries, const uint32_t* d_qidx, uint32_t m,
+                        const uint32_t* d_ids, uint64_t n_pairs, float* d_out, uint32_t* d_status, void* stream) {
     if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
     if (n_pairs == 0) return GRANNE_HIP_OK;
-    if (!d_queries || !d_qidx || !d_ids || !d_out) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (!d_queries || !d_ids || !d_out) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+    uint32_t* st = d_status; // optional: count of out-of-range ids
+    // eight lanes per pair, 32 pairs per 256-thread block; enough blocks to cover the chip many times
+    uint64_t blocks = (n_pairs + 31) / 32;
+    if (blocks > 256u * 64u) blocks = 256u * 64u;
     if (ix->dtype == GRANNE_HIP_F32)
-        hipLaunchKernelGGL(dist_pairs_kernel<0>, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream,
-                           ix->d_elements, ix->row_bytes, ix->dim, (const uint8_t*)d_queries, d_qidx, d_ids, n_pairs, d_out);
+        hipLaunchKernelGGL(dists_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, ix->d_elements,
+                           ix->n_elements, ix->row_bytes, ix->dim, (const uint8_t*)d_queries, d_qidx, m, d_ids, n_pairs,
+                           d_out, st);
     else
-        hipLaunchKernelGGL(dist_pairs_kernel<1>, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream,
-                           ix->d_elements, ix->row_bytes, ix->dim, (const uint8_t*)d_queries, d_qidx, d_ids, n_pairs, d_out);
+        hipLaunchKernelGGL(dists_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, ix->d_elements,
+                           ix->n_elements, ix->row_bytes, ix->dim, (const uint8_t*)d_queries, d_qidx, m, d_ids, n_pairs,
+                           d_out, st);
     HIP_TRY(hipGetLastError());
     return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_dist_pairs_device(const granne_hip_index* ix, const void* d_queries, const uint32_t* d_qidx,
+                                            const uint32_t* d_ids, uint64_t n_pairs, float* d_out, void* stream) {
+    if (n_pairs && !d_qidx) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    return dists_launch(ix, d_queries, d_qidx, 1, d_ids, n_pairs, d_out, nullptr, stream);
+}
+
+extern "C" int granne_hip_dists_device(const granne_hip_index* ix, const void* d_queries, uint32_t nq,
+                                       const uint32_t* d_ids, uint32_t m, float* d_out, uint32_t* d_status,
+                                       void* stream) {
+    if (nq && m == 0) return GRANNE_HIP_OK;
+    return dists_launch(ix, d_queries, nullptr, m ? m : 1, d_ids, (uint64_t)nq * m, d_out, d_status, stream);
 }
 
 extern "C" int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,

@@ -128,28 +128,108 @@ __global__ void quantize_rows_kernel(const float* __restrict__ rows, int8_t* __r
     }
 }
 
-// ElementContainer::dist_to_element for explicit pairs; one lane per pair, rows straight from HBM
+// ElementContainer::dists / dist_to_element (src/elements/mod.rs:35-39, dense_vector.rs:149-163) as a
+// stand-alone operator: pair t = (query qidx[t] or t / m, element ids[t]). Eight lanes share one
+// element row, lane `sub` reading the 16-byte piece `sub` of every 128-byte block, so a wave
+// fetches eight rows with fully used 128-byte lines -- the same lane layout as the walk's
+// fast_rows. f32 keeps the reference's association: lane `sub` owns accumulators 4*sub..4*sub+3
+// of the 32, the ordered sum runs down the eight lanes, the tail is folded by sequential fmas.
+__device__ __forceinline__ float lane_shr1(float v) { // value of lane-1 (within a 16-lane row)
+#if GRANNE_HIP_USE_DPP
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+#else
+    return __shfl_up(v, 1, 64);
+#endif
+}
+
 template <int DT>
-__global__ void dist_pairs_kernel(const uint8_t* __restrict__ elements, uint32_t row_bytes, uint32_t dim,
-                                  const uint8_t* __restrict__ queries, const uint32_t* __restrict__ qidx,
-                                  const uint32_t* __restrict__ ids, uint64_t n_pairs, float* __restrict__ out) {
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_pairs;
-         t += (uint64_t)gridDim.x * blockDim.x) {
-        const uint8_t* row = elements + (uint64_t)ids[t] * row_bytes;
+__global__ __launch_bounds__(256) void dists_kernel(const uint8_t* __restrict__ elements, uint64_t n_elements,
+                                                    uint32_t row_bytes, uint32_t dim,
+                                                    const uint8_t* __restrict__ queries,
+                                                    const uint32_t* __restrict__ qidx, uint32_t m,
+                                                    const uint32_t* __restrict__ ids, uint64_t n_pairs,
+                                                    float* __restrict__ out, uint32_t* __restrict__ status) {
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u;
+    const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const uint64_t n_groups = ((uint64_t)gridDim.x * blockDim.x) >> 3;
+    // wave-uniform trip count: every lane of a wave runs the same number of rounds
+    const uint64_t wave_first = group - (lane >> 3);
+    for (uint64_t t0 = wave_first; t0 < n_pairs; t0 += n_groups) {
+        const uint64_t t = t0 + (lane >> 3);
+        const bool live = t < n_pairs;
+        const uint64_t tc = live ? t : n_pairs - 1;
+        const uint32_t id = ids[tc];
+        const bool valid = id < n_elements;
+        const uint64_t qi = qidx ? qidx[tc] : tc / m;
+        const uint8_t* row = elements + (uint64_t)(valid ? id : 0u) * row_bytes;
+        float d;
         if constexpr (DT == 0) {
-            const float* q = reinterpret_cast<const float*>(queries) + (uint64_t)qidx[t] * dim;
-            out[t] = angular_from_dot(dot_f32_exact_rt(reinterpret_cast<const float*>(row), q, dim));
-        } else {
-            const int8_t* q = reinterpret_cast<const int8_t*>(queries) + (uint64_t)qidx[t] * dim;
-            const int8_t* x = reinterpret_cast<const int8_t*>(row);
-            int r = 0, dx = 0, dy = 0;
-            for (uint32_t i = 0; i < dim; ++i) {
-                int xi = x[i], qi = q[i];
-                r += xi * qi;
-                dx += xi * xi;
-                dy += qi * qi;
+            const float* q = reinterpret_cast<const float*>(queries) + qi * dim;
+            const uint32_t nfull = dim >> 5, tail = dim & 31u;
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll 4
+            for (uint32_t c = 0; c < nfull; ++c) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + (size_t)c * 128u + sub * 16u);
+                const float* qc = q + c * 32u + sub * 4u;
+                a0 = __builtin_fmaf(__uint_as_float(v.x), qc[0], a0);
+                a1 = __builtin_fmaf(__uint_as_float(v.y), qc[1], a1);
+                a2 = __builtin_fmaf(__uint_as_float(v.z), qc[2], a2);
+                a3 = __builtin_fmaf(__uint_as_float(v.w), qc[3], a3);
             }
-            out[t] = angular_int_from_sums(r, dx, dy);
+            uint4 vt = make_uint4(0, 0, 0, 0); // the (zero padded) tail block
+            if (nfull * 128u + sub * 16u + 16u <= row_bytes)
+                vt = *reinterpret_cast<const uint4*>(row + (size_t)nfull * 128u + sub * 16u);
+            float r = 0.0f; // ordered sum acc[0] .. acc[31]: lane s is right after step s
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                float u = (ps == 0) ? 0.0f : lane_shr1(r);
+                u = u + a0; u = u + a1; u = u + a2; u = u + a3;
+                r = u;
+            }
+            r = __shfl(r, (int)(lane | 7u), 64);
+            for (uint32_t k = 0; k < tail; ++k) { // src/math.rs:47-49
+                const uint32_t w = (k & 3u) == 0 ? vt.x : (k & 3u) == 1 ? vt.y : (k & 3u) == 2 ? vt.z : vt.w;
+                const float xv = __uint_as_float((uint32_t)__shfl((int)w, (int)((lane & ~7u) + (k >> 2)), 64));
+                r = __builtin_fmaf(xv, q[nfull * 32u + k], r);
+            }
+            d = angular_from_dot(r);
+        } else {
+            const int8_t* q = reinterpret_cast<const int8_t*>(queries) + qi * dim;
+            int r = 0, dx = 0, dy = 0;
+            for (uint32_t b = sub * 16u; b < row_bytes; b += 128u) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + b);
+                uint32_t qw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t o = b + 4u * j;
+                    if ((dim & 3u) == 0) {
+                        qw[j] = (o < dim) ? *reinterpret_cast<const uint32_t*>(q + o) : 0u;
+                    } else {
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (o + e < dim) w |= (uint32_t)(uint8_t)q[o + e] << (8 * e);
+                        qw[j] = w;
+                    }
+                }
+                r = dot4_i8(v.x, qw[0], r); r = dot4_i8(v.y, qw[1], r);
+                r = dot4_i8(v.z, qw[2], r); r = dot4_i8(v.w, qw[3], r);
+                dx = dot4_i8(v.x, v.x, dx); dx = dot4_i8(v.y, v.y, dx);
+                dx = dot4_i8(v.z, v.z, dx); dx = dot4_i8(v.w, v.w, dx);
+                dy = dot4_i8(qw[0], qw[0], dy); dy = dot4_i8(qw[1], qw[1], dy);
+                dy = dot4_i8(qw[2], qw[2], dy); dy = dot4_i8(qw[3], qw[3], dy);
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                r += __shfl_xor(r, o, 64);
+                dx += __shfl_xor(dx, o, 64);
+                dy += __shfl_xor(dy, o, 64);
+            }
+            d = angular_int_from_sums(r, dx, dy);
+        }
+        if (live && sub == 0) {
+            out[t] = valid ? d : __builtin_inff();
+            if (!valid && status) atomicAdd(status, 1u);
         }
     }
 }

@@ -245,6 +245,30 @@ class Granne:
                                                    C.c_void_p(d_counts), C.c_void_p(d_stats), C.c_void_p(d_status),
                                                    C.c_void_p(stream)))
 
+    def dists_device(self, d_queries, nq, d_ids, m, d_out, d_status=0, stream=0):
+        """ElementContainer::dists (src/elements/mod.rs:35-39) batched on device: out[q, j] =
+        dist(element ids[q, j], query q). Raw device pointers (int), asynchronous on `stream`."""
+        check(lib().granne_hip_dists_device(self._h, C.c_void_p(d_queries), int(nq), C.c_void_p(d_ids), int(m),
+                                            C.c_void_p(d_out), C.c_void_p(d_status), C.c_void_p(stream)))
+
+    def dists_many(self, queries, ids):
+        """ElementContainer::dists for a batch: queries [nq, dim] (prepared), ids [nq, m] -> [nq, m] f32
+        (+inf where an id is out of range)."""
+        import torch
+        q = np.ascontiguousarray(queries, dtype=self.np_dtype)
+        ii = np.ascontiguousarray(ids, dtype=np.uint32)
+        if q.ndim != 2 or q.shape[1] != self.dim or ii.ndim != 2 or ii.shape[0] != q.shape[0]:
+            raise ValueError("queries must be [nq, %d] and ids [nq, m]" % self.dim)
+        dev = torch.device("cuda", self.device)
+        tq = torch.from_numpy(q.view(np.uint8).reshape(q.shape[0], -1)).to(dev)
+        ti = torch.from_numpy(ii.view(np.int32)).to(dev)
+        out = torch.empty(ii.shape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            s = torch.cuda.current_stream().cuda_stream
+            self.dists_device(tq.data_ptr(), q.shape[0], ti.data_ptr(), ii.shape[1], out.data_ptr(), 0, s)
+            torch.cuda.synchronize()
+        return out.cpu().numpy()
+
     def dists(self, queries, qidx, ids):
         """ElementContainer::dist_to_element for explicit (query, element) pairs."""
         q = np.ascontiguousarray(queries, dtype=self.np_dtype)

@@ -145,7 +145,15 @@ int granne_hip_quantize_f32_device(const float* d_rows, int8_t* d_out, uint64_t 
 int granne_hip_dist_pairs_device(const granne_hip_index* index, const void* d_queries,
                                  const uint32_t* d_qidx, const uint32_t* d_ids, uint64_t n_pairs,
                                  float* d_out, void* stream);
-/* Host conveniences over the two above (copy in, run, copy out). */
+/* ElementContainer::dists(&self, element, indices) -> Vec<f32> (src/elements/mod.rs:35-39,
+ * src/elements/dense_vector.rs:157-163), batched over nq elements with m indices each:
+ * d_out[q*m + j] = dist(elements[d_ids[q*m + j]], queries[q]). An id >= len yields +inf and is
+ * counted in *d_status (optional device u32, zeroed by the caller). Same arithmetic, bit for bit,
+ * as the walk. */
+int granne_hip_dists_device(const granne_hip_index* index, const void* d_queries, uint32_t nq,
+                            const uint32_t* d_ids, uint32_t m, float* d_out, uint32_t* d_status,
+                            void* stream);
+/* Host conveniences over the ones above (copy in, run, copy out). */
 int granne_hip_normalize_f32(float* rows, uint64_t n, uint32_t dim, int device_id);
 int granne_hip_quantize_f32(const float* rows, int8_t* out, uint64_t n, uint32_t dim, int device_id);
 int granne_hip_dist_pairs(const granne_hip_index* index, const void* queries, uint32_t nq,

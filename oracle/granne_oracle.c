@@ -468,6 +468,117 @@ size_t gro_search(const gro_index* ix, const void* query, size_t max_search, siz
     return n;
 }
 
+/* ---- Granne::reorder, src/index/reorder.rs ------------------------------------------------ */
+#define TRAIL_LAYERS 8 /* NUM_LAYERS, reorder.rs:177 */
+typedef struct {
+    uint32_t eps[TRAIL_LAYERS];
+    uint64_t idx;
+} trail_key;
+
+static int trail_key_cmp(const void* a, const void* b) { /* (eps, idx) tuple order, reorder.rs:161 */
+    const trail_key* x = (const trail_key*)a;
+    const trail_key* y = (const trail_key*)b;
+    for (int i = 0; i < TRAIL_LAYERS; ++i)
+        if (x->eps[i] != y->eps[i]) return x->eps[i] < y->eps[i] ? -1 : 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+/* find_entrypoint_trail, reorder.rs:180-208. `let ep = if i == 0 { 0 } else { eps[i] }` reads the
+ * slot that is still 0, so every layer's walk starts at node 0 -- restated as written. */
+static void find_entrypoint_trail(const gro_index* ix, uint32_t max_layer, const void* element, scratch_t* S,
+                                  uint32_t* eps) {
+    for (int i = 0; i < TRAIL_LAYERS; ++i) eps[i] = 0;
+    uint32_t take = max_layer < TRAIL_LAYERS ? max_layer : TRAIL_LAYERS;
+    if (take > ix->n_layers) take = ix->n_layers;
+    for (uint32_t i = 0; i < take; ++i) {
+        uint64_t ep = (i == 0) ? 0 : eps[i];
+        layer_view L;
+        make_layer_view(ix, i, &L);
+        search_for_neighbors_impl(&L, ep, ix->elements, ix->dim, ix->dtype, element, 1, S, NULL);
+        eps[i] = (uint32_t)S->res.v[0].id;
+    }
+}
+
+int gro_compute_order(const gro_index* ix, uint64_t* order, int n_threads) {
+    if (ix->n_layers < 2) return -1; /* num_layers() - 2 underflows, reorder.rs:137 */
+    const size_t esz = ix->dtype == GRO_F32 ? 4 : 1;
+    const uint64_t len0 = ix->layer_len[0];
+    for (uint64_t i = 0; i < len0; ++i) order[i] = i;            /* :136 */
+    const uint64_t inv_len = ix->layer_len[ix->n_layers - 2];
+    uint64_t* order_inv = (uint64_t*)calloc(inv_len ? inv_len : 1, sizeof(uint64_t)); /* zeros, :137 */
+    (void)n_threads;
+    for (uint32_t layer = 1; layer < ix->n_layers; ++layer) {   /* :149 */
+        const uint64_t lo = ix->layer_len[layer - 1], hi = ix->layer_len[layer];
+        trail_key* keys = (trail_key*)malloc(sizeof(trail_key) * (size_t)(hi > lo ? hi - lo : 1));
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+        {
+            scratch_t S;
+            memset(&S, 0, sizeof(S));
+#pragma omp for schedule(dynamic, 256)
+            for (int64_t idx = (int64_t)lo; idx < (int64_t)hi; ++idx) {
+                trail_key* k = &keys[idx - (int64_t)lo];
+                find_entrypoint_trail(ix, layer, (const uint8_t*)ix->elements + (size_t)idx * ix->dim * esz, &S,
+                                      k->eps);
+                for (int i = 0; i < TRAIL_LAYERS; ++i) k->eps[i] = (uint32_t)order_inv[k->eps[i]]; /* :159 */
+                k->idx = (uint64_t)idx;
+            }
+            scratch_free(&S);
+        }
+        qsort(keys, (size_t)(hi - lo), sizeof(trail_key), trail_key_cmp); /* :164 (total order: idx is unique) */
+        for (uint64_t i = lo; i < hi; ++i) order[i] = keys[i - lo].idx;   /* :165 */
+        free(keys);
+        if (layer < ix->n_layers - 1)                                     /* :167-171 */
+            for (uint64_t i = lo; i < hi; ++i) order_inv[order[i]] = i;
+    }
+    free(order_inv);
+    return 0;
+}
+
+typedef struct {
+    uint64_t key, idx;
+} key_idx;
+static int key_idx_cmp(const void* a, const void* b) {
+    const key_idx* x = (const key_idx*)a;
+    const key_idx* y = (const key_idx*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+int gro_order_by_keys(const gro_index* ix, const uint64_t* keys, uint64_t* order) { /* reorder.rs:88-110 */
+    for (uint32_t layer = 0; layer < ix->n_layers; ++layer) {
+        const uint64_t lo = layer ? ix->layer_len[layer - 1] : 0, hi = ix->layer_len[layer];
+        key_idx* v = (key_idx*)malloc(sizeof(key_idx) * (size_t)(hi > lo ? hi - lo : 1));
+        for (uint64_t l = lo; l < hi; ++l) {
+            v[l - lo].key = keys[l];
+            v[l - lo].idx = l;
+        }
+        qsort(v, (size_t)(hi - lo), sizeof(key_idx), key_idx_cmp);
+        for (uint64_t l = lo; l < hi; ++l) order[l] = v[l - lo].idx;
+        free(v);
+    }
+    return 0;
+}
+
+static int u32_cmp(const void* a, const void* b) {
+    uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return (x > y) - (x < y);
+}
+
+void gro_reorder_layer(const uint32_t* rows, uint64_t len, uint32_t width, const uint64_t* order, uint64_t n_order,
+                       uint32_t* out_rows) {
+    uint64_t* rev = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n_order ? n_order : 1)); /* get_reverse_mapping, :283-292 */
+    for (uint64_t i = 0; i < n_order; ++i) rev[order[i]] = i;
+    for (uint64_t i = 0; i < len; ++i) { /* mapping[..layer.len()], :243 */
+        const uint32_t* src = rows + (size_t)order[i] * width;
+        uint32_t* dst = out_rows + (size_t)i * width;
+        uint32_t n = 0;
+        for (uint32_t c = 0; c < width && src[c] != GRO_UNUSED; ++c) dst[n++] = (uint32_t)rev[src[c]]; /* :250-256 */
+        qsort(dst, n, sizeof(uint32_t), u32_cmp); /* MultiSetVector::push sorts */
+        for (uint32_t c = n; c < width; ++c) dst[c] = GRO_UNUSED;
+    }
+    free(rev);
+}
+
 int gro_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -129,6 +129,19 @@ size_t gro_set_encode(const uint32_t* sorted, size_t n, uint8_t* out);
 /* decode_into (:91-115): returns count; out must hold max(4,count) u32. */
 size_t gro_set_decode(const uint8_t* enc, size_t enc_len, uint32_t* out);
 
+/* ---- Granne::reorder, src/index/reorder.rs ------------------------------------------------ */
+/* compute_order (:135-175) with find_entrypoint_trail (:180-208). order[i] = j means the
+ * element with idx j moves to idx i. Needs n_layers >= 2 (the reference underflows
+ * num_layers() - 2 and panics otherwise): returns -1 then, 0 on success. */
+int gro_compute_order(const gro_index* ix, uint64_t* order, int n_threads);
+/* reorder_by_keys (:88-133): layer-preserving sort by (key, idx). */
+int gro_order_by_keys(const gro_index* ix, const uint64_t* keys, uint64_t* order);
+/* reorder_layer (:230-281) for one FixWidth layer: row i of the result holds the neighbors of
+ * order[i] mapped through the reverse mapping, SORTED ascending (MultiSetVector::push sorts,
+ * src/slice_vector/set_vector.rs:41-47) and GRO_UNUSED padded to `width`. */
+void gro_reorder_layer(const uint32_t* rows, uint64_t len, uint32_t width, const uint64_t* order,
+                       uint64_t n_order, uint32_t* out_rows);
+
 /* ---- synthetic data: counter-based, identical on every box ------------------ */
 /* component i of row r: uniform [-0.5, 0.5) with 24 random bits, like rand 0.7's
  * gen::<f32>() - 0.5 (src/test_helper.rs:3-6). */

@@ -112,6 +112,12 @@ def lib():
         L.gro_set_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.gro_set_decode.restype = C.c_size_t
         L.gro_set_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.gro_compute_order.restype = C.c_int
+        L.gro_compute_order.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_int]
+        L.gro_order_by_keys.restype = C.c_int
+        L.gro_order_by_keys.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_void_p]
+        L.gro_reorder_layer.restype = None
+        L.gro_reorder_layer.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
         L.gro_synth_rows.restype = None
         L.gro_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
         L.gro_max_threads.restype = C.c_int
@@ -245,6 +251,32 @@ class Index:
         if rc != 0:
             raise RuntimeError("max_search == 0 (reference panics, src/index/mod.rs:1019)")
         return ids, ds, cnt, ctr
+
+    # ---- Granne::reorder (src/index/reorder.rs) -------------------------------------------------
+    def compute_order(self, n_threads=0):
+        """compute_order (reorder.rs:135-175): order[i] = j <=> element j moves to position i."""
+        order = np.empty(len(self), np.uint64)
+        if lib().gro_compute_order(C.byref(self._c), _p(order), n_threads or lib().gro_max_threads()) != 0:
+            raise RuntimeError("reorder needs at least two layers (the reference panics, reorder.rs:137)")
+        return order
+
+    def order_by_keys(self, keys):
+        """The order reorder_by_keys computes (reorder.rs:88-110)."""
+        k = np.ascontiguousarray(keys, np.uint64)
+        assert k.shape == (len(self),)
+        order = np.empty(len(self), np.uint64)
+        lib().gro_order_by_keys(C.byref(self._c), _p(k), _p(order))
+        return order
+
+    def reordered(self, order):
+        """reorder_layers + elements.permute (reorder.rs:59-85, 210-281): a new Index."""
+        order = np.ascontiguousarray(order, np.uint64)
+        layers = []
+        for l in self.layers:
+            out = np.empty_like(l)
+            lib().gro_reorder_layer(_p(l), l.shape[0], l.shape[1], _p(order), order.size, _p(out))
+            layers.append(out)
+        return Index(self.elements[order.astype(np.int64)], layers)
 
 
 def build_index(elements, num_neighbors=30, max_search=200, layer_multiplier=15.0, reinsert_elements=True,

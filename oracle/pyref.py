@@ -163,3 +163,42 @@ def search(layers, elements, query, max_search, num_neighbors, counters=None):
     for layer in layers[:-1]:
         entrypoint = search_for_neighbors(layer, entrypoint, elements, query, 1, counters)[0][0]
     return search_for_neighbors(layers[-1], entrypoint, elements, query, max_search, counters)[:num_neighbors]
+
+
+# ---- Granne::reorder (src/index/reorder.rs) ---------------------------------------------------------
+NUM_LAYERS = 8  # reorder.rs:177
+
+
+def find_entrypoint_trail(layers, elements, max_layer, element):
+    """reorder.rs:180-208. eps[i] is read before it is assigned, so every walk starts at node 0."""
+    eps = [0] * NUM_LAYERS
+    for i, layer in list(enumerate(layers))[: min(NUM_LAYERS, max_layer)]:
+        ep = 0 if i == 0 else eps[i]
+        eps[i] = search_for_neighbors(layer, ep, elements, element, 1)[0][0]
+    return eps
+
+
+def compute_order(layers, elements):
+    """reorder.rs:135-175."""
+    order = list(range(len(layers[0])))
+    order_inv = [0] * len(layers[len(layers) - 2])
+    for layer in range(1, len(layers)):
+        keyed = []
+        for idx in range(len(layers[layer - 1]), len(layers[layer])):
+            eps = find_entrypoint_trail(layers, elements, layer, elements[idx])
+            keyed.append(([order_inv[i] for i in eps], idx))
+        keyed.sort()
+        order.extend(idx for _, idx in keyed)
+        if layer < len(layers) - 1:
+            for i in range(len(layers[layer - 1]), len(layers[layer])):
+                order_inv[order[i]] = i
+    return order
+
+
+def reorder_layers(layers, order):
+    """reorder.rs:210-292: rows follow `order`, ids go through the reverse mapping; MultiSetVector::push
+    sorts each set (src/slice_vector/set_vector.rs:41-47)."""
+    rev = [0] * len(order)
+    for i, j in enumerate(order):
+        rev[j] = i
+    return [[sorted(rev[n] for n in get_neighbors(layer, order[i])) for i in range(len(layer))] for layer in layers]

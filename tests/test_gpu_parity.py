@@ -75,6 +75,24 @@ def test_dist_operator_bit_exact(ga, oracle, int8, dim):
     assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("dim", [1, 31, 32, 33, 100, 128, 200, 1500])
+def test_dists_batched_bit_exact(ga, oracle, int8, dim):
+    """ElementContainer::dists (src/elements/mod.rs:35-39): one element against many indices, batched."""
+    rng = np.random.default_rng(11 * dim + int8)
+    n, nq, m = 777, 13, 37
+    el = prep(oracle, random_floats(rng, n, dim), int8)
+    q = prep(oracle, random_floats(rng, nq, dim), int8)
+    ix = ga.Granne("angular_int" if int8 else "angular", el, [])
+    ids = rng.integers(0, n, (nq, m)).astype(np.uint32)
+    ids[3, 5] = n            # out of range -> +inf
+    ids[12, 36] = 0xFFFFFFFF  # UNUSED
+    got = ix.dists_many(q, ids)
+    want = np.array([[oracle.dist(el[e], q[a]) if e < n else np.inf for e in ids[a]] for a in range(nq)], np.float32)
+    assert got.tobytes() == want.tobytes()
+    assert ix.dists_many(q, np.zeros((nq, 0), np.uint32)).shape == (nq, 0)
+
+
 def test_synthetic_rows_match_oracle(ga, oracle):
     import torch
     from granne_amd import _lib
