@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--recall-ef", default="", help="extra comma-separated ef values to report recall/QPS for")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--reorder", action="store_true",
+                    help="apply Granne::reorder (src/index/reorder.rs) to the built index before searching")
     return ap.parse_args()
 
 
@@ -135,6 +137,11 @@ def main():
     index = builder.get_index()
     torch.cuda.synchronize()
     t_build = time.time() - t0
+    order, t_reorder = None, 0.0
+    if args.reorder:
+        t0 = time.time()
+        order = index.reorder()  # order[new id] = old id
+        t_reorder = time.time() - t0
     layer_sizes = [builder.layer_len(l) for l in range(builder.num_layers())]
     if rank == 0:
         log("gen %.1fs, gpu build %.1fs, layers %s, index %.2f GB HBM" % (t_gen, t_build, layer_sizes,
@@ -209,6 +216,8 @@ def main():
     traffic = None
     wl_key = "%d|%d|%s|nq%d|ef%d|k%d|nn%d|ms%d|re%d" % (n, dim, args.dtype, nq, ef, k, args.num_neighbors,
                                                      args.build_max_search, args.build_reinsert)
+    if args.reorder:
+        wl_key += "|reordered"
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             traffic = json.load(f).get(wl_key, {}).get("hbm_bytes_per_launch")
@@ -238,7 +247,8 @@ def main():
             "n_elements": n, "dim": dim, "batch": nq, "ef_search": ef, "k": k, "layers": layer_sizes,
             "graph": {"builder": "gpu-batched", "num_neighbors": args.num_neighbors,
                       "max_search": args.build_max_search, "reinsert": bool(args.build_reinsert),
-                      "layer_multiplier": 15.0, "batch_max": args.batch_max, "build_s": round(t_build, 1)},
+                      "layer_multiplier": 15.0, "batch_max": args.batch_max, "build_s": round(t_build, 1),
+                      "reordered": bool(args.reorder), "reorder_s": round(t_reorder, 2)},
             "parallelism": "replica x%d (one process per GPU, no data-path collective); %d batches in flight per GPU"
                            % (world, inflight),
         },
@@ -269,6 +279,10 @@ def main():
                 got = id_tensor.cpu().numpy()
                 return float(np.mean([len(set(gt[i]) & set(got[i])) / k for i in range(nq)]))
 
+            if order is not None:  # ground truth is in build ids, results in reordered ids
+                t_order = torch.from_numpy(order.astype(np.int64)).cuda()
+                inner_recall = recall_of
+                recall_of = lambda t: inner_recall(t_order[t.clamp_min(0)])  # noqa: E731
             out["recall_at_10"] = round(recall_of(ids[b0]), 4)
             sweeps = []
             for e_ in [int(x) for x in args.recall_ef.split(",") if x]:
@@ -297,6 +311,8 @@ def main():
             h_el = elements.cpu().numpy()
             h_layers = builder.layers()
             oix = orc.Index(h_el, h_layers)
+            if order is not None:
+                oix = oix.reordered(order)
             nb = min(args.cpu_batches, args.steps)
             h_q = queries[b0 * nq:(b0 + nb) * nq].cpu().numpy()
             # thread count: the best of {OpenMP default, all logical CPUs} unless given (a cgroup

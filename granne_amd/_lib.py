@@ -64,6 +64,8 @@ SIGNATURES = {
     "granne_hip_quantize_f32_device": (i32, [vp, vp, u64, u32, i32, vp]),
     "granne_hip_dist_pairs_device": (i32, [vp, vp, vp, vp, u64, vp, vp]),
     "granne_hip_dists_device": (i32, [vp, vp, u32, vp, u32, vp, vp, vp]),
+    "granne_hip_index_reorder": (i32, [vp, vp]),
+    "granne_hip_index_reorder_by_keys": (i32, [vp, vp, vp]),
     "granne_hip_normalize_f32": (i32, [vp, u64, u32, i32]),
     "granne_hip_quantize_f32": (i32, [vp, vp, u64, u32, i32]),
     "granne_hip_dist_pairs": (i32, [vp, vp, u32, vp, vp, u64, vp]),

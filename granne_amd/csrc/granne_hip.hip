@@ -530,11 +530,13 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef) {
 
 static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t q_stride, uint32_t nq, uint32_t ef,
                          uint32_t k, uint64_t* d_ids, float* d_dists, uint32_t* d_counts, uint64_t* d_stats,
-                         uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */) {
+                         uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */,
+                         uint32_t* d_trail = nullptr /* [nq][8]: trail mode, no search outputs */,
+                         uint32_t trail_layers = 0) {
     if (ef == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
     if (nq == 0) return GRANNE_HIP_OK;
     if (k == 0) return fail(GRANNE_HIP_ERR_INVALID, "num_neighbors must be > 0");
-    if (!d_queries || !d_ids || !d_dists || !d_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (!d_queries || (!d_trail && (!d_ids || !d_dists || !d_counts))) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
 
@@ -586,6 +588,8 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.qlist = nullptr;
     p.qcount = nullptr;
     p.retry_total = nullptr;
+    p.trail_out = d_trail;
+    p.trail_layers = trail_layers;
 
     search_fn fn = pick_kernel(ix->dtype, ix->dim, ef > 256 ? 256 : ef);
     if (const char* e = getenv("GRANNE_HIP_LDS_PAD")) plan.lds_bytes += (uint32_t)atoi(e); // occupancy experiments
@@ -897,6 +901,11 @@ extern "C" int granne_hip_dist_pairs(const granne_hip_index* ix, const void* que
 // GranneBuilder on the GPU
 // ------------------------------------------------------------------------------------------------
 #include "builder_host.h"
+
+// ------------------------------------------------------------------------------------------------
+// Granne::reorder on the GPU
+// ------------------------------------------------------------------------------------------------
+#include "reorder_host.h"
 
 // ------------------------------------------------------------------------------------------------
 // granne's file formats

@@ -63,7 +63,12 @@ struct SearchParams {
     const uint32_t* qlist;   // retry launch: walk queries qlist[0..*qcount) instead of 0..nq
     const uint32_t* qcount;
     uint32_t* retry_total;   // optional: += *qcount (statistics)
+    // trail mode (Granne::reorder, src/index/reorder.rs:180-208): instead of a search, walk layers
+    // 0..trail_layers-1 with max_search 1, each from node 0, and record the ids found
+    uint32_t* trail_out;     // [nq][8] or null
+    uint32_t trail_layers;
 };
+constexpr uint32_t TRAIL_WIDTH = 8; // NUM_LAYERS, reorder.rs:177
 
 struct WalkStats {
     uint64_t n_dist, n_expand, n_adj;
@@ -674,6 +679,23 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
 
     Walker<DT, DIM, S> w(p, smem);
     w.load_query(qi);
+
+    if (p.trail_out) { // find_entrypoint_trail: `ep` reads the still-zero eps[i], every walk starts at node 0
+        const uint32_t take = min(min(p.trail_layers, TRAIL_WIDTH), p.n_layers);
+        uint32_t mine = 0;
+        for (uint32_t l = 0; l < take; ++l) {
+            w.search_layer(p.layers[l], 0u, 1u, p.upper_slots);
+            if (w.bail) break;
+            const uint32_t found = key_id(w.res.get(0));
+            if (lane == l) mine = found;
+        }
+        if (w.bail) {
+            if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+        } else if (lane < TRAIL_WIDTH) {
+            p.trail_out[(size_t)qi * TRAIL_WIDTH + lane] = mine;
+        }
+        return;
+    }
 
     uint32_t entrypoint = 0; // mod.rs:989
     for (uint32_t l = 0; l < p.n_layers; ++l) {

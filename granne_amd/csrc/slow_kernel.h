@@ -133,9 +133,13 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
         uint32_t n_res = 0;
         bool overflow = false;
 
-        for (uint32_t l = 0; l < p.n_layers && !overflow; ++l) {
+        const bool trail = p.trail_out != nullptr; // reorder.rs:180-208, see search_kernel.h
+        const uint32_t walk_layers = trail ? min(min(p.trail_layers, TRAIL_WIDTH), p.n_layers) : p.n_layers;
+        uint32_t trail_mine = 0;
+        for (uint32_t l = 0; l < walk_layers && !overflow; ++l) {
             const LayerDev L = p.layers[l];
-            const bool bottom = (l + 1 == p.n_layers);
+            const bool bottom = !trail && (l + 1 == p.n_layers);
+            if (trail) entrypoint = 0;
             const uint32_t ef = bottom ? p.ef : 1u;
             const uint32_t slots = bottom ? P.slots : min(P.slots, 65536u);
             const uint32_t mask = slots - 1;
@@ -227,7 +231,20 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
                 uint32_t ep = 0;
                 if (lane == 0) ep = key_id(res[0]);
                 entrypoint = readlane32(ep, 0);
+                if (trail && lane == l) trail_mine = entrypoint;
             }
+        }
+        if (trail) {
+            if (overflow) {
+                if (lane == 0) {
+                    atomicExch(P.status, 1u);
+                    if (P.status2) atomicExch(P.status2, 1u);
+                }
+            } else if (lane < TRAIL_WIDTH) {
+                p.trail_out[(size_t)qi * TRAIL_WIDTH + lane] = trail_mine;
+            }
+            __syncthreads();
+            continue;
         }
 
         // output: ascending (dist, id) = repeatedly take the max of `res` from the back

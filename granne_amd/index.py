@@ -202,6 +202,23 @@ class Granne:
     def hbm_bytes(self):
         return int(lib().granne_hip_index_hbm_bytes(self._h))
 
+    # ---- reorder (src/index/reorder.rs) --------------------------------------------------------------
+    def reorder(self):
+        """Granne::reorder: places similar elements closer together, in place. Returns the permutation
+        (uint64): permutation[i] == j means the element with idx j has been moved to idx i."""
+        order = np.empty(len(self), np.uint64)
+        check(lib().granne_hip_index_reorder(self._h, _p(order)))
+        return order
+
+    def reorder_by_keys(self, keys):
+        """Granne::reorder_by_keys: layer-preserving sort by (key, idx); keys are u64."""
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        if k.shape != (len(self),):
+            raise ValueError("need one key per element")  # assert_eq!(self.len(), keys.len()), reorder.rs:91
+        order = np.empty(len(self), np.uint64)
+        check(lib().granne_hip_index_reorder_by_keys(self._h, _p(k), _p(order)))
+        return order
+
     # ---- options --------------------------------------------------------------------------------
     def set_option(self, option, value):
         check(lib().granne_hip_index_set_option(self._h, option, value))

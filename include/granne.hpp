@@ -170,6 +170,18 @@ public:
         check(granne_hip_index_get_element(h_.get(), index, e.data.data()));
         return e;
     }
+    // Granne::reorder / reorder_by_keys (src/index/reorder.rs:59-133): returns the permutation
+    std::vector<size_t> reorder(bool /*show_progress*/ = false) {
+        std::vector<uint64_t> order(len());
+        check(granne_hip_index_reorder(h_.get(), order.data()));
+        return std::vector<size_t>(order.begin(), order.end());
+    }
+    std::vector<size_t> reorder_by_keys(const std::vector<uint64_t>& keys, bool /*show_progress*/ = false) {
+        if (keys.size() != len()) throw std::runtime_error("need one key per element"); // reorder.rs:91
+        std::vector<uint64_t> order(len());
+        check(granne_hip_index_reorder_by_keys(h_.get(), keys.data(), order.data()));
+        return std::vector<size_t>(order.begin(), order.end());
+    }
     void write_index(const std::string& path) const { check(granne_hip_index_save(h_.get(), path.c_str(), nullptr)); }
     void write_elements(const std::string& path) const { check(granne_hip_index_save(h_.get(), nullptr, path.c_str())); }
     granne_hip_index* raw() const { return h_.get(); }

@@ -134,6 +134,19 @@ int granne_hip_search_batch_device(const granne_hip_index* index, const void* d_
 int granne_hip_search(const granne_hip_index* index, const void* query, uint32_t max_search,
                       uint32_t num_neighbors, uint64_t* out_ids, float* out_dists, uint32_t* out_count);
 
+/* ---- Granne::reorder (src/index/reorder.rs) ----------------------------------------------------- */
+/* Granne::reorder(&mut self) -> Vec<usize> (reorder.rs:59-85): computes the entry-point-trail order
+ * (compute_order :135-175, find_entrypoint_trail :180-208) on the device, rewrites every layer
+ * through the reverse mapping (reorder_layers :210-281; neighbor sets come out sorted, as the
+ * reference's MultiSetVector stores them) and permutes the elements. out_order (optional, host,
+ * [len]) receives the permutation: out_order[i] == j means the element with idx j moved to idx i.
+ * The index must not be searched concurrently (the reference takes &mut self). Fewer than two
+ * layers, or len() != number of elements, are the reference's panics: GRANNE_HIP_ERR_INVALID. */
+int granne_hip_index_reorder(granne_hip_index* index, uint64_t* out_order);
+/* Granne::reorder_by_keys(&mut self, keys) (reorder.rs:88-133) for u64 keys (host, [len]): a
+ * layer-preserving sort by (key, idx). */
+int granne_hip_index_reorder_by_keys(granne_hip_index* index, const uint64_t* keys, uint64_t* out_order);
+
 /* ---- element preparation and the Dist / ElementContainer operators on device ------------------ */
 /* angular::Vector::from(Vec<f32>) over n rows, in place (src/math.rs:123-150). Device pointers. */
 int granne_hip_normalize_f32_device(float* d_rows, uint64_t n, uint32_t dim, int device_id, void* stream);

@@ -71,6 +71,22 @@ int main(int argc, char** argv) {
             REQUIRE(a == b);
         }
     }
+    {   // reorder_index (src/index/reorder.rs:299-322)
+        auto elements = random_vectors<angular::Vectors>(5, 5000, [](std::vector<float> v) { return angular::from(std::move(v)); });
+        GranneBuilder<angular::Vectors> builder(BuildConfig().max_search(5).layer_multiplier(5.0f), elements);
+        builder.build();
+        auto index = builder.get_index();
+        auto reordered_index = builder.get_index();
+        auto permutation = reordered_index.reorder(false);
+        REQUIRE(permutation.size() == 5000);
+        for (size_t idx : {0, 10, 123, 99, 499}) {
+            auto element = index.get_element(idx);
+            auto exp = index.search(element, 10, 10);
+            auto res = reordered_index.search(element, 10, 10);
+            REQUIRE(exp.size() == 10 && res.size() == 10);
+            for (size_t i = 0; i < 10; ++i) REQUIRE(exp[i].first == permutation[res[i].first]);
+        }
+    }
     {   // build_and_search_int8
         auto elements = random_vectors<angular_int::Vectors>(32, 500, [](std::vector<float> v) { return angular_int::from(v); });
         GranneBuilder<angular_int::Vectors> builder(BuildConfig().num_neighbors(20).max_search(20), elements);
