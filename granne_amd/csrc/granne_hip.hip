@@ -467,6 +467,16 @@ static search_fn pick_s(uint32_t ef) {
     return search_kernel<DT, DIM, 4>;
 }
 
+// Granne::reorder's trail walks (max_search 1): the S = 1 walker in trail mode
+static search_fn pick_trail_kernel(int dtype, uint32_t dim) {
+    if (dtype == GRANNE_HIP_I8) return search_kernel<DT_I8, 0, 1, true>;
+    switch (dim) {
+    case 100: return search_kernel<DT_F32, 100, 1, true>;
+    case 200: return search_kernel<DT_F32, 200, 1, true>;
+    default: return search_kernel<DT_F32, 0, 1, true>;
+    }
+}
+
 static search_fn pick_kernel(int dtype, uint32_t dim, uint32_t ef) {
     if (dtype == GRANNE_HIP_I8) return pick_s<DT_I8, 0>(ef);
     switch (dim) {
@@ -591,7 +601,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.trail_out = d_trail;
     p.trail_layers = trail_layers;
 
-    search_fn fn = pick_kernel(ix->dtype, ix->dim, ef > 256 ? 256 : ef);
+    search_fn fn = d_trail ? pick_trail_kernel(ix->dtype, ix->dim) : pick_kernel(ix->dtype, ix->dim, ef > 256 ? 256 : ef);
     if (const char* e = getenv("GRANNE_HIP_LDS_PAD")) plan.lds_bytes += (uint32_t)atoi(e); // occupancy experiments
     // the retry launch (below) needs up to 4x the visited table: raise the limit once for both
     const bool retry = !all_slow && !ix->opt_visited_slots && plan.visited_slots < 32768;

@@ -669,7 +669,7 @@ struct Walker {
     }
 };
 
-template <int DT, int DIM, int S>
+template <int DT, int DIM, int S, bool TRAIL>
 __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t qi, uint8_t* smem) {
     const uint32_t lane = threadIdx.x;
     if (p.force_slow) {
@@ -680,7 +680,7 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
     Walker<DT, DIM, S> w(p, smem);
     w.load_query(qi);
 
-    if (p.trail_out) { // find_entrypoint_trail: `ep` reads the still-zero eps[i], every walk starts at node 0
+    if constexpr (TRAIL) { // find_entrypoint_trail: `ep` reads the still-zero eps[i], every walk starts at node 0
         const uint32_t take = min(min(p.trail_layers, TRAIL_WIDTH), p.n_layers);
         uint32_t mine = 0;
         for (uint32_t l = 0; l < take; ++l) {
@@ -695,7 +695,7 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
             p.trail_out[(size_t)qi * TRAIL_WIDTH + lane] = mine;
         }
         return;
-    }
+    } else {
 
     uint32_t entrypoint = 0; // mod.rs:989
     for (uint32_t l = 0; l < p.n_layers; ++l) {
@@ -739,13 +739,16 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
             p.out_stats[(size_t)qi * 3 + 2] = w.st.n_adj;
         }
     }
+    } // !TRAIL
 }
 
 
 // Main launch: block b walks query b. Retry launch (qlist != null): the blocks share the queries
 // the main launch handed over because their LDS visited table filled; they rerun them, untouched,
 // with a larger table -- same code, same results -- before the global-memory walker is considered.
-template <int DT, int DIM, int S>
+// TRAIL = true is the variant Granne::reorder launches (SearchParams::trail_out): a kernel of its own,
+// so that the search kernel carries one copy of the walker and nothing else.
+template <int DT, int DIM, int S, bool TRAIL = false>
 __global__ __launch_bounds__(64) void search_kernel(const SearchParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
     if (p.qlist) {
@@ -753,10 +756,10 @@ __global__ __launch_bounds__(64) void search_kernel(const SearchParams p) {
         if (blockIdx.x == 0 && threadIdx.x == 0 && p.retry_total && n) atomicAdd(p.retry_total, n);
         for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
             __syncthreads();
-            walk_one<DT, DIM, S>(p, p.qlist[i], smem);
+            walk_one<DT, DIM, S, TRAIL>(p, p.qlist[i], smem);
         }
     } else if (blockIdx.x < p.nq) {
-        walk_one<DT, DIM, S>(p, blockIdx.x, smem);
+        walk_one<DT, DIM, S, TRAIL>(p, blockIdx.x, smem);
     }
 }
 

@@ -89,7 +89,7 @@ def test_reorder_twice_and_save(ga, oracle, tmp_path):
     assert sorted(o1.tolist()) == list(range(2500))
     gix.save_index(str(tmp_path / "i.granne"))
     gix.save_elements(str(tmp_path / "e.bin"))
-    layers = fileformat.read_index(open(str(tmp_path / "i.granne"), "rb").read())
+    _meta, layers = fileformat.read_index((tmp_path / "i.granne").read_bytes())
     for l, rows in enumerate(ore2.layers):
         for i in range(0, rows.shape[0], 7):
             assert list(layers[l][i]) == pyref.get_neighbors(rows, i)
