@@ -48,7 +48,8 @@ def build_library(force=False, use_dpp=None, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     if use_dpp is None:
         use_dpp = int(os.environ.get("GRANNE_HIP_USE_DPP", "1"))
-    cmd = [HIPCC] + FLAGS + ["-DGRANNE_HIP_USE_DPP=%d" % int(use_dpp), "-I", INCLUDE] + _sources() + ["-o", LIB_PATH]
+    extra = os.environ.get("GRANNE_HIP_EXTRA_FLAGS", "").split()  # kernel experiments, e.g. -DGRANNE_HIP_PQ_MERGE_MIN=99
+    cmd = [HIPCC] + FLAGS + ["-DGRANNE_HIP_USE_DPP=%d" % int(use_dpp)] + extra + ["-I", INCLUDE] + _sources() + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

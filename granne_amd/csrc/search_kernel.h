@@ -82,6 +82,11 @@ constexpr uint32_t LDS_ADJSPEC_BYTES = 4096 + 16;        // 32x32 u32 + a 16-byt
 constexpr uint32_t COLSTAGE_ROW_BYTES = 144;             // column-streamed stage: 32 floats + pad = 9 x 16 B (odd)
 constexpr uint32_t COLSTAGE_BYTES = 32 * COLSTAGE_ROW_BYTES;
 
+#ifndef GRANNE_HIP_PQ_MERGE_MIN
+#define GRANNE_HIP_PQ_MERGE_MIN 4
+#endif
+constexpr uint32_t PQ_MERGE_MIN = GRANNE_HIP_PQ_MERGE_MIN; // candidates per expansion from which the bulk merge pays
+
 template <int DT, int DIM, int S>
 struct Walker {
     // ---- immutable per-launch state
@@ -477,6 +482,39 @@ struct Walker {
     }
 
     // mod.rs:1029-1031 + pq.push for per-lane candidates (lanes with active hold d, id)
+    // pq.push for several candidates at once (S == 1: the queue is one key per lane). Every queue
+    // entry counts the candidates below it, every candidate its rank in the queue plus its rank
+    // among the candidates; the 64 + m keys are scattered to their final places through LDS and
+    // the first 64 read back. Same survivors as m sequential pushes; a real key that falls off is
+    // safe under the argument in pq_push, taken against the final queue.
+    __device__ __forceinline__ void pq_merge(uint64_t pm, uint32_t m, bool pass, uint64_t ck, uint32_t ef) {
+        static_assert(S == 1, "one key per lane");
+        const uint64_t mine = pq.key[0];
+        uint32_t above = 0; // queue lanes: candidates that sort after my key
+        uint32_t mypos = 0; // candidate lanes: final position
+        for (uint64_t it = pm; it; it &= it - 1) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(it);
+            const uint64_t K = readlane64(ck, src);
+            const bool below = mine < K;
+            above += below ? 1u : 0u;
+            const uint32_t pos = (uint32_t)__popcll(wave_ballot(below)) + (uint32_t)__popcll(wave_ballot(pass && ck < K));
+            if (lane == src) mypos = pos;
+        }
+        const uint32_t newpos = lane + (m - above);
+        uint64_t* slot = reinterpret_cast<uint64_t*>(cand); // cand + dout = 64 x 8 bytes, idle on this path
+        if (newpos < 64u) slot[newpos] = mine;
+        if (pass && mypos < 64u) slot[mypos] = ck;
+        const bool lost_q = newpos >= 64u && mine != KEY_INF;
+        const bool lost_c = pass && mypos >= 64u;
+        __syncthreads();
+        pq.key[0] = slot[lane];
+        __syncthreads();
+        if (wave_ballot(lost_q || lost_c)) {
+            const float kth = key_dist(pq.get(ef - 1));
+            if (wave_ballot((lost_q && key_dist(mine) == kth) || (lost_c && key_dist(ck) == kth))) bail = true;
+        }
+    }
+
     __device__ __forceinline__ void offer_lanes(bool active, float d, uint32_t id, bool full, float worst, uint32_t ef) {
         uint64_t ck = make_key(d, id);
         bool pass = active && (!full || d < worst);
@@ -487,6 +525,13 @@ struct Walker {
             pass = pass && !dropnow;
         }
         uint64_t pm = wave_ballot(pass);
+        if constexpr (S == 1) {
+            const uint32_t m = (uint32_t)__popcll(pm);
+            if (m >= PQ_MERGE_MIN) {
+                pq_merge(pm, m, pass, ck, ef);
+                return;
+            }
+        }
         while (pm) {
             uint32_t src = (uint32_t)__builtin_ctzll(pm);
             pm &= pm - 1;

@@ -108,3 +108,33 @@ def test_larger_max_search_is_never_worse(built):
     d200 = ix.search_batch(q[:256], 200, 10)[1]
     assert (d200[:, 0] <= d50[:, 0]).mean() > 0.99
     assert (d200[:, 9] <= d50[:, 9]).mean() > 0.99
+
+
+def test_reorder_at_full_size(built):
+    """Granne::reorder (src/index/reorder.rs) at BASELINE size, through its size-independent properties.
+    LAST in this module: it reorders the fixture's index in place."""
+    import torch
+    kind, el, q, ix, sizes = built
+    before = ix.search_batch(q, 50, 10)
+    order = ix.reorder()
+    assert order.shape == (N,)
+    assert np.array_equal(np.sort(order), np.arange(N, dtype=np.uint64))  # a permutation
+    lens = [0] + sizes
+    for a, b in zip(lens[:-1], lens[1:]):  # layer preserving (reorder.rs:87-90)
+        assert int(order[a:b].min()) == a and int(order[a:b].max()) == b - 1
+    if len(sizes) >= 2:  # layer 0 keeps its order; layer 1's keys all map to 0 -> idx order (:136-137,159)
+        assert np.array_equal(order[: lens[2]], np.arange(lens[2], dtype=np.uint64))
+        assert not np.array_equal(order[lens[2]:], np.arange(lens[2], N, dtype=np.uint64))
+    # the reference's own test (:311-320): same results modulo the permutation
+    after = ix.search_batch(q, 50, 10)
+    assert after[1].tobytes() == before[1].tobytes() and (after[2] == before[2]).all()
+    distinct = (np.diff(before[1], axis=1) > 0).all(axis=1)  # a distance tie may swap with the new ids
+    assert distinct.mean() > 0.99
+    assert np.array_equal(order[after[0][distinct].astype(np.int64)], before[0][distinct])
+    # elements moved with their ids; neighbor sets come out sorted (MultiSetVector::push)
+    pick = np.random.default_rng(2).choice(N, 64, replace=False)
+    rows = el[torch.from_numpy(order[pick].astype(np.int64)).cuda()].cpu().numpy()
+    for j, i in enumerate(pick.tolist()):
+        assert ix.get_element(i).tobytes() == rows[j].tobytes()
+        nb = ix.get_neighbors(i)
+        assert nb == sorted(nb) and len(set(nb)) == len(nb) and all(x < N for x in nb)
