@@ -237,7 +237,7 @@ def main():
         "metric": "queries/sec (recall@10 alongside), 10M x 100-d angular, batch=1024",
         "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "inflight_batches": inflight, "slow_path_queries": slow_timed, "lds_retry_queries": int(status[2].item()),
+        "inflight_batches": inflight, "slow_path_queries": slow_timed, "visited_spill_walks": int(status[2].item()),
         "sequential": {"value": round(args.steps * nq / seq_elapsed, 1), "ms_per_step": round(seq_elapsed / args.steps * 1e3, 4),
                        "note": "same K steps, one stream, one batch at a time (rank-local)"},
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

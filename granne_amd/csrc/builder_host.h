@@ -215,6 +215,7 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     T.opt_force_slow = 0;
     T.opt_slow_slots = 1u << 18;
     T.opt_slow_blocks = 16;
+    T.opt_overflow_slots = 0;
 
     BuildParams P;
     P.elements = b->d_elements;

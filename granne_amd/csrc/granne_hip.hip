@@ -94,6 +94,7 @@ struct granne_hip_index {
     uint64_t opt_force_slow = 0;
     uint64_t opt_slow_slots = 1u << 18;
     uint64_t opt_slow_blocks = 16;
+    uint64_t opt_overflow_slots = 0; // 0 auto, 1 off, else slots per overflow table
     std::atomic<uint64_t> last_slow_count{0};
 };
 
@@ -403,6 +404,11 @@ extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uin
         if (value < 1 || value > 1024) return fail(GRANNE_HIP_ERR_INVALID, "slow blocks must be in [1, 1024]");
         ix->opt_slow_blocks = value;
         return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_OVERFLOW_SLOTS:
+        if (value > 1 && (value < 512 || value > (1ull << 20) || (value & (value - 1))))
+            return fail(GRANNE_HIP_ERR_INVALID, "overflow slots must be 0 (auto), 1 (off) or a power of two in [512, 2^20]");
+        ix->opt_overflow_slots = value;
+        return GRANNE_HIP_OK;
     default:
         return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
     }
@@ -415,6 +421,7 @@ extern "C" int granne_hip_index_get_option(const granne_hip_index* ix, int optio
     case GRANNE_HIP_OPT_FORCE_SLOW: *value = ix->opt_force_slow; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_SLOW_SLOTS: *value = ix->opt_slow_slots; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_SLOW_BLOCKS: *value = ix->opt_slow_blocks; return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_OVERFLOW_SLOTS: *value = ix->opt_overflow_slots; return GRANNE_HIP_OK;
     default: return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -437,7 +444,7 @@ struct SearchTarget {
     const LayerDev* d_layers;
     uint32_t n_layers;
     uint32_t max_dev_width;
-    uint64_t opt_visited_slots, opt_force_slow, opt_slow_slots, opt_slow_blocks;
+    uint64_t opt_visited_slots, opt_force_slow, opt_slow_slots, opt_slow_blocks, opt_overflow_slots;
 };
 
 static SearchTarget target_of(const granne_hip_index* ix) {
@@ -455,6 +462,7 @@ static SearchTarget target_of(const granne_hip_index* ix) {
     T.opt_force_slow = ix->opt_force_slow;
     T.opt_slow_slots = ix->opt_slow_slots;
     T.opt_slow_blocks = ix->opt_slow_blocks;
+    T.opt_overflow_slots = ix->opt_overflow_slots;
     return T;
 }
 
@@ -498,7 +506,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef) {
     uint32_t want = ix->opt_visited_slots ? (uint32_t)ix->opt_visited_slots : next_pow2(ef * 64u);
     if (!ix->opt_visited_slots) {
         if (want < 1024) want = 1024;
-        if (want > 16384) want = 16384;
+        if (want > 4096) want = 4096; // larger walks spill to the global overflow table; LDS buys occupancy
     }
     P.visited_slots = want;
     P.upper_slots = want < 1024 ? want : 1024;
@@ -554,20 +562,37 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     LaunchPlan plan = plan_launch(ix, ef > 256 ? 256 : ef);
     if (plan.lds_bytes > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
 
-    // stream-ordered scratch: hand-over lists + slow-path containers.
-    // header words: [0] count of list 1 (main launch), [1] overflow flag, [2] count of list 2 (retry)
+    // visited-set overflow pool: one table per walker that can be resident at once (bounded by
+    // LDS: 160 KiB per CU, and by 32 waves per CU), at most one per query
+    uint32_t ovf_slots = 0, ovf_regions = 0;
+    if (!all_slow && ix->opt_overflow_slots != 1) {
+        ovf_slots = ix->opt_overflow_slots ? next_pow2((uint32_t)ix->opt_overflow_slots) : next_pow2((ef > 256 ? 256 : ef) * 64u);
+        if (!ix->opt_overflow_slots && ovf_slots < 4096) ovf_slots = 4096;
+        if (ovf_slots < 512) ovf_slots = 512;
+        if (ovf_slots > (1u << 20)) ovf_slots = 1u << 20;
+        uint32_t per_cu = (160u * 1024u) / (plan.lds_bytes ? plan.lds_bytes : 1u);
+        if (per_cu > 32) per_cu = 32;
+        if (per_cu < 1) per_cu = 1;
+        ovf_regions = 256u * per_cu * 2u; // 2x the residency bound keeps the region probe short
+        if (ovf_regions > nq) ovf_regions = nq;
+    }
+
+    // stream-ordered scratch: hand-over list, overflow pool, slow-path containers.
+    // header words: [0] hand-over count, [1] slow-path exhaustion flag, [2] walks that spilled
     const uint32_t slow_blocks = (uint32_t)ix->opt_slow_blocks;
     const uint32_t slots = (uint32_t)ix->opt_slow_slots;
     const size_t list_bytes = ((size_t)nq * 4 + 15) & ~(size_t)15;
-    size_t off_list = 16;
-    size_t off_list2 = off_list + list_bytes;
-    size_t off_vis = off_list2 + list_bytes;
+    const size_t state_bytes = ((size_t)ovf_regions * 4 + 15) & ~(size_t)15;
+    size_t off_state = 16;
+    size_t off_list = off_state + state_bytes;
+    size_t off_ovf = off_list + list_bytes;
+    size_t off_vis = off_ovf + (size_t)ovf_regions * ovf_slots * 4;
     size_t off_pq = off_vis + (size_t)slow_blocks * slots * 4;
     size_t off_res = off_pq + (size_t)slow_blocks * slots * 8;
     size_t total = off_res + (size_t)slow_blocks * ef * 8;
     uint8_t* scratch = nullptr;
     HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
-    HIP_TRY(hipMemsetAsync(scratch, 0, 16, s));
+    HIP_TRY(hipMemsetAsync(scratch, 0, off_list, s)); // header + region states
 
     SearchParams p;
     p.elements = ix->d_elements;
@@ -595,46 +620,24 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.slow_list = (uint32_t*)(scratch + off_list);
     p.force_slow = all_slow ? 1 : 0;
     p.spec = 1;
-    p.qlist = nullptr;
-    p.qcount = nullptr;
-    p.retry_total = nullptr;
+    p.ovf.tables = (uint32_t*)(scratch + off_ovf);
+    p.ovf.state = (uint32_t*)(scratch + off_state);
+    p.ovf.slots = ovf_slots;
+    p.ovf.regions = ovf_regions;
+    p.ovf.spilled = d_status ? d_status + 2 : ((uint32_t*)scratch) + 2;
     p.trail_out = d_trail;
     p.trail_layers = trail_layers;
 
     search_fn fn = d_trail ? pick_trail_kernel(ix->dtype, ix->dim) : pick_kernel(ix->dtype, ix->dim, ef > 256 ? 256 : ef);
     if (const char* e = getenv("GRANNE_HIP_LDS_PAD")) plan.lds_bytes += (uint32_t)atoi(e); // occupancy experiments
-    // the retry launch (below) needs up to 4x the visited table: raise the limit once for both
-    const bool retry = !all_slow && !ix->opt_visited_slots && plan.visited_slots < 32768;
-    const uint32_t retry_slots = plan.visited_slots * 4 > 32768 ? 32768 : plan.visited_slots * 4;
-    const uint32_t retry_lds = plan.lds_bytes + (retry ? (retry_slots - plan.visited_slots) * 4u : 0u);
-    if (retry_lds > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
-    if (retry_lds > 32u * 1024u)
-        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)retry_lds));
+    if (plan.lds_bytes > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
+    if (plan.lds_bytes > 32u * 1024u)
+        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes));
     hipLaunchKernelGGL(fn, dim3(nq), dim3(64), plan.lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
 
-    // second chance in LDS for walks whose visited table filled: same kernel, 4x the table
-    uint32_t* final_count = p.slow_count;
-    uint32_t* final_list = p.slow_list;
-    if (retry) {
-        SearchParams r = p;
-        r.qlist = p.slow_list;
-        r.qcount = p.slow_count;
-        r.visited_slots = retry_slots;
-        r.slow_count = ((uint32_t*)scratch) + 2;
-        r.slow_list = (uint32_t*)(scratch + off_list2);
-        r.retry_total = d_status ? d_status + 2 : nullptr;
-        uint32_t grid = nq < 128 ? nq : 128;
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(64), retry_lds, s, r);
-        HIP_TRY(hipGetLastError());
-        final_count = r.slow_count;
-        final_list = r.slow_list;
-    }
-
     SlowParams sp;
     sp.sp = p;
-    sp.sp.slow_count = final_count;
-    sp.sp.slow_list = final_list;
     sp.vis = (uint32_t*)(scratch + off_vis);
     sp.pq = (uint64_t*)(scratch + off_pq);
     sp.res = (uint64_t*)(scratch + off_res);
@@ -652,7 +655,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
         uint32_t hs[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(hs, scratch, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        h_slow_count[0] = retry ? hs[2] : hs[0]; // queries served by the global-memory walker
+        h_slow_count[0] = hs[0]; // queries served by the global-memory walker
         h_slow_count[1] = hs[1];
     }
     HIP_TRY(hipFreeAsync(scratch, s));

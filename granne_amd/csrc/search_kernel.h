@@ -60,9 +60,7 @@ struct SearchParams {
     uint32_t* slow_list;     // [nq]
     uint32_t force_slow;
     uint32_t spec;           // 1: speculative adjacency prefetch (narrow layers)
-    const uint32_t* qlist;   // retry launch: walk queries qlist[0..*qcount) instead of 0..nq
-    const uint32_t* qcount;
-    uint32_t* retry_total;   // optional: += *qcount (statistics)
+    OverflowPool ovf;        // global overflow tables of the visited sets (wave_prims.h)
     // trail mode (Granne::reorder, src/index/reorder.rs:180-208): instead of a search, walk layers
     // 0..trail_layers-1 with max_search 1, each from node 0, and record the ids found
     uint32_t* trail_out;     // [nq][8] or null
@@ -128,6 +126,7 @@ struct Walker {
         dy = 0;
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
+        vis.init_walker();
     }
 
     // stage the query in LDS, zero padded to row_bytes
@@ -371,7 +370,7 @@ struct Walker {
             const uint4 a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
             const uint4 a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
             const uint4 a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
-            fresh = vis.insert(nb, lane < nvalid); // visited.insert(neighbor_idx), mod.rs:1026 -- under the loads
+            fresh = vis.insert(nb, lane < nvalid, p.ovf); // visited.insert(neighbor_idx), mod.rs:1026 -- under the loads
             {   // pin: everything above is issued (and the set updated) before anything below waits
                 float chk = vt.x;
 #define GRANNE_FB_CHK(B) chk += v##B##_0.x + v##B##_1.x + v##B##_2.x + v##B##_3.x;
@@ -451,7 +450,7 @@ struct Walker {
             const uint4 a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
             const uint4 a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
             const uint4 a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
-            fresh = vis.insert(nb, lane < nvalid);
+            fresh = vis.insert(nb, lane < nvalid, p.ovf);
             {
                 uint32_t chk = x0.x ^ x1.x ^ x2.x ^ x3.x;
                 asm volatile("" ::"v"(chk) : "memory");
@@ -590,7 +589,7 @@ struct Walker {
             pq.insert_at(0, k0, lane);
         } else {
             if (lane == 0) cand[0] = entrypoint;
-            vis.insert(entrypoint, lane == 0);
+            vis.insert(entrypoint, lane == 0, p.ovf);
             vis.count = 1;
             __syncthreads();
             float d0 = distances(1);
@@ -660,18 +659,18 @@ struct Walker {
                         bool fresh;
                         float d = fast_rows(nb, nvalid, adjg, fresh); // mod.rs:1026-1027
                         const uint32_t m = (uint32_t)__popcll(wave_ballot(fresh));
-                        vis.count += m;
+                        vis.added(m);
                         st.n_dist += m;
                         specB_m = nvalid;
                         specB_cid = (lane < nvalid) ? nb : ID_EMPTY;
                         offer_lanes(fresh, d, nb, full, worst, ef);
                     }
                 } else {
-                    bool fresh = vis.insert(nb, lane < nvalid); // visited.insert(neighbor_idx), mod.rs:1026
+                    bool fresh = vis.insert(nb, lane < nvalid, p.ovf); // visited.insert(neighbor_idx), mod.rs:1026
                     uint64_t fm = wave_ballot(fresh);
                     uint32_t m = (uint32_t)__popcll(fm);
                     if (m) {
-                        vis.count += m;
+                        vis.added(m);
                         uint32_t pos = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
                         __syncthreads(); // adjspec / cand of the previous expansion are dead from here on
                         if (fresh) cand[pos] = nb;
@@ -684,18 +683,18 @@ struct Walker {
                         offer_candidates(m, d, cid, full, worst, ef);
                     }
                 }
-                if (vis.count > vis.limit) bail = true;
+                if (!vis.make_room(p.ovf, lane)) bail = true;
             } else {
                 for (uint32_t base = 0; base < L.width; base += 64) {
                     uint32_t nb = (base + lane < L.width) ? row[base + lane] : ID_EMPTY;
                     uint64_t unused = wave_ballot(nb == ID_EMPTY);
                     uint32_t nvalid = unused ? (uint32_t)__builtin_ctzll(unused) : 64u;
                     st.n_adj += nvalid;
-                    bool fresh = vis.insert(nb, lane < nvalid); // visited.insert(neighbor_idx), mod.rs:1026
+                    bool fresh = vis.insert(nb, lane < nvalid, p.ovf); // visited.insert(neighbor_idx), mod.rs:1026
                     uint64_t fm = wave_ballot(fresh);
                     uint32_t m = (uint32_t)__popcll(fm);
                     if (m) {
-                        vis.count += m;
+                        vis.added(m);
                         uint32_t pos = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
                         if (fresh) cand[pos] = nb;
                         __syncthreads();
@@ -705,7 +704,7 @@ struct Walker {
                         offer_candidates(m, d, cid, full, worst, ef);
                         __syncthreads();
                     }
-                    if (vis.count > vis.limit) bail = true;
+                    if (!vis.make_room(p.ovf, lane)) bail = true;
                     if (nvalid < 64u) break;
                 }
             }
@@ -734,6 +733,7 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
             const uint32_t found = key_id(w.res.get(0));
             if (lane == l) mine = found;
         }
+        w.vis.release(p.ovf, lane);
         if (w.bail) {
             if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
         } else if (lane < TRAIL_WIDTH) {
@@ -751,6 +751,7 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
         if (!bottom) entrypoint = key_id(w.res.get(0)); // res[0].0, mod.rs:993
     }
 
+    w.vis.release(p.ovf, lane);
     if (w.bail) { // hand the untouched query to the exact global-memory walker
         if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
         return;
@@ -788,24 +789,15 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
 }
 
 
-// Main launch: block b walks query b. Retry launch (qlist != null): the blocks share the queries
-// the main launch handed over because their LDS visited table filled; they rerun them, untouched,
-// with a larger table -- same code, same results -- before the global-memory walker is considered.
+// Block b walks query b. A walk whose LDS visited table fills continues with an overflow table
+// borrowed from p.ovf; only a walk that cannot continue exactly (unsafe queue drop, no overflow
+// region left) is handed, untouched, to the global-memory walker of slow_kernel.h.
 // TRAIL = true is the variant Granne::reorder launches (SearchParams::trail_out): a kernel of its own,
 // so that the search kernel carries one copy of the walker and nothing else.
 template <int DT, int DIM, int S, bool TRAIL = false>
 __global__ __launch_bounds__(64) void search_kernel(const SearchParams p) {
     extern __shared__ __align__(16) uint8_t smem[];
-    if (p.qlist) {
-        const uint32_t n = *p.qcount;
-        if (blockIdx.x == 0 && threadIdx.x == 0 && p.retry_total && n) atomicAdd(p.retry_total, n);
-        for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-            __syncthreads();
-            walk_one<DT, DIM, S, TRAIL>(p, p.qlist[i], smem);
-        }
-    } else if (blockIdx.x < p.nq) {
-        walk_one<DT, DIM, S, TRAIL>(p, blockIdx.x, smem);
-    }
+    if (blockIdx.x < p.nq) walk_one<DT, DIM, S, TRAIL>(p, blockIdx.x, smem);
 }
 
 } // namespace granne_hip

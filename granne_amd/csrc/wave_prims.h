@@ -128,14 +128,36 @@ struct SortedList {
     }
 };
 
-// Exact visited set in LDS (HashSet<usize>, src/index/mod.rs:1009-1010,1016,1026): open
-// addressing with double hashing (no primary clustering, so the table can run at 7/8 load).
-struct VisitedSet {
-    uint32_t* tab;  // LDS
-    uint32_t mask;  // slots - 1
-    uint32_t count; // wave-uniform number of stored ids
-    uint32_t limit; // max ids before the walk is handed to the global-memory path
+// Exact visited set (HashSet<usize>, src/index/mod.rs:1009-1010,1016,1026): open addressing with
+// double hashing (no primary clustering, so a table can run at 7/8 load), in two levels. The
+// front table lives in LDS. When it reaches its load limit it is frozen (lookups only) and new
+// ids go to an overflow table in global memory that the walker borrows from a per-launch pool --
+// the walk continues where it is, nothing is recomputed. The set stays exact: an id is in the set
+// iff it is in one of the two tables.
+struct OverflowPool {
+    uint32_t* tables;  // [regions][slots] u32, global
+    uint32_t* state;   // [regions] 0 = free, 1 = taken (zeroed per launch)
+    uint32_t slots;    // per region, power of two; 0 = no overflow: a full front table bails
+    uint32_t regions;
+    uint32_t* spilled; // optional statistics: += 1 per walk that spilled
+};
 
+struct VisitedSet {
+    uint32_t* tab;   // LDS front table
+    uint32_t mask;   // slots - 1
+    uint32_t count;  // wave-uniform number of ids in the front table
+    uint32_t limit;  // front table load limit
+    // overflow state, kept to two wave-uniform words: the borrowed region (or NONE) and the number
+    // of ids in its table (NONE while the front table still accepts inserts)
+    static constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t region;
+    uint32_t ocount;
+
+    __device__ __forceinline__ void init_walker() {
+        region = NONE;
+        ocount = NONE;
+    }
+    __device__ __forceinline__ bool frozen() const { return ocount != NONE; }
     __device__ __forceinline__ void reset(uint32_t* lds, uint32_t slots, uint32_t lane) {
         tab = lds;
         mask = slots - 1;
@@ -146,24 +168,88 @@ struct VisitedSet {
         uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
         uint4* t4 = reinterpret_cast<uint4*>(lds);
         for (uint32_t i = lane; i < (slots >> 2); i += 64) t4[i] = e;
+        ocount = NONE; // a borrowed region is kept for the next layer and wiped when it is used again
     }
     __device__ __forceinline__ static uint32_t hash(uint32_t id) { return (id * 0x9E3779B1u) >> 7; }
     __device__ __forceinline__ static uint32_t step(uint32_t id) { return ((id * 0x85EBCA6Bu) >> 9) | 1u; }
 
     // HashSet::insert: true iff id was not present. Lanes with active==false do nothing.
-    __device__ __forceinline__ bool insert(uint32_t id, bool active) {
+    __device__ __forceinline__ bool insert(uint32_t id, bool active, const OverflowPool& pool) {
         bool fresh = false;
-        if (active) {
-            uint32_t slot = hash(id) & mask;
-            const uint32_t st = step(id); // odd: visits every slot of the power-of-two table
-            for (;;) {
-                uint32_t old = atomicCAS(&tab[slot], ID_EMPTY, id);
-                if (old == ID_EMPTY) { fresh = true; break; }
-                if (old == id) break;
-                slot = (slot + st) & mask;
+        const uint32_t st = step(id); // odd: visits every slot of a power-of-two table
+        if (!frozen()) {
+            if (active) {
+                uint32_t slot = hash(id) & mask;
+                for (;;) {
+                    uint32_t old = atomicCAS(&tab[slot], ID_EMPTY, id);
+                    if (old == ID_EMPTY) { fresh = true; break; }
+                    if (old == id) break;
+                    slot = (slot + st) & mask;
+                }
+            }
+        } else {
+            bool absent = false;
+            if (active) { // the frozen front table: lookup only
+                uint32_t slot = hash(id) & mask;
+                for (;;) {
+                    uint32_t v = tab[slot];
+                    if (v == ID_EMPTY) { absent = true; break; }
+                    if (v == id) break;
+                    slot = (slot + st) & mask;
+                }
+            }
+            if (absent) {
+                uint32_t* otab = pool.tables + (size_t)region * pool.slots;
+                const uint32_t omask = pool.slots - 1;
+                uint32_t slot = (hash(id) >> 3) & omask;
+                for (;;) {
+                    uint32_t old = atomicCAS(&otab[slot], ID_EMPTY, id);
+                    if (old == ID_EMPTY) { fresh = true; break; }
+                    if (old == id) break;
+                    slot = (slot + st) & omask;
+                }
             }
         }
         return fresh;
+    }
+    // m ids were inserted (wave-uniform)
+    __device__ __forceinline__ void added(uint32_t m) {
+        if (frozen()) ocount += m; else count += m;
+    }
+    // after an expansion: spill to the overflow table when the front table is full. Returns false
+    // when the walk cannot go on in this kernel (no overflow configured, pool exhausted, or the
+    // overflow table itself is full): the caller hands the query to the global-memory walker.
+    __device__ __forceinline__ bool make_room(const OverflowPool& pool, uint32_t lane) {
+        if (frozen()) return ocount <= pool.slots - (pool.slots >> 2) - 72u; // 75 % load
+        if (count <= limit) return true;
+        if (pool.slots == 0) return false;
+        if (region == NONE) {
+            uint32_t got = NONE;
+            if (lane == 0) {
+                uint32_t r = (blockIdx.x * 0x9E3779B1u) % pool.regions;
+                for (uint32_t tries = 0; tries < pool.regions; ++tries) {
+                    if (atomicCAS(&pool.state[r], 0u, 1u) == 0u) { got = r; break; }
+                    r = (r + 1 == pool.regions) ? 0u : r + 1;
+                }
+                if (got != NONE && pool.spilled) atomicAdd(pool.spilled, 1u);
+            }
+            region = (uint32_t)__shfl((int)got, 0, 64);
+            if (region == NONE) return false;
+        }
+        uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
+        uint4* t4 = reinterpret_cast<uint4*>(pool.tables + (size_t)region * pool.slots);
+        for (uint32_t i = lane; i < (pool.slots >> 2); i += 64) t4[i] = e;
+        __threadfence(); // the wipe is complete before any lane's atomicCAS on the table
+        ocount = 0;
+        return true;
+    }
+    // end of the walk: give the region back
+    __device__ __forceinline__ void release(const OverflowPool& pool, uint32_t lane) {
+        if (region != NONE) {
+            __threadfence();
+            if (lane == 0) atomicExch(&pool.state[region], 0u);
+            region = NONE;
+        }
     }
 };
 

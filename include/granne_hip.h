@@ -124,7 +124,8 @@ int granne_hip_search_batch(const granne_hip_index* index, const void* queries, 
  * enqueued on `stream` (a hipStream_t) and NOT synchronised. d_status (u32[4], optional, zeroed by
  * the caller): [0] is set to 1 if any query exhausted the exact-search scratch
  * (GRANNE_HIP_ERR_OVERFLOW); [1] accumulates the queries served by the exact global-memory
- * walker; [2] accumulates the queries that needed the second LDS pass (4x visited table).          */
+ * walker; [2] accumulates the walks whose LDS visited table filled and that continued with a
+ * global overflow table (GRANNE_HIP_OPT_OVERFLOW_SLOTS).                                          */
 int granne_hip_search_batch_device(const granne_hip_index* index, const void* d_queries, uint32_t nq,
                                    uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
                                    float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
@@ -273,7 +274,9 @@ enum {
     GRANNE_HIP_OPT_VISITED_SLOTS = 1, /* LDS visited-table slots per query, power of two; 0 = auto */
     GRANNE_HIP_OPT_FORCE_SLOW = 2,    /* 1: route every query through the exact global-memory path */
     GRANNE_HIP_OPT_SLOW_SLOTS = 3,    /* global visited/queue slots per slow-path query (pow2)      */
-    GRANNE_HIP_OPT_SLOW_BLOCKS = 4    /* concurrent slow-path walkers                               */
+    GRANNE_HIP_OPT_SLOW_BLOCKS = 4,   /* concurrent slow-path walkers                               */
+    GRANNE_HIP_OPT_OVERFLOW_SLOTS = 5 /* global overflow slots per walk for a full LDS visited table:
+                                         0 = auto, 1 = off (such walks go to the slow path), else pow2 */
 };
 int granne_hip_index_set_option(granne_hip_index* index, int option, uint64_t value);
 int granne_hip_index_get_option(const granne_hip_index* index, int option, uint64_t* value);

@@ -306,11 +306,46 @@ def test_visited_table_overflow_hands_over(ga, oracle):
     gix = ga.Granne("angular", el, oix.layers)
     q = prep(oracle, random_floats(rng, 64, 32), False)
     gix.set_option(_lib.OPT_VISITED_SLOTS, 256)  # far too small for max_search=100
+    gix.set_option(_lib.OPT_OVERFLOW_SLOTS, 1)   # no overflow table: the walks are handed over
     assert_same(oix, gix, q, 100, 10)
     assert gix.last_slow_count() > 0
     gix.set_option(_lib.OPT_VISITED_SLOTS, 0)
+    gix.set_option(_lib.OPT_OVERFLOW_SLOTS, 0)
     assert_same(oix, gix, q, 100, 10)
     assert gix.last_slow_count() == 0
+
+
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("ef,lds_slots,ovf_slots", [(100, 256, 0), (100, 256, 4096), (250, 1024, 0), (40, 256, 2048),
+                                                    (200, 512, 512)])
+def test_visited_set_spills_to_global_overflow(ga, oracle, int8, ef, lds_slots, ovf_slots):
+    """A full LDS visited table freezes and the walk continues with a global overflow table: same results,
+    no hand-over -- unless the overflow table is too small as well (512 slots at ef=200), which hands over."""
+    import torch
+    from granne_amd import _lib
+    rng = np.random.default_rng(140 + ef + int8)
+    el = prep(oracle, random_floats(rng, 4000, 100), int8)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
+    gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 96, 100), int8)
+    gix.set_option(_lib.OPT_VISITED_SLOTS, lds_slots)
+    gix.set_option(_lib.OPT_OVERFLOW_SLOTS, ovf_slots)
+    assert_same(oix, gix, q, ef, 10)
+    slow = gix.last_slow_count()
+    assert (slow > 0) == (ef == 200 and ovf_slots == 512)
+    # the device-side status words: [1] slow-path queries, [2] walks that spilled
+    tq = torch.from_numpy(q.view(np.uint8).reshape(96, -1)).cuda()
+    ids = torch.empty((96, 10), dtype=torch.int64, device="cuda")
+    ds = torch.empty((96, 10), dtype=torch.float32, device="cuda")
+    cnt = torch.empty(96, dtype=torch.int32, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    gix.search_batch_device(tq.data_ptr(), 96, ef, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), 0,
+                            status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert st[0] == 0 and st[1] == slow and st[2] > 0
+    want = oix.search_batch(q, ef, 10)
+    assert (ids.cpu().numpy().astype(np.uint64) == want[0]).all()
 
 
 def test_slow_scratch_exhaustion_is_reported(ga, oracle):
