@@ -57,12 +57,14 @@ def parse():
     ap.add_argument("--build-reinsert", type=int, default=1)
     ap.add_argument("--num-neighbors", type=int, default=30)
     ap.add_argument("--batch-max", type=int, default=65536)
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight: step i is enqueued on HIP stream i %% inflight (1 = strictly sequential)")
     ap.add_argument("--cpu-batches", type=int, default=16, help="batches of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--recall-ef", default="", help="extra comma-separated ef values to report recall/QPS for")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--visited-slots", type=int, default=0,
+                    help="GRANNE_HIP_OPT_VISITED_SLOTS: LDS visited-table slots per walker (0 = auto)")
     ap.add_argument("--reorder", action="store_true",
                     help="apply Granne::reorder (src/index/reorder.rs) to the built index before searching")
     return ap.parse_args()
@@ -137,6 +139,9 @@ def main():
     index = builder.get_index()
     torch.cuda.synchronize()
     t_build = time.time() - t0
+    if args.visited_slots:
+        from granne_amd import _lib as _glib
+        index.set_option(_glib.OPT_VISITED_SLOTS, args.visited_slots)
     order, t_reorder = None, 0.0
     if args.reorder:
         t0 = time.time()
