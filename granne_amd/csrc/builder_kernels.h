@@ -70,9 +70,12 @@ struct BuildLds {
     float* sd;        // [64]
     uint32_t* cur;    // [64]
     uint32_t* slot;   // [64]
+    float* pair;      // [BUILD_CHUNK][BUILD_CHUNK], aliases selrows when that is large enough
 };
+constexpr uint32_t PAIR_BYTES = BUILD_CHUNK * BUILD_CHUNK * 4; // pairwise distances of one chunk of candidates
 __host__ __device__ inline uint32_t build_lds_bytes(uint32_t lrow, uint32_t cap) {
-    return lrow * (1 + BUILD_CHUNK + cap) + BUILD_MAX_CAND * 8 + 64 * 4 * 4;
+    // the pairwise matrix shares the selected-rows stage when that is large enough
+    return lrow * (1 + BUILD_CHUNK + cap) + (lrow * cap < PAIR_BYTES ? PAIR_BYTES : 0u) + BUILD_MAX_CAND * 8 + 64 * 4 * 4;
 }
 
 template <int DT, int DIM>
@@ -87,6 +90,11 @@ struct RowWork {
         L.chunk = smem + p.lrow;
         L.selrows = L.chunk + (size_t)BUILD_CHUNK * p.lrow;
         uint8_t* a = L.selrows + (size_t)p.cap * p.lrow;
+        L.pair = reinterpret_cast<float*>(L.selrows);
+        if (p.lrow * p.cap < PAIR_BYTES) {
+            L.pair = reinterpret_cast<float*>(a);
+            a += PAIR_BYTES;
+        }
         L.cid = reinterpret_cast<uint32_t*>(a);
         L.cd = reinterpret_cast<float*>(a + BUILD_MAX_CAND * 4);
         a += BUILD_MAX_CAND * 8;
@@ -161,9 +169,9 @@ struct RowWork {
         }
     }
 
-    // select_neighbors (mod.rs:849-883). Candidates cid/cd[0..n) sorted ascending. If `preloaded`,
-    // candidate j's row already sits in chunk[slot[j]] (n <= BUILD_CHUNK). Result in sid/sd.
-    __device__ __forceinline__ uint32_t select_neighbors(uint32_t n, uint32_t max_neighbors, bool preloaded) {
+    // select_neighbors (mod.rs:849-883). Candidates cid/cd[0..n) sorted ascending, rows gathered a
+    // chunk at a time. Result in sid/sd.
+    __device__ __forceinline__ uint32_t select_neighbors(uint32_t n, uint32_t max_neighbors) {
         if (n <= max_neighbors) { // :854-856
             if (lane < n) {
                 L.sid[lane] = L.cid[lane];
@@ -175,14 +183,12 @@ struct RowWork {
         uint32_t nsel = 0;
         for (uint32_t c0 = 0; c0 < n && nsel < max_neighbors; c0 += BUILD_CHUNK) {
             const uint32_t cn = min(BUILD_CHUNK, n - c0);
-            if (!preloaded) {
-                __syncthreads();
-                gather_chunk(L.cid + c0, cn);
-                __syncthreads();
-            }
+            __syncthreads();
+            gather_chunk(L.cid + c0, cn);
+            __syncthreads();
             for (uint32_t j = c0; j < c0 + cn && nsel < max_neighbors; ++j) { // :866-881
                 const float dj = L.cd[j];
-                const uint8_t* rj = L.chunk + (size_t)(preloaded ? L.slot[j] : (j - c0)) * P.lrow;
+                const uint8_t* rj = L.chunk + (size_t)(j - c0) * P.lrow;
                 bool bad = false;
                 if (lane < nsel) {
                     float dd = dist_lds(L.selrows + (size_t)lane * P.lrow, rj); // dist_to_element(n, &element_j)
@@ -198,7 +204,60 @@ struct RowWork {
                     __syncthreads();
                 }
             }
-            if (preloaded) break; // a preloaded set is one chunk
+        }
+        __syncthreads();
+        return nsel;
+    }
+
+    // select_neighbors (mod.rs:849-883) for n <= BUILD_CHUNK candidates whose rows already sit in the
+    // chunk stage (candidate j in chunk[slot[j]]): the distances the reference evaluates one
+    // candidate at a time -- dist(selected, candidate j) -- are a pure function of the pair, so all
+    // n(n-1)/2 of them are computed first, 64 pairs at a time, and the selection loop only compares.
+    // Pair rows a and n-2-a are folded into one row of n entries so that every lane has work.
+    __device__ __forceinline__ uint32_t select_neighbors_pairs(uint32_t n, uint32_t max_neighbors) {
+        if (n <= max_neighbors) { // :854-856
+            if (lane < n) {
+                L.sid[lane] = L.cid[lane];
+                L.sd[lane] = L.cd[lane];
+            }
+            __syncthreads();
+            return n;
+        }
+        const uint32_t folded = (n >> 1) * n;
+        for (uint32_t p0 = 0; p0 < folded; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            const uint32_t r = p / n, c = p - r * n;
+            const uint32_t len1 = n - 1u - r;
+            uint32_t a, b;
+            bool valid = p < folded;
+            if (c < len1) {
+                a = r;
+                b = r + 1u + c;
+            } else {
+                a = n - 2u - r;
+                b = a + 1u + (c - len1);
+                valid = valid && a != r; // the middle row of an odd triangle has no partner
+            }
+            if (valid) {
+                const float dd = dist_lds(L.chunk + (size_t)L.slot[a] * P.lrow, L.chunk + (size_t)L.slot[b] * P.lrow);
+                L.pair[a * BUILD_CHUNK + b] = dd;
+                L.pair[b * BUILD_CHUNK + a] = dd;
+            }
+        }
+        __syncthreads();
+        uint32_t nsel = 0;
+        uint32_t mine = 0; // lane s < nsel: sorted index of the s-th selected candidate
+        for (uint32_t j = 0; j < n && nsel < max_neighbors; ++j) { // :866-881
+            const float dj = L.cd[j];
+            const bool bad = lane < nsel && !(dj <= L.pair[mine * BUILD_CHUNK + j]); // dist_to_element(n, &element_j)
+            if (wave_ballot(bad) == 0) {
+                if (lane == nsel) {
+                    mine = j;
+                    L.sid[nsel] = L.cid[j];
+                    L.sd[nsel] = dj;
+                }
+                nsel += 1;
+            }
         }
         __syncthreads();
         return nsel;
@@ -236,7 +295,7 @@ struct RowWork {
             L.slot[rank] = lane; // where this candidate's row sits when everything fits one chunk
         }
         __syncthreads();
-        const uint32_t ns = select_neighbors(n, num_neighbors, one_chunk); // :947
+        const uint32_t ns = one_chunk ? select_neighbors_pairs(n, num_neighbors) : select_neighbors(n, num_neighbors); // :947
         if (lane < 64) L.cur[lane] = (lane < ns) ? L.sid[lane] : ID_EMPTY;  // :950-958
         __syncthreads();
         return ns;
@@ -283,7 +342,7 @@ __global__ __launch_bounds__(64) void select_kernel(const BuildParams P) {
             m += (uint32_t)__popcll(km);
         }
         __syncthreads();
-        nsel = w.select_neighbors(m, P.m_layer, false); // :824
+        nsel = w.select_neighbors(m, P.m_layer); // :824
         // duplicates rule, :828-832
         const uint32_t half = P.m_layer / 2;
         if (half < nsel && w.L.sd[half] < EPS100) nsel = 0;
