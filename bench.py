@@ -198,16 +198,40 @@ def main():
 
     # ---- the same K steps strictly one after the other on ONE stream, HIP events around each launch:
     # the per-launch duration the roofline is quoted on (and what rocprofv3 sees per kernel) -----------
+    # Two pairs of HIP events per step, all on the launch stream: around the whole call (scratch memset +
+    # search_kernel + slow_kernel) and, inside the library, immediately around search_kernel's dispatch.
+    import ctypes as C
+    from granne_amd import _lib as _glib
+    glib = _glib.lib()
+
+    def hip_event():
+        e = C.c_void_p()
+        _glib.check(glib.granne_hip_event_create(C.byref(e)))
+        return e
+
+    def hip_elapsed_ms(a, b):
+        ms = C.c_float()
+        _glib.check(glib.granne_hip_event_elapsed_ms(a, b, C.byref(ms)))
+        return float(ms.value)
+
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    kev = [(hip_event(), hip_event()) for _ in range(args.steps)]
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(args.steps):
+        b = args.warmup + i
         ev[i][0].record()
-        step(args.warmup + i)
+        index.search_batch_device_timed(queries[b * nq:(b + 1) * nq].data_ptr(), nq, ef, k, ids[b].data_ptr(),
+                                        dists[b].data_ptr(), counts[b].data_ptr(), stats[b].data_ptr(),
+                                        status.data_ptr(), stream, kev[i][0].value, kev[i][1].value)
         ev[i][1].record()
     torch.cuda.synchronize()
     seq_elapsed = time.perf_counter() - t1
-    step_ms = [a.elapsed_time(b) for a, b in ev]  # HIP events on the launch stream
+    call_ms = [a.elapsed_time(b) for a, b in ev]
+    step_ms = [hip_elapsed_ms(a, b) for a, b in kev]  # search_kernel alone: what rocprofv3 --kernel-trace reports
+    for a, b in kev:
+        glib.granne_hip_event_destroy(a)
+        glib.granne_hip_event_destroy(b)
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------
     st = stats[args.warmup:].sum(dim=(0, 1)).cpu().numpy().astype(np.float64)  # n_dist, n_expand, n_adj
@@ -234,6 +258,7 @@ def main():
         "aggregate_achieved_with_inflight": round(alg_bytes_per_launch * (value / world / nq) / 1e9, 1),
         "alg_bytes_per_launch": int(alg_bytes_per_launch), "launch_ms_mean": round(mean_launch_ms, 4),
         "launch_ms_min": round(float(np.min(step_ms)), 4),
+        "call_ms_mean": round(float(np.mean(call_ms)), 4),  # + scratch memset and the (empty) slow-path kernel
         "per_query": {"n_dist": round(st[0] / (args.steps * nq), 1), "n_expand": round(st[1] / (args.steps * nq), 1),
                       "n_adj": round(st[2] / (args.steps * nq), 1)},
     }

@@ -59,6 +59,10 @@ SIGNATURES = {
     "granne_hip_index_get_element": (i32, [vp, u64, vp]),
     "granne_hip_search_batch": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
     "granne_hip_search_batch_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]),
+    "granne_hip_event_create": (i32, [vp]),
+    "granne_hip_event_destroy": (None, [vp]),
+    "granne_hip_event_elapsed_ms": (i32, [vp, vp, vp]),
+    "granne_hip_search_batch_device_timed": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "granne_hip_search": (i32, [vp, vp, u32, u32, vp, vp, C.POINTER(u32)]),
     "granne_hip_normalize_f32_device": (i32, [vp, u64, u32, i32, vp]),
     "granne_hip_quantize_f32_device": (i32, [vp, vp, u64, u32, i32, vp]),

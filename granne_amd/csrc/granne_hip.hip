@@ -557,7 +557,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
                          uint32_t k, uint64_t* d_ids, float* d_dists, uint32_t* d_counts, uint64_t* d_stats,
                          uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */,
                          uint32_t* d_trail = nullptr /* [nq][8]: trail mode, no search outputs */,
-                         uint32_t trail_layers = 0) {
+                         uint32_t trail_layers = 0, hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr) {
     if (ef == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
     if (nq == 0) return GRANNE_HIP_OK;
     if (k == 0) return fail(GRANNE_HIP_ERR_INVALID, "num_neighbors must be > 0");
@@ -640,8 +640,10 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     if (plan.lds_bytes > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
     if (plan.lds_bytes > 32u * 1024u)
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes));
+    if (ev_before) HIP_TRY(hipEventRecord(ev_before, s));
     hipLaunchKernelGGL(fn, dim3(nq), dim3(64), plan.lds_bytes, s, p);
     HIP_TRY(hipGetLastError());
+    if (ev_after) HIP_TRY(hipEventRecord(ev_after, s));
 
     SlowParams sp;
     sp.sp = p;
@@ -677,6 +679,33 @@ extern "C" int granne_hip_search_batch_device(const granne_hip_index* ix, const 
     SearchTarget T = target_of(ix);
     return search_launch(&T, d_queries, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
                          d_out_ids, d_out_dists, d_out_counts, d_out_stats, d_status, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int granne_hip_search_batch_device_timed(const granne_hip_index* ix, const void* d_queries, uint32_t nq,
+                                                    uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
+                                                    float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
+                                                    uint32_t* d_status, void* stream, void* ev_before, void* ev_after) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    SearchTarget T = target_of(ix);
+    return search_launch(&T, d_queries, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
+                         d_out_ids, d_out_dists, d_out_counts, d_out_stats, d_status, (hipStream_t)stream, nullptr,
+                         nullptr, 0, (hipEvent_t)ev_before, (hipEvent_t)ev_after);
+}
+
+extern "C" int granne_hip_event_create(void** out_event) {
+    if (!out_event) return fail(GRANNE_HIP_ERR_INVALID, "out_event is null");
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreate(&e));
+    *out_event = (void*)e;
+    return GRANNE_HIP_OK;
+}
+extern "C" void granne_hip_event_destroy(void* event) {
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+extern "C" int granne_hip_event_elapsed_ms(void* before, void* after, float* out_ms) {
+    if (!before || !after || !out_ms) return fail(GRANNE_HIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipEventElapsedTime(out_ms, (hipEvent_t)before, (hipEvent_t)after));
+    return GRANNE_HIP_OK;
 }
 
 extern "C" int granne_hip_search_batch(const granne_hip_index* ix, const void* queries, uint32_t nq, uint32_t max_search,

@@ -262,6 +262,14 @@ class Granne:
                                                    C.c_void_p(d_counts), C.c_void_p(d_stats), C.c_void_p(d_status),
                                                    C.c_void_p(stream)))
 
+    def search_batch_device_timed(self, d_queries, nq, max_search, num_elements, d_ids, d_dists, d_counts, d_stats,
+                                  d_status, stream, ev_before, ev_after):
+        """search_batch_device plus two raw hipEvent_t recorded around the search kernel's dispatch."""
+        check(lib().granne_hip_search_batch_device_timed(self._h, C.c_void_p(d_queries), nq, int(max_search),
+                                                         int(num_elements), C.c_void_p(d_ids), C.c_void_p(d_dists),
+                                                         C.c_void_p(d_counts), C.c_void_p(d_stats), C.c_void_p(d_status),
+                                                         C.c_void_p(stream), C.c_void_p(ev_before), C.c_void_p(ev_after)))
+
     def dists_device(self, d_queries, nq, d_ids, m, d_out, d_status=0, stream=0):
         """ElementContainer::dists (src/elements/mod.rs:35-39) batched on device: out[q, j] =
         dist(element ids[q, j], query q). Raw device pointers (int), asynchronous on `stream`."""

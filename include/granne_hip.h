@@ -131,6 +131,21 @@ int granne_hip_search_batch_device(const granne_hip_index* index, const void* d_
                                    float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
                                    uint32_t* d_status, void* stream);
 
+/* granne_hip_search_batch_device, and two optional hipEvent_t recorded on `stream` immediately
+ * before and after the dispatch of the search kernel itself (the call also enqueues a small
+ * scratch memset before it and the slow-path kernel after it): lets a caller time the dominant
+ * kernel alone, the way rocprofv3 --kernel-trace sees it. No reference counterpart (measurement). */
+int granne_hip_search_batch_device_timed(const granne_hip_index* index, const void* d_queries, uint32_t nq,
+                                         uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
+                                         float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
+                                         uint32_t* d_status, void* stream, void* ev_before, void* ev_after);
+
+/* hipEvent_t helpers for the call above, so that a host language without HIP bindings can time it:
+ * create / destroy an event, milliseconds between two recorded and completed events. */
+int granne_hip_event_create(void** out_event);
+void granne_hip_event_destroy(void* event);
+int granne_hip_event_elapsed_ms(void* before, void* after, float* out_ms);
+
 /* Granne::search for one query (host pointers); *out_count results written. */
 int granne_hip_search(const granne_hip_index* index, const void* query, uint32_t max_search,
                       uint32_t num_neighbors, uint64_t* out_ids, float* out_dists, uint32_t* out_count);

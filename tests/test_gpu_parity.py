@@ -446,3 +446,33 @@ def test_concurrent_searches_on_a_shared_index(ga, oracle):
     [t.join() for t in th]
     for i in range(4):
         assert (got[i][0] == want[i][0]).all() and got[i][1].tobytes() == want[i][1].tobytes()
+
+
+def test_timed_search_records_events_around_the_kernel(ga, oracle):
+    """granne_hip_search_batch_device_timed: same results, and the two events bracket the search kernel."""
+    import ctypes as C
+    import torch
+    from granne_amd import _lib
+    rng = np.random.default_rng(77)
+    el = prep(oracle, random_floats(rng, 3000, 100), False)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
+    gix = ga.Granne("angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 128, 100), False)
+    tq = torch.from_numpy(q).cuda()
+    ids = torch.empty((128, 10), dtype=torch.int64, device="cuda")
+    ds = torch.empty((128, 10), dtype=torch.float32, device="cuda")
+    cnt = torch.empty(128, dtype=torch.int32, device="cuda")
+    lib = _lib.lib()
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    _lib.check(lib.granne_hip_event_create(C.byref(e0)))
+    _lib.check(lib.granne_hip_event_create(C.byref(e1)))
+    gix.search_batch_device_timed(tq.data_ptr(), 128, 50, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), 0, 0,
+                                  torch.cuda.current_stream().cuda_stream, e0.value, e1.value)
+    torch.cuda.synchronize()
+    ms = C.c_float(-1.0)
+    _lib.check(lib.granne_hip_event_elapsed_ms(e0, e1, C.byref(ms)))
+    assert 0.0 < ms.value < 1000.0
+    lib.granne_hip_event_destroy(e0)
+    lib.granne_hip_event_destroy(e1)
+    want = oix.search_batch(q, 50, 10)
+    assert (ids.cpu().numpy().astype(np.uint64) == want[0]).all() and ds.cpu().numpy().tobytes() == want[1].tobytes()
