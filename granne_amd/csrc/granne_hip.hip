@@ -627,6 +627,11 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.slow_list = (uint32_t*)(scratch + off_list);
     p.force_slow = all_slow ? 1 : 0;
     p.spec = 1;
+    // The candidates' adjacency rows can ride along with the row gather (SearchParams::spec_ticks).
+    // Measured on MI355X at C2: no gain with one batch in flight (2.54M vs 2.54M queries/s), 10-25 % lost
+    // with three (the rows are 20 % of the traffic) at every threshold tried -> off unless asked for.
+    p.spec_ticks = 0;
+    if (const char* e = getenv("GRANNE_HIP_SPEC_TICKS")) p.spec_ticks = (uint32_t)strtoul(e, nullptr, 10); // experiments
     p.ovf.tables = (uint32_t*)(scratch + off_ovf);
     p.ovf.state = (uint32_t*)(scratch + off_state);
     p.ovf.slots = ovf_slots;

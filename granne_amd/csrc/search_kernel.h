@@ -60,6 +60,9 @@ struct SearchParams {
     uint32_t* slow_list;     // [nq]
     uint32_t force_slow;
     uint32_t spec;           // 1: speculative adjacency prefetch (narrow layers)
+    uint32_t spec_ticks;     // fast expansion: the candidates' adjacency rows ride along with the row gather
+                             // while the gather of the previous expansion came back within this many
+                             // s_memrealtime ticks (100 MHz); 0 = never, ~0u = always
     OverflowPool ovf;        // global overflow tables of the visited sets (wave_prims.h)
     // trail mode (Granne::reorder, src/index/reorder.rs:180-208): instead of a search, walk layers
     // 0..trail_layers-1 with max_search 1, each from node 0, and record the ids found
@@ -112,6 +115,7 @@ struct Walker {
     SortedList<S> pq;  // `pq`, bounded at 64*S entries
     WalkStats st;
     bool bail; // visited table full or unsafe queue drop: hand over to the slow path
+    bool spec_on, spec_was_on; // see SearchParams::spec_ticks (wave-uniform)
 
     __device__ __forceinline__ Walker(const SearchParams& p_, uint8_t* smem) : p(p_) {
         lane = threadIdx.x;
@@ -126,6 +130,8 @@ struct Walker {
         dy = 0;
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
+        spec_on = p.spec_ticks != 0;
+        spec_was_on = false;
         vis.init_walker();
     }
 
@@ -342,6 +348,8 @@ struct Walker {
         const uint32_t id2 = (uint32_t)__shfl((int)nb, (int)min(16u + rip, last), 64);
         const uint32_t id3 = (uint32_t)__shfl((int)nb, (int)min(24u + rip, last), 64);
         float d = 0.0f;
+        const uint64_t t_issue = __builtin_amdgcn_s_memrealtime();
+        spec_was_on = spec_on;
         if constexpr (FASTF32) {
             const uint8_t* e0 = p.elements + (size_t)id0 * p.row_bytes + sub * 16u;
             const uint8_t* e1 = p.elements + (size_t)id1 * p.row_bytes + sub * 16u;
@@ -366,10 +374,13 @@ struct Walker {
                 const uint32_t idt = (uint32_t)__shfl((int)nb, (int)min(trow, last), 64);
                 vt = *reinterpret_cast<const float4*>(p.elements + (size_t)idt * p.row_bytes + NB * 128 + tpart * 16u);
             }
-            const uint4 a0 = load_global_u4(adj + (size_t)id0 * 32u + sub * 4u);
-            const uint4 a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
-            const uint4 a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
-            const uint4 a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
+            uint4 a0 = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY), a1 = a0, a2 = a0, a3 = a0;
+            if (spec_on) {
+                a0 = load_global_u4(adj + (size_t)id0 * 32u + sub * 4u);
+                a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
+                a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
+                a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
+            }
             fresh = vis.insert(nb, lane < nvalid, p.ovf); // visited.insert(neighbor_idx), mod.rs:1026 -- under the loads
             {   // pin: everything above is issued (and the set updated) before anything below waits
                 float chk = vt.x;
@@ -397,6 +408,11 @@ struct Walker {
     }
             GRANNE_FOR_FB(GRANNE_FB_FMA)
 #undef GRANNE_FB_FMA
+            {   // the gather has landed: how long did it take? (throttles the speculative adjacency fetch)
+                asm volatile("" ::"v"(c0_0), "v"(c1_1), "v"(c2_2), "v"(c3_3));
+                const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
+                spec_on = (uint32_t)(t_done - t_issue) < p.spec_ticks;
+            }
 #undef GRANNE_FB_LOAD
 #undef GRANNE_FOR_FB
             // ordered sum over the 32 accumulators of a row: at step ps the lane with sub == ps adds its
@@ -446,14 +462,19 @@ struct Walker {
             const uint4 x1 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id1 * 128u + sub * 16u);
             const uint4 x2 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id2 * 128u + sub * 16u);
             const uint4 x3 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id3 * 128u + sub * 16u);
-            const uint4 a0 = load_global_u4(adj + (size_t)id0 * 32u + sub * 4u);
-            const uint4 a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
-            const uint4 a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
-            const uint4 a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
+            uint4 a0 = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY), a1 = a0, a2 = a0, a3 = a0;
+            if (spec_on) {
+                a0 = load_global_u4(adj + (size_t)id0 * 32u + sub * 4u);
+                a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
+                a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
+                a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
+            }
             fresh = vis.insert(nb, lane < nvalid, p.ovf);
             {
                 uint32_t chk = x0.x ^ x1.x ^ x2.x ^ x3.x;
                 asm volatile("" ::"v"(chk) : "memory");
+                const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
+                spec_on = (uint32_t)(t_done - t_issue) < p.spec_ticks;
             }
             sa0 = a0; sa1 = a1; sa2 = a2; sa3 = a3;
             const uint4 y = qpiece;
@@ -583,7 +604,7 @@ struct Walker {
             float d0 = fast_rows(nb0, 1, adjg, fresh0); // also fetches the entry point's adjacency row
             vis.count = 1;
             st.n_dist += 1;
-            specB_m = 1;
+            specB_m = spec_was_on ? 1u : 0u;
             specB_cid = nb0;
             uint64_t k0 = readlane64(make_key(d0, entrypoint), 0);
             pq.insert_at(0, k0, lane);
@@ -661,7 +682,7 @@ struct Walker {
                         const uint32_t m = (uint32_t)__popcll(wave_ballot(fresh));
                         vis.added(m);
                         st.n_dist += m;
-                        specB_m = nvalid;
+                        specB_m = spec_was_on ? nvalid : 0u;
                         specB_cid = (lane < nvalid) ? nb : ID_EMPTY;
                         offer_lanes(fresh, d, nb, full, worst, ef);
                     }
