@@ -1,21 +1,27 @@
 // search_kernel.h -- Granne::search as one gfx950 kernel: one wavefront walks one query through
 // every layer (find_entrypoint + search_for_neighbors, /root/reference/src/index/mod.rs:963-1037).
 //
-// Per expansion (one iteration of the reference's `while let Some(..) = pq.pop()` loop):
-//   1. the expanded node's adjacency row (device layout: fixed width, 128-byte aligned) is read
-//      with one coalesced load, one neighbor id per lane;
-//   2. every lane offers its id to the exact LDS visited set (ds_cmpst), new ids are compacted;
-//   3. f32: the new candidates' rows are gathered from HBM with 16-byte loads, 64 lanes wide,
-//      into an LDS stage; then ONE LANE PER CANDIDATE evaluates the reference's exact
-//      32-accumulator dot product from LDS (dist.h), the query being broadcast from LDS;
-//      i8: 16-byte pieces of the rows go straight to lanes, v_dot4_i32_i8, xor-shuffle reduce;
-//   4. candidate keys (dist,id) that pass the reference's filter are ranked into the register-
-//      resident sorted queue with ballots.
+// Per expansion (one iteration of the reference's `while let Some(..) = pq.pop()` loop), on the
+// fast path (layers of device width 32; f32 with a compile-time dim, or i8 with 128-byte rows --
+// fast_rows below):
+//   1. the expanded node's adjacency row is already in registers when the node was the queue head
+//      one expansion earlier (prefetch), else it is read with one coalesced load, one id per lane;
+//   2. ALL loads of the expansion are issued from the neighbor ids alone, eight lanes per element
+//      row and 16 bytes per lane so that every requested 128-byte line is used in full, before the
+//      exact visited set (LDS front table + global overflow, wave_prims.h) is consulted under them;
+//   3. f32: the lane that loaded bytes 16*sub.. of a 128-byte block owns accumulators 4*sub..4*sub+3
+//      of the reference's 32 (dist.h explains why that association must be kept); the ordered sum
+//      runs down the eight lanes with row_shr DPP, the tail is folded by sequential fmas.
+//      i8: v_dot4_i32_i8 partial sums, xor-shuffle reduce, the reference's float tail;
+//   4. candidate keys (dist,id) that pass the reference's filter enter the register-resident
+//      sorted queue (ballot rank + DPP shift, or one bulk merge through LDS).
+// Other shapes (runtime-dim f32, other i8 row sizes, layers wider than 32) take the general path:
+// candidates compacted through LDS, rows staged in LDS, one lane per candidate (distances()).
 // The walk is a strict restatement of the reference's control flow, so results are identical;
-// only memory (never logic) is parallel. Two bounded structures can overflow: the LDS visited
-// table, and the candidate queue (64*S entries; dropping its largest entry is provably safe
-// unless that entry ties with the max_search-th smallest distance). Either event hands the
-// query, untouched, to the unbounded global-memory walker (slow_kernel below), which is the
+// only memory (never logic) is parallel. One bounded structure can change results: the candidate
+// queue (64*S entries; dropping its largest entry is provably safe unless that entry ties with
+// the max_search-th smallest distance). That event -- or running out of visited-set overflow --
+// hands the query, untouched, to the unbounded global-memory walker (slow_kernel.h), which is the
 // same algorithm with literal heaps -- still on the GPU, never on the CPU.
 #pragma once
 

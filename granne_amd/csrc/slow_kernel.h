@@ -2,8 +2,9 @@
 // (/root/reference/src/index/mod.rs:963-1037), but `res`, `pq` and `visited` are the reference's
 // literal containers (binary heaps and an open-addressing set) in GLOBAL memory, sized by the
 // host, so no walk can outgrow them short of GRANNE_HIP_ERR_OVERFLOW. It serves
-//   - queries the LDS walker hands over (visited table full, or a queue drop that ties with the
-//     max_search-th distance -- search_kernel.h explains why only those are unsafe),
+//   - queries the register/LDS walker hands over (a queue drop that ties with the max_search-th
+//     distance -- search_kernel.h explains why only those are unsafe -- or no visited-set
+//     overflow table left),
 //   - max_search > 256, and GRANNE_HIP_OPT_FORCE_SLOW (tests).
 // It is slow on purpose of simplicity: lane 0 runs the heaps; the 64 lanes split the neighbor
 // row (visited insert + one exact distance each, rows read straight from HBM).
