@@ -599,6 +599,11 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     size_t total = off_res + (size_t)slow_blocks * ef * 8;
     uint8_t* scratch = nullptr;
     HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
+    struct ScratchRelease { // stream-ordered free on every exit path
+        void* ptr;
+        hipStream_t stream;
+        ~ScratchRelease() { (void)hipFreeAsync(ptr, stream); }
+    } scratch_release{scratch, s};
     HIP_TRY(hipMemsetAsync(scratch, 0, off_list, s)); // header + region states
 
     SearchParams p;
@@ -672,7 +677,6 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
         h_slow_count[0] = hs[0]; // queries served by the global-memory walker
         h_slow_count[1] = hs[1];
     }
-    HIP_TRY(hipFreeAsync(scratch, s));
     return GRANNE_HIP_OK;
 }
 
