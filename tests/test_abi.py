@@ -78,3 +78,12 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.granne_hip_index_create(C.byref(h), p, 4, 8, 0, 2, lens, None, None, 0) == _lib.ERR_INVALID
     assert b"prefix" in lib.granne_hip_last_error()
     assert lib.granne_hip_search_batch(None, p, 1, 10, 1, p, p, p, None) == _lib.ERR_INVALID
+    # entries added for the operators around the path: null handles / buffers are rejected before any device call
+    assert lib.granne_hip_index_reorder(None, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_index_reorder_by_keys(None, p, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_dists_device(None, p, 1, p, 1, p, None, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_dist_pairs_device(None, p, p, p, 1, p, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_search_batch_device_timed(None, p, 1, 10, 1, p, p, p, None, None, None, None, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_event_create(None) == _lib.ERR_INVALID
+    assert lib.granne_hip_event_elapsed_ms(None, None, None) == _lib.ERR_INVALID
+    lib.granne_hip_event_destroy(None)  # a no-op
