@@ -88,6 +88,14 @@ class GranneBuilder:
             self._h = h
             self._pending = []
 
+    def load_index(self, index):
+        """GranneBuilder::from_bytes / from_file (src/index/mod.rs:430-469): adopt the layers of a written
+        index (bytes or a path) before building on; lists are resized to num_neighbors."""
+        self._ensure()
+        data = index if isinstance(index, (bytes, bytearray, memoryview)) else open(index, "rb").read()
+        buf = np.frombuffer(data, np.uint8)
+        check(lib().granne_hip_builder_load_index(self._h, buf.ctypes.data_as(C.c_void_p), buf.size))
+
     def build(self, num_elements=None):
         """GranneBuilder.build (py/src/lib.rs:499-507): all elements, or the first num_elements."""
         self._ensure()

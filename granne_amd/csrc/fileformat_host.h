@@ -426,3 +426,59 @@ extern "C" int granne_hip_index_file_decode_layer(const void* index_bytes, uint6
     if (out_ids && !layers[layer].ids.empty()) memcpy(out_ids, layers[layer].ids.data(), layers[layer].ids.size() * 4);
     return GRANNE_HIP_OK;
 }
+
+// GranneBuilder::from_bytes (src/index/mod.rs:430-461): a fresh builder adopts the layers of a written
+// index; every neighbor list is resized to config.num_neighbors (:448 -- truncated, or padded with UNUSED).
+extern "C" int granne_hip_builder_load_index(granne_hip_builder* b, const void* index_bytes, uint64_t index_len) {
+    if (!b) return fail(GRANNE_HIP_ERR_INVALID, "builder is null");
+    if (!index_bytes) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (!b->layers.empty()) return fail(GRANNE_HIP_ERR_INVALID, "the builder already has layers");
+    std::vector<granne_file::DecodedLayer> layers;
+    std::string err;
+    if (granne_file::decode_index((const uint8_t*)index_bytes, index_len, &layers, &err))
+        return fail(GRANNE_HIP_ERR_IO, "index file: %s", err.c_str());
+    uint64_t prev = 0;
+    for (size_t l = 0; l < layers.size(); ++l) {
+        const uint64_t len = layers[l].offsets.size() - 1;
+        if (len < prev) return fail(GRANNE_HIP_ERR_IO, "index file: layers are not prefix-nested");
+        if (len > b->n_elements) return fail(GRANNE_HIP_ERR_IO, "index file: more nodes than the builder has elements");
+        for (uint32_t id : layers[l].ids)
+            if (id >= len) return fail(GRANNE_HIP_ERR_IO, "index file: neighbor id outside its layer");
+        prev = len;
+    }
+    if (layers.size() > 64) return fail(GRANNE_HIP_ERR_INVALID, "too many layers");
+    DeviceGuard g(b->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", b->device);
+    const uint32_t nn = b->cfg.num_neighbors, W = b->W;
+    std::vector<BuilderLayer> fresh;
+    auto drop = [&]() {
+        for (auto& L : fresh)
+            if (L.d_adj) (void)hipFree(L.d_adj);
+    };
+    for (size_t l = 0; l < layers.size(); ++l) {
+        const granne_file::DecodedLayer& D = layers[l];
+        const uint64_t len = D.offsets.size() - 1;
+        std::vector<uint32_t> rows((size_t)len * W, 0xFFFFFFFFu);
+        for (uint64_t i = 0; i < len; ++i) {
+            const uint64_t cnt = D.offsets[i + 1] - D.offsets[i];
+            const uint64_t keep = cnt < nn ? cnt : nn; // neighbors.resize(num_neighbors, UNUSED)
+            for (uint64_t c = 0; c < keep; ++c) rows[(size_t)i * W + c] = D.ids[D.offsets[i] + c];
+        }
+        BuilderLayer L;
+        L.len = len;
+        L.cap_rows = len;
+        size_t bytes = rows.size() * 4;
+        hipError_t e = hipMalloc((void**)&L.d_adj, bytes ? bytes : 16);
+        if (e == hipSuccess && bytes) e = hipMemcpy(L.d_adj, rows.data(), bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (L.d_adj) (void)hipFree(L.d_adj);
+            drop();
+            return fail(GRANNE_HIP_ERR_HIP, "layer upload failed: %s", hipGetErrorString(e));
+        }
+        b->hbm_bytes += bytes;
+        fresh.push_back(L);
+    }
+    b->layers = fresh;
+    return GRANNE_HIP_OK;
+}
+

@@ -202,6 +202,13 @@ public:
                                         (uint32_t)(elements.dim() ? elements.dim() : 1), detail::dtype_of<Scalar>::value, device));
         b_.reset(b, granne_hip_builder_destroy);
     }
+    // GranneBuilder::from_bytes (mod.rs:430-461): a builder resuming from a written index
+    static GranneBuilder from_bytes(const BuildConfig& config, const void* index, size_t index_len, const Elements& elements,
+                                    int device = 0) {
+        GranneBuilder b(config, elements, device);
+        check(granne_hip_builder_load_index(b.b_.get(), index, index_len));
+        return b;
+    }
     void build() { check(granne_hip_builder_build(b_.get(), 0)); }
     void build_partial(size_t num_elements) {
         if (num_elements == 0) return; // mod.rs:375-377

@@ -269,6 +269,12 @@ int granne_hip_builder_create(granne_hip_builder** out, const granne_hip_build_c
 int granne_hip_builder_create_device(granne_hip_builder** out, const granne_hip_build_config* config,
                                      const void* d_elements, uint64_t n_elements, uint32_t dim, int dtype,
                                      int device_id, void* stream);
+/* GranneBuilder::from_bytes(config, buffer, elements) (src/index/mod.rs:430-461): a builder that has
+ * not built anything yet adopts the layers of a written index (granne's index file format); every
+ * neighbor list is resized to config.num_neighbors -- truncated, or padded with UNUSED (:448).
+ * granne_hip_builder_build then continues from len() as the reference does. */
+int granne_hip_builder_load_index(granne_hip_builder* builder, const void* index_bytes, uint64_t index_len);
+
 /* Builder::build_partial(num_elements) (src/index/mod.rs:374-402); num_elements == 0 means
  * Builder::build() = all elements. Synchronous. */
 int granne_hip_builder_build(granne_hip_builder* builder, uint64_t num_elements);

@@ -994,6 +994,35 @@ static void index_elements_in_last_layer(gro_builder* b, uint64_t max_num_elemen
 }
 
 /* build_partial, mod.rs:374-402 */
+/* GranneBuilder::from_bytes, mod.rs:430-461: the layers of a written index become the builder's
+ * layers; every neighbor list is resized to config.num_neighbors (:448 -- truncated or padded
+ * with UNUSED). sets[l] is a [len[l]][set_width[l]] matrix, UNUSED padded. Returns 0, -1 if the
+ * builder already has layers. */
+int gro_builder_load_layers(gro_builder* b, uint32_t n_layers, const uint64_t* len, const uint32_t* const* sets,
+                            const uint32_t* set_width) {
+    if (b->n_layers) return -1;
+    b->cap_layers = n_layers > 8 ? n_layers : 8;
+    b->rows = (uint32_t**)realloc(b->rows, sizeof(uint32_t*) * b->cap_layers);
+    b->len = (uint64_t*)realloc(b->len, sizeof(uint64_t) * b->cap_layers);
+    b->width = (uint32_t*)realloc(b->width, sizeof(uint32_t) * b->cap_layers);
+    const uint32_t w = b->cfg.num_neighbors;
+    for (uint32_t l = 0; l < n_layers; ++l) {
+        size_t bytes = sizeof(uint32_t) * (size_t)len[l] * w;
+        b->rows[l] = (uint32_t*)malloc(bytes ? bytes : 4);
+        b->len[l] = len[l];
+        b->width[l] = w;
+        for (uint64_t i = 0; i < len[l]; ++i) {
+            const uint32_t* src = sets[l] + (size_t)i * set_width[l];
+            uint32_t* dst = b->rows[l] + (size_t)i * w;
+            uint32_t n = 0;
+            while (n < set_width[l] && src[n] != GRO_UNUSED) ++n; /* layer.get_into(i, ..) */
+            for (uint32_t c = 0; c < w; ++c) dst[c] = c < n ? src[c] : GRO_UNUSED; /* neighbors.resize(..) */
+        }
+    }
+    b->n_layers = n_layers;
+    return 0;
+}
+
 void gro_builder_build_partial(gro_builder* b, uint64_t num_elements) {
     if (num_elements == 0) return;
     if (num_elements > b->n_elements) num_elements = b->n_elements; /* reference asserts */

@@ -109,6 +109,10 @@ typedef struct gro_builder gro_builder;
 gro_builder* gro_builder_create(const gro_build_config* cfg, const void* elements,
                                 uint64_t n_elements, uint32_t dim, int dtype);
 void gro_builder_build_partial(gro_builder* b, uint64_t num_elements); /* mod.rs:374-402 */
+/* GranneBuilder::from_bytes (mod.rs:430-461): adopt the layers of a written index; sets[l] is
+ * [len[l]][set_width[l]], GRO_UNUSED padded, each list resized to cfg.num_neighbors. */
+int gro_builder_load_layers(gro_builder* b, uint32_t n_layers, const uint64_t* len,
+                            const uint32_t* const* sets, const uint32_t* set_width);
 uint32_t gro_builder_num_layers(const gro_builder* b);
 uint64_t gro_builder_layer_len(const gro_builder* b, uint32_t layer);
 uint32_t gro_builder_layer_width(const gro_builder* b, uint32_t layer);

@@ -91,6 +91,8 @@ def lib():
         L.gro_builder_create.argtypes = [C.POINTER(_BuildConfig), C.c_void_p, C.c_uint64, C.c_uint32, C.c_int]
         L.gro_builder_build_partial.restype = None
         L.gro_builder_build_partial.argtypes = [C.c_void_p, C.c_uint64]
+        L.gro_builder_load_layers.restype = C.c_int
+        L.gro_builder_load_layers.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gro_builder_num_layers.restype = C.c_uint32
         L.gro_builder_num_layers.argtypes = [C.c_void_p]
         L.gro_builder_layer_len.restype = C.c_uint64
@@ -280,9 +282,11 @@ class Index:
 
 
 def build_index(elements, num_neighbors=30, max_search=200, layer_multiplier=15.0, reinsert_elements=True,
-                expected_num_elements=0, n_threads=1, num_elements=None, batch_max=0, batch_div=8):
+                expected_num_elements=0, n_threads=1, num_elements=None, batch_max=0, batch_div=8, resume_from=None):
     """GranneBuilder::new(config, elements).build() -> get_index() (src/index/mod.rs:364-488).
-    n_threads=1 is the reference's `singlethreaded` feature: deterministic insertion order."""
+    n_threads=1 is the reference's `singlethreaded` feature: deterministic insertion order.
+    resume_from = layers of a written index (neighbor sets as UNUSED-padded matrices): the builder
+    adopts them first, GranneBuilder::from_bytes (mod.rs:430-461)."""
     elements = np.ascontiguousarray(elements)
     cfg = _BuildConfig()
     lib().gro_build_config_default(C.byref(cfg))
@@ -297,6 +301,13 @@ def build_index(elements, num_neighbors=30, max_search=200, layer_multiplier=15.
     b = lib().gro_builder_create(C.byref(cfg), _p(elements), elements.shape[0], elements.shape[1],
                                  _dtype_code(elements))
     try:
+        if resume_from is not None:
+            sets = [np.ascontiguousarray(l, np.uint32) for l in resume_from]
+            n = len(sets)
+            lens = (C.c_uint64 * max(n, 1))(*[l.shape[0] for l in sets])
+            widths = (C.c_uint32 * max(n, 1))(*[l.shape[1] for l in sets])
+            ptrs = (C.c_void_p * max(n, 1))(*[l.ctypes.data for l in sets])
+            assert lib().gro_builder_load_layers(b, n, lens, ptrs, widths) == 0
         lib().gro_builder_build_partial(b, elements.shape[0] if num_elements is None else num_elements)
         layers = []
         for l in range(lib().gro_builder_num_layers(b)):

@@ -123,3 +123,71 @@ def test_invalid_configs(ga):
         ga.GranneBuilder("angular", el, max_search=0).build()
     with pytest.raises(ValueError):
         ga.GranneBuilder("cosine", el)
+
+
+def _sets_matrix(sets, width):
+    m = np.full((len(sets), max(width, 1)), 0xFFFFFFFF, np.uint32)
+    for i, row in enumerate(sets):
+        m[i, :len(row)] = row
+    return m
+
+
+@pytest.mark.parametrize("int8", [False, True])
+def test_incremental_build_with_write_and_read(ga, oracle, tmp_path, int8):
+    """index/tests.rs:195-243: build in chunks, each chunk by a NEW builder that resumes from the index
+    file the previous one wrote (GranneBuilder::from_bytes, mod.rs:430-461) -- against the oracle doing the same."""
+    from oracle import fileformat
+    rng = np.random.default_rng(31 + int8)
+    el = prep(oracle, random_floats(rng, 1000, 25), int8)
+    et = "angular_int" if int8 else "angular"
+    kw = dict(num_neighbors=30, max_search=40, reinsert_elements=False)
+    path = str(tmp_path / "chunks.granne")
+    o_layers = None
+    for i in range(4):
+        b = ga.GranneBuilder(et, el, batch_max=64, batch_div=8, **kw)
+        if i:
+            b.load_index(path)
+            assert len(b) == i * 250
+        b.build((i + 1) * 250)
+        assert len(b) == (i + 1) * 250
+        b.save_index(path)
+        # the oracle resumes from the neighbor sets a file holds: sorted ascending (MultiSetVector::push)
+        if o_layers is None:
+            o = oracle.build_index(el, num_elements=250, batch_max=64, n_threads=0, **kw)
+        else:
+            o = oracle.build_index(el, num_elements=(i + 1) * 250, batch_max=64, n_threads=0, resume_from=o_layers, **kw)
+        meta, sets = fileformat.read_index(open(path, "rb").read())
+        o_layers = [_sets_matrix([sorted(x for x in row if x != 0xFFFFFFFF) for row in l.tolist()], l.shape[1]) for l in o.layers]
+        assert len(sets) == len(o.layers)
+        for l, want in enumerate(o_layers):
+            got = _sets_matrix(sets[l], want.shape[1])
+            assert (got == want).all(), (i, l)
+    ix = b.get_index()
+    hit = 0
+    for j in range(0, 1000, 10):  # verify_search(&index, 0.95, 40); equal int8 rows tie at distance 0
+        (found, d), = ix.search(el[j], 40, 1)
+        hit += int(found == j or d <= 1e-6)
+    assert hit >= 95
+
+
+def test_read_index_reduce_num_neighbors(ga, oracle, tmp_path):
+    """index/tests.rs:245-292: a builder resuming with a lower num_neighbors truncates the stored lists."""
+    rng = np.random.default_rng(33)
+    el = prep(oracle, random_floats(rng, 1000, 5), False)
+    b = ga.GranneBuilder("angular", el, num_neighbors=20, max_search=10, batch_max=64)
+    b.build(500)
+    path = str(tmp_path / "half.granne")
+    b.save_index(path)
+    assert len(b.get_index().get_neighbors(0)) > 5
+    b2 = ga.GranneBuilder("angular", el, num_neighbors=5, max_search=10, batch_max=64)
+    b2.load_index(open(path, "rb").read())
+    assert len(b2) == 500 and b2.num_layers() == b.num_layers()
+    first = b2.get_layer(b2.num_layers() - 1)
+    stored = sorted(b.get_index().get_neighbors(0))
+    assert [x for x in first[0].tolist() if x != 0xFFFFFFFF] == stored[:5]  # neighbors.resize(5, UNUSED), mod.rs:448
+    b2.build()
+    assert len(b2) == 1000
+    ix = b2.get_index()
+    assert all(len(ix.get_neighbors(i)) <= 5 for i in range(0, 1000, 37))
+    with pytest.raises(ga.GranneHipError):
+        b2.load_index(path)  # only a builder without layers may adopt an index
