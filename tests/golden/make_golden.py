@@ -49,9 +49,16 @@ def make(name, dtype, n, dim, nn, ms, nq, searches):
         out["stats_%d_%d" % (ms_, k)] = ctr
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, [l.shape for l in ix.layers], os.path.getsize(os.path.join(HERE, name + ".npz")))
+    return ix
+
+
+def make_reorder(indexes):
+    """Granne::reorder (src/index/reorder.rs): the permutation compute_order gives for each fixture index."""
+    out = {name: ix.compute_order(n_threads=1).astype(np.uint32) for name, ix in indexes.items() if len(ix.layers) >= 2}
+    np.savez_compressed(os.path.join(HERE, "reorder_orders.npz"), **out)
+    print("reorder_orders", sorted(out), os.path.getsize(os.path.join(HERE, "reorder_orders.npz")))
 
 
 if __name__ == "__main__":
     orc.build()
-    for c in CASES:
-        make(*c)
+    make_reorder({c[0]: make(*c) for c in CASES})

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GOLDEN = [p for p in GOLDEN if not os.path.basename(p).startswith("reorder_")]
 
 
 def load_case(path):
@@ -38,3 +39,13 @@ def test_golden_build_is_reproduced(oracle):
     ix = oracle.build_index(z["elements"], num_neighbors=20, max_search=20, n_threads=1)
     assert len(ix.layers) == len(layers)
     assert all((a == b).all() for a, b in zip(ix.layers, layers))
+
+
+def test_oracle_reproduces_golden_reorder(oracle):
+    """Granne::reorder's permutation for every fixture index (tests/golden/reorder_orders.npz)."""
+    orders = np.load(os.path.join(os.path.dirname(GOLDEN[0]), "reorder_orders.npz"))
+    assert sorted(orders.files) == sorted(os.path.basename(p)[:-4] for p in GOLDEN)
+    for path in GOLDEN:
+        z, layers, _ = load_case(path)
+        got = oracle.Index(z["elements"], layers).compute_order(n_threads=2)
+        assert got.tolist() == orders[os.path.basename(path)[:-4]].tolist()

@@ -132,3 +132,17 @@ def test_reorder_rejects_what_the_reference_panics_on(ga, oracle):
     from granne_amd import _lib
     g.set_option(_lib.OPT_FORCE_SLOW, 1)
     assert g.reorder().tolist() == full.compute_order().tolist()
+
+
+def test_gpu_reorder_reproduces_golden(ga):
+    """The committed permutations (tests/golden/reorder_orders.npz, made by tests/golden/make_golden.py)."""
+    import glob
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    orders = np.load(os.path.join(here, "reorder_orders.npz"))
+    for name in orders.files:
+        z = np.load(os.path.join(here, name + ".npz"))
+        layers = [z["layer%d" % l] for l in range(int(z["n_layers"]))]
+        et = "angular" if z["elements"].dtype == np.float32 else "angular_int"
+        gix = ga.Granne(et, z["elements"], layers)
+        assert gix.reorder().tolist() == orders[name].tolist(), name
