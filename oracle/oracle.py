@@ -324,6 +324,53 @@ def build_index(elements, num_neighbors=30, max_search=200, layer_multiplier=15.
     return Index(elements, layers)
 
 
+class Builder:
+    """GranneBuilder with several build_partial calls on one builder (src/index/mod.rs:364-402)."""
+
+    def __init__(self, elements, num_neighbors=30, max_search=200, layer_multiplier=15.0, reinsert_elements=True,
+                 expected_num_elements=0, n_threads=1, batch_max=0, batch_div=8):
+        self.elements = np.ascontiguousarray(elements)
+        cfg = _BuildConfig()
+        lib().gro_build_config_default(C.byref(cfg))
+        cfg.layer_multiplier = layer_multiplier
+        cfg.expected_num_elements = expected_num_elements
+        cfg.num_neighbors = num_neighbors
+        cfg.max_search = max_search
+        cfg.reinsert_elements = int(bool(reinsert_elements))
+        cfg.n_threads = n_threads
+        cfg.batch_max = batch_max
+        cfg.batch_div = batch_div
+        self._b = lib().gro_builder_create(C.byref(cfg), _p(self.elements), self.elements.shape[0],
+                                           self.elements.shape[1], _dtype_code(self.elements))
+
+    def build_partial(self, num_elements):
+        lib().gro_builder_build_partial(self._b, num_elements)
+
+    def build(self):
+        self.build_partial(self.elements.shape[0])
+
+    def layer_lens(self):
+        return [int(lib().gro_builder_layer_len(self._b, l)) for l in range(lib().gro_builder_num_layers(self._b))]
+
+    def __len__(self):
+        lens = self.layer_lens()
+        return lens[-1] if lens else 0
+
+    def get_index(self):
+        layers = []
+        for l in range(lib().gro_builder_num_layers(self._b)):
+            n, w = lib().gro_builder_layer_len(self._b, l), lib().gro_builder_layer_width(self._b, l)
+            ptr = lib().gro_builder_layer_rows(self._b, l)
+            layers.append(np.zeros((0, w), np.uint32) if n == 0 else
+                          np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n, w)).copy())
+        return Index(self.elements, layers)
+
+    def __del__(self):
+        if getattr(self, "_b", None):
+            lib().gro_builder_destroy(self._b)
+            self._b = None
+
+
 def select_neighbors(elements, cand_ids, cand_dists, max_neighbors):
     elements = np.ascontiguousarray(elements)
     ci = np.ascontiguousarray(cand_ids, np.uint64); cd = np.ascontiguousarray(cand_dists, np.float32)

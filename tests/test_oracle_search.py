@@ -287,3 +287,45 @@ def test_batched_build_with_batch_of_one_is_the_sequential_build(oracle):
     a = oracle.build_index(e, num_neighbors=10, max_search=20, n_threads=1)
     b = oracle.build_index(e, num_neighbors=10, max_search=20, batch_max=1)
     assert all((x == y).all() for x, y in zip(a.layers, b.layers))
+
+
+def _verify_search(ix, num, max_search):
+    """verify_search (src/index/tests.rs:50-62): fraction of elements that find themselves first."""
+    n = len(ix)
+    hits = sum(1 for i in range(0, n, max(1, n // num)) if ix.search(ix.elements[i], max_search, 1)[0][0] == i)
+    return hits / len(range(0, n, max(1, n // num)))
+
+
+def test_incremental_build_0(oracle):
+    """src/index/tests.rs:134-168: layer counts after build_partial(12), (102) and build()."""
+    rng = np.random.default_rng(41)
+    b = oracle.Builder(random_vectors(oracle, rng, 1000, 5), layer_multiplier=10.0, num_neighbors=20, max_search=5)
+    b.build_partial(12)
+    assert b.layer_lens() == [10, 12]
+    b.build_partial(102)
+    assert b.layer_lens() == [10, 100, 102]
+    b.build()
+    assert b.layer_lens() == [10, 100, 1000]
+    assert _verify_search(b.get_index(), 200, 5) > 0.95
+
+
+def test_incremental_build_1(oracle):
+    """src/index/tests.rs:170-192: ten chunks through build_partial on int8 vectors."""
+    rng = np.random.default_rng(42)
+    el = np.stack([oracle.quantize(r) for r in (rng.random((1000, 5), dtype=np.float32) - 0.5)])
+    b = oracle.Builder(el, max_search=50)
+    for i in range(1, 11):
+        b.build_partial(i * 100)
+        assert len(b) == i * 100
+    ix = b.get_index()
+    # 5-d int8 rows collide: a hit is the element itself or an exact duplicate at distance 0
+    ok = sum(1 for i in range(0, 1000, 5) if ix.search(el[i], 5, 1)[0][0] == i or ix.search(el[i], 5, 1)[0][1] <= 1e-6)
+    assert ok / 200 > 0.95
+
+
+def test_empty_build(oracle):
+    """src/index/tests.rs:293-302: build_partial(0) on a fresh builder does nothing."""
+    rng = np.random.default_rng(43)
+    b = oracle.Builder(random_vectors(oracle, rng, 100, 25))
+    b.build_partial(0)
+    assert b.layer_lens() == [] and len(b) == 0
