@@ -329,3 +329,22 @@ def test_empty_build(oracle):
     b = oracle.Builder(random_vectors(oracle, rng, 100, 25))
     b.build_partial(0)
     assert b.layer_lens() == [] and len(b) == 0
+
+
+def test_append_elements_with_expected_num_elements(oracle):
+    """src/index/tests.rs:502-566: expected_num_elements(1000) fixes the layer sizes while only half of the
+    elements have been pushed; the rest is indexed by a later build()."""
+    rng = np.random.default_rng(44)
+    el = random_vectors(oracle, rng, 1000, 50)
+    b = oracle.Builder(el, expected_num_elements=1000, layer_multiplier=10.0, num_neighbors=20, max_search=50)
+    b.build_partial(500)  # "insert half of the elements ... builder.build()"
+    assert b.layer_lens() == [10, 100, 500]
+    assert b.get_index().search(el[123], 50, 1)[0][0] == 123
+    b.build()
+    assert b.layer_lens() == [10, 100, 1000]
+    ix = b.get_index()
+    assert ix.search(el[123], 50, 1)[0][0] == 123 and ix.search(el[500 + 123], 50, 1)[0][0] == 500 + 123
+    # without the hint the first half would have been laid out as a 500-element index
+    c = oracle.Builder(el[:500], layer_multiplier=10.0, num_neighbors=20, max_search=50)
+    c.build()
+    assert c.layer_lens() == [5, 50, 500]
