@@ -85,6 +85,7 @@ SIGNATURES = {
     "granne_hip_build_config_default": (None, [vp]),
     "granne_hip_builder_create": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, i32]),
     "granne_hip_builder_create_device": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, i32, vp]),
+    "granne_hip_builder_append": (i32, [vp, vp, u64]),
     "granne_hip_builder_load_index": (i32, [vp, vp, u64]),
     "granne_hip_builder_build": (i32, [vp, u64]),
     "granne_hip_builder_len": (u64, [vp]),

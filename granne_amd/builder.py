@@ -67,15 +67,16 @@ class GranneBuilder:
         return self
 
     def append(self, element):
-        """GranneBuilder.append (py/src/lib.rs:487-489); only before the first build()."""
-        if self._h is not None:
-            raise NotImplementedError("the GPU builder takes its elements before the first build()")
+        """GranneBuilder.append (py/src/lib.rs:487-489): the element is indexed by the next build()."""
         row = np.asarray(element).reshape(1, -1)
         if self.dim is None:
             self.dim = row.shape[1]
         self._pending.append(self._prep(row))
 
     def _ensure(self):
+        if self._h is not None and self._pending and int(lib().granne_hip_builder_num_elements(self._h)) == 0:
+            self.close()  # an empty builder takes its dimension from the first element pushed
+            self.dim = self._pending[0].shape[1]
         if self._h is None:
             if self._pending:
                 el = np.ascontiguousarray(np.concatenate(self._pending, axis=0))
@@ -86,6 +87,12 @@ class GranneBuilder:
             check(lib().granne_hip_builder_create(C.byref(h), C.byref(self.config), _p(el), el.shape[0], el.shape[1],
                                                   self.dtype_code, self.device))
             self._h = h
+            self._pending = []
+        elif self._pending:  # elements appended after the builder went to the device
+            el = np.ascontiguousarray(np.concatenate(self._pending, axis=0))
+            if el.shape[1] != self.dim:
+                raise ValueError("dimension mismatch")
+            check(lib().granne_hip_builder_append(self._h, _p(el), el.shape[0]))
             self._pending = []
 
     def load_index(self, index):

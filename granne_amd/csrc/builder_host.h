@@ -139,6 +139,48 @@ extern "C" int granne_hip_builder_create(granne_hip_builder** out, const granne_
     return rc;
 }
 
+// Builder::push for a batch of rows (src/index/mod.rs:303-315, dense_vector.rs push): the element
+// container grows, nothing is indexed until the next build.
+extern "C" int granne_hip_builder_append(granne_hip_builder* b, const void* elements, uint64_t n_new) {
+    if (!b) return fail(GRANNE_HIP_ERR_INVALID, "builder is null");
+    if (n_new == 0) return GRANNE_HIP_OK;
+    if (!elements) return fail(GRANNE_HIP_ERR_INVALID, "elements is null");
+    if (b->n_elements + n_new >= 0xFFFFFFFFull) return fail(GRANNE_HIP_ERR_INVALID, "too many elements (src/index/mod.rs:420)");
+    DeviceGuard g(b->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", b->device);
+    const size_t dense = (size_t)b->dim * elem_size(b->dtype);
+    const size_t old_bytes = (size_t)b->n_elements * b->row_bytes, add_bytes = (size_t)n_new * b->row_bytes;
+    uint8_t* grown = nullptr;
+    void* staged = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMalloc((void**)&grown, old_bytes + add_bytes));
+        HIP_TRY(hipMalloc(&staged, n_new * dense));
+        HIP_TRY(hipMemcpy(staged, elements, n_new * dense, hipMemcpyHostToDevice));
+        if (old_bytes) HIP_TRY(hipMemcpyAsync(grown, b->d_elements, old_bytes, hipMemcpyDeviceToDevice, nullptr));
+        if (dense == b->row_bytes) {
+            HIP_TRY(hipMemcpyAsync(grown + old_bytes, staged, add_bytes, hipMemcpyDeviceToDevice, nullptr));
+        } else {
+            const uint64_t units = n_new * (b->row_bytes / 16);
+            hipLaunchKernelGGL(relayout_rows_kernel, dim3(grid_for(units, 256)), dim3(256), 0, nullptr,
+                               (const uint8_t*)staged, grown + old_bytes, n_new, (uint32_t)dense, b->row_bytes);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        return GRANNE_HIP_OK;
+    };
+    int rc = body();
+    if (staged) (void)hipFree(staged);
+    if (rc) {
+        if (grown) (void)hipFree(grown);
+        return rc;
+    }
+    if (b->d_elements) (void)hipFree(b->d_elements);
+    b->d_elements = grown;
+    b->n_elements += n_new;
+    b->hbm_bytes += add_bytes;
+    return GRANNE_HIP_OK;
+}
+
 extern "C" void granne_hip_builder_destroy(granne_hip_builder* b) { destroy_builder(b); }
 extern "C" uint64_t granne_hip_builder_len(const granne_hip_builder* b) {
     return (b && !b->layers.empty()) ? b->layers.back().len : 0;

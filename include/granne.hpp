@@ -209,6 +209,10 @@ public:
         check(granne_hip_builder_load_index(b.b_.get(), index, index_len));
         return b;
     }
+    // Builder::push (mod.rs:303-315): indexed by the next build()
+    void push(const typename Elements::Element& element) {
+        check(granne_hip_builder_append(b_.get(), element.as_slice(), 1));
+    }
     void build() { check(granne_hip_builder_build(b_.get(), 0)); }
     void build_partial(size_t num_elements) {
         if (num_elements == 0) return; // mod.rs:375-377

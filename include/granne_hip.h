@@ -269,6 +269,11 @@ int granne_hip_builder_create(granne_hip_builder** out, const granne_hip_build_c
 int granne_hip_builder_create_device(granne_hip_builder** out, const granne_hip_build_config* config,
                                      const void* d_elements, uint64_t n_elements, uint32_t dim, int dtype,
                                      int device_id, void* stream);
+/* Builder::push (src/index/mod.rs:303-315) for n_new prepared rows (host, dense [n_new][dim]): the
+ * builder's element container grows; nothing is indexed until the next granne_hip_builder_build
+ * (the reference's append_elements flow, src/index/tests.rs:502-566). */
+int granne_hip_builder_append(granne_hip_builder* builder, const void* elements, uint64_t n_new);
+
 /* GranneBuilder::from_bytes(config, buffer, elements) (src/index/mod.rs:430-461): a builder that has
  * not built anything yet adopts the layers of a written index (granne's index file format); every
  * neighbor list is resized to config.num_neighbors -- truncated, or padded with UNUSED (:448).

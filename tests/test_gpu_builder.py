@@ -191,3 +191,27 @@ def test_read_index_reduce_num_neighbors(ga, oracle, tmp_path):
     assert all(len(ix.get_neighbors(i)) <= 5 for i in range(0, 1000, 37))
     with pytest.raises(ga.GranneHipError):
         b2.load_index(path)  # only a builder without layers may adopt an index
+
+
+def test_append_elements_after_a_build(ga, oracle):
+    """src/index/tests.rs:502-566: expected_num_elements(1000), build on the first half, push the rest, build again."""
+    rng = np.random.default_rng(35)
+    el = prep(oracle, random_floats(rng, 1000, 50), False)
+    kw = dict(expected_num_elements=1000, layer_multiplier=10.0, num_neighbors=20, max_search=50, batch_max=64)
+    b = ga.GranneBuilder("angular", el[:500], **kw)
+    b.build()
+    assert [b.layer_len(l) for l in range(b.num_layers())] == [10, 100, 500]
+    assert b.get_index().search(el[123], 50, 1)[0][0] == 123
+    for row in el[500:]:
+        b.append(row)
+    assert b.num_elements() == 1000 and len(b) == 500  # pushed, not yet indexed
+    b.build()
+    assert [b.layer_len(l) for l in range(b.num_layers())] == [10, 100, 1000]
+    ob = oracle.Builder(el, n_threads=0, **kw)
+    ob.build_partial(500)
+    ob.build()
+    for l, want in enumerate(ob.get_index().layers):
+        assert (b.get_layer(l) == want).all(), l
+    ix = b.get_index()
+    assert ix.search(el[123], 50, 1)[0][0] == 123 and ix.search(el[623], 50, 1)[0][0] == 623
+    assert ix.get_element(999).tobytes() == el[999].tobytes()
