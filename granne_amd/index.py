@@ -12,8 +12,7 @@ import os
 
 import numpy as np
 
-from . import _lib
-from ._lib import F32, I8, UNUSED, GranneHipError, check, lib
+from ._lib import F32, I8, check, lib
 
 DEFAULT_MAX_SEARCH = 200   # py/src/lib.rs:14
 DEFAULT_NUM_ELEMENTS = 10  # py/src/lib.rs:15

@@ -136,7 +136,6 @@ def test_reorder_rejects_what_the_reference_panics_on(ga, oracle):
 
 def test_gpu_reorder_reproduces_golden(ga):
     """The committed permutations (tests/golden/reorder_orders.npz, made by tests/golden/make_golden.py)."""
-    import glob
     import os
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     orders = np.load(os.path.join(here, "reorder_orders.npz"))
