@@ -59,6 +59,18 @@ def make_reorder(indexes):
     print("reorder_orders", sorted(out), os.path.getsize(os.path.join(HERE, "reorder_orders.npz")))
 
 
+def make_batched_build():
+    """The graph of the GPU builder's schedule (gro_build_config.batch_max) on the f32_d28 rows."""
+    el = orc.normalize_f32(orc.synth_rows(SEED, 0, 1500, 28))
+    ix = orc.build_index(el, num_neighbors=20, max_search=20, batch_max=64, batch_div=8, n_threads=1)
+    out = {"n_layers": np.int64(len(ix.layers))}
+    for l, layer in enumerate(ix.layers):
+        out["layer%d" % l] = layer
+    np.savez_compressed(os.path.join(HERE, "build_batched_f32_d28.npz"), **out)
+    print("build_batched_f32_d28", [l.shape for l in ix.layers], os.path.getsize(os.path.join(HERE, "build_batched_f32_d28.npz")))
+
+
 if __name__ == "__main__":
     orc.build()
     make_reorder({c[0]: make(*c) for c in CASES})
+    make_batched_build()

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
-GOLDEN = [p for p in GOLDEN if not os.path.basename(p).startswith("reorder_")]
+GOLDEN = [p for p in GOLDEN if not os.path.basename(p).startswith(("reorder_", "build_"))]
 
 
 def load_case(path):
@@ -49,3 +49,14 @@ def test_oracle_reproduces_golden_reorder(oracle):
         z, layers, _ = load_case(path)
         got = oracle.Index(z["elements"], layers).compute_order(n_threads=2)
         assert got.tolist() == orders[os.path.basename(path)[:-4]].tolist()
+
+
+def test_oracle_reproduces_golden_batched_build(oracle):
+    """The batched insertion schedule (what the GPU builder runs) on the f32_d28 rows: tests/golden/build_batched_f32_d28.npz."""
+    here = os.path.dirname(GOLDEN[0])
+    z = np.load(os.path.join(here, "build_batched_f32_d28.npz"))
+    el = np.load(os.path.join(here, "f32_d28.npz"))["elements"]
+    for threads in (1, 3):  # deterministic for any thread count
+        ix = oracle.build_index(el, num_neighbors=20, max_search=20, batch_max=64, batch_div=8, n_threads=threads)
+        assert len(ix.layers) == int(z["n_layers"])
+        assert all((a == z["layer%d" % l]).all() for l, a in enumerate(ix.layers))

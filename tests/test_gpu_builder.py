@@ -215,3 +215,16 @@ def test_append_elements_after_a_build(ga, oracle):
     ix = b.get_index()
     assert ix.search(el[123], 50, 1)[0][0] == 123 and ix.search(el[623], 50, 1)[0][0] == 623
     assert ix.get_element(999).tobytes() == el[999].tobytes()
+
+
+def test_gpu_build_reproduces_golden(ga):
+    """tests/golden/build_batched_f32_d28.npz (made by tests/golden/make_golden.py from the oracle's batched build)."""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(here, "build_batched_f32_d28.npz"))
+    el = np.load(os.path.join(here, "f32_d28.npz"))["elements"]
+    b = ga.GranneBuilder("angular", el, num_neighbors=20, max_search=20, batch_max=64, batch_div=8)
+    b.build()
+    assert b.num_layers() == int(z["n_layers"])
+    for l in range(b.num_layers()):
+        assert (b.get_layer(l) == z["layer%d" % l]).all(), l

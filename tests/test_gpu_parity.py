@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 from tests.conftest import random_floats  # noqa: E402
 
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
-GOLDEN = [p for p in GOLDEN if not os.path.basename(p).startswith("reorder_")]
+GOLDEN = [p for p in GOLDEN if not os.path.basename(p).startswith(("reorder_", "build_"))]
 
 
 @pytest.fixture(scope="module")
