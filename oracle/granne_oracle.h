@@ -14,7 +14,8 @@
  *     delta encoding (src/slice_vector/set_vector.rs:231-237);
  *   - the reference's property tests restated in tests/ (math.rs:183-196,
  *     angular.rs:99-126, index/tests.rs:50-62,114-132);
- *   - a second, independent numpy/Python restatement (oracle/pyref.py) diffed against it.
+ *   - a second, independent numpy/Python restatement (oracle/pyref.py: arithmetic, search, the
+ *     whole single-threaded builder, reorder) diffed against it bit for bit / id for id.
  * Search-output parity against a *running* reference is therefore "unpinned"; see DESIGN.md.
  */
 #ifndef GRANNE_ORACLE_H

@@ -202,3 +202,130 @@ def reorder_layers(layers, order):
     for i, j in enumerate(order):
         rev[j] = i
     return [[sorted(rev[n] for n in get_neighbors(layer, order[i])) for i in range(len(layer))] for layer in layers]
+
+
+# ---- GranneBuilder, `singlethreaded` order (src/index/mod.rs:364-402, 645-960) ----------------------
+EPS100 = float(np.float32(100.0) * np.float32(1.1920929e-07))  # 100.0 * f32::EPSILON
+
+
+class Builder:
+    """GranneBuilder::new + build_partial, restated from the Rust source independently of
+    oracle/granne_oracle.c. Layers are lists of rows (lists of ids, UNUSED padded to num_neighbors).
+    Where the reference's sort is unstable (add_and_limit_neighbors sorts by distance only,
+    mod.rs:943) ties are ordered by id, the convention the C oracle and the GPU builder share."""
+
+    def __init__(self, elements, num_neighbors=30, max_search=200, layer_multiplier=15.0, reinsert_elements=True,
+                 expected_num_elements=None):
+        self.elements = elements
+        self.num_neighbors = num_neighbors
+        self.max_search = max_search
+        self.layer_multiplier = layer_multiplier
+        self.reinsert_elements = reinsert_elements
+        self.expected_num_elements = expected_num_elements
+        self.layers = []
+
+    def __len__(self):
+        return len(self.layers[-1]) if self.layers else 0
+
+    # mod.rs:374-402
+    def build_partial(self, num_elements):
+        if num_elements == 0:
+            return
+        assert num_elements >= len(self) and num_elements <= len(self.elements)
+        if self.layers:
+            self._index_elements_in_last_layer(num_elements)
+        while len(self) < num_elements:
+            self.layers.append([list(r) for r in self.layers[-1]] if self.layers else [])
+            self._index_elements_in_last_layer(num_elements)
+
+    # mod.rs:646-713
+    def _index_elements_in_last_layer(self, max_num_elements):
+        total = self.expected_num_elements if self.expected_num_elements is not None else len(self.elements)
+        ideal = compute_num_elements_in_layer(max(total, len(self.elements)), self.layer_multiplier, len(self.layers) - 1)
+        if ideal <= len(self.layers[-1]):
+            return
+        num_in_layer = min(max_num_elements, ideal)
+        nn, ms = self.num_neighbors, self.max_search
+        if ideal < total:  # not the last layer: half num_neighbors
+            nn = max(1, nn // 2)
+        layer = self.layers.pop()
+        prev_layers = self.layers  # get_index() over the layers below the one being built
+        self._index_elements(nn, ms, num_in_layer, prev_layers, layer, False)
+        if self.reinsert_elements:
+            self._index_elements(nn, max(1, ms // 2), num_in_layer, prev_layers, layer, True)
+        self.layers.append(layer)
+
+    # mod.rs:716-802
+    def _index_elements(self, nn, ms, num_elements, prev_layers, layer, reinsert):
+        assert len(layer) <= num_elements
+        already = len(layer)
+        if reinsert:
+            already = 0
+        else:
+            layer.extend([UNUSED] * self.num_neighbors for _ in range(num_elements - len(layer)))
+        order = range(len(layer) - 1, -1, -1) if reinsert else range(already, len(layer))
+        for idx in order:
+            self._index_element(nn, ms, prev_layers, layer, idx)
+        for i in range(len(layer)):
+            self._add_and_limit_neighbors(layer[i], i, [], nn)
+
+    # mod.rs:805-846
+    def _index_element(self, nn, ms, prev_layers, layer, idx):
+        el = self.elements
+        if float(dist(el[idx], el[idx])) > EPS100:
+            return
+        found = search(prev_layers, el, el[idx], 1, 1)
+        entrypoint = found[0][0] if found else 0
+        candidates = [(i, d) for i, d in search_for_neighbors(layer, entrypoint, el, el[idx], ms) if i != idx]
+        neighbors = self._select_neighbors(candidates, nn)
+        if nn // 2 < len(neighbors) and neighbors[nn // 2][1] < EPS100:
+            return
+        if layer[idx][0] == UNUSED:
+            for k, (j, _) in enumerate(neighbors[: len(layer[idx])]):  # initialize_node, :886-896
+                layer[idx][k] = j
+        else:
+            for j, d in neighbors:
+                self._connect_nodes(layer[idx], idx, j, d)
+        for j, d in neighbors:
+            self._connect_nodes(layer[j], j, idx, d)
+
+    # mod.rs:849-883
+    def _select_neighbors(self, candidates, max_neighbors):
+        if len(candidates) <= max_neighbors:
+            return list(candidates)
+        el = self.elements
+        out = []
+        for j, d in candidates:
+            if len(out) >= max_neighbors:
+                break
+            if all(d <= float(dist(el[n], el[j])) for n, _ in out):
+                out.append((j, d))
+        return out
+
+    # mod.rs:898-921
+    def _connect_nodes(self, node, i, j, d):
+        if i == j:
+            return
+        for pos, x in enumerate(node):
+            if x == UNUSED or x == j:
+                node[pos] = j
+                return
+        self._add_and_limit_neighbors(node, i, [(j, d)], len(node))
+
+    # mod.rs:923-959
+    def _add_and_limit_neighbors(self, node, node_id, extra, num_neighbors):
+        el = self.elements
+        neighbors = []
+        for x in node:
+            if x == UNUSED:
+                break
+            neighbors.append(x)
+        candidates = [(n, float(dist(el[node_id], el[n]))) for n in neighbors] + list(extra)
+        candidates.sort(key=lambda c: (c[1], c[0]))
+        kept = self._select_neighbors(candidates, num_neighbors)
+        for k in range(len(node)):
+            node[k] = kept[k][0] if k < len(kept) else UNUSED
+
+    def rows(self):
+        """Layers as UNUSED-padded uint32 matrices, like the oracle's."""
+        return [np.array(l, np.uint32).reshape(len(l), self.num_neighbors) for l in self.layers]

@@ -348,3 +348,39 @@ def test_append_elements_with_expected_num_elements(oracle):
     c = oracle.Builder(el[:500], layer_multiplier=10.0, num_neighbors=20, max_search=50)
     c.build()
     assert c.layer_lens() == [5, 50, 500]
+
+
+@pytest.mark.parametrize("n,dim,int8,nn,ms,mult,reinsert", [
+    (220, 8, False, 10, 20, 6.0, True),
+    (180, 16, True, 8, 15, 5.0, True),
+    (200, 5, False, 6, 10, 4.0, False),
+])
+def test_sequential_build_matches_python_restatement(oracle, n, dim, int8, nn, ms, mult, reinsert):
+    """The whole builder (src/index/mod.rs:364-402, 645-960) restated a second time in oracle/pyref.py::Builder:
+    the graphs must be identical, layer by layer, id by id."""
+    from oracle import pyref
+    rng = np.random.default_rng(n + dim)
+    el = random_vectors(oracle, rng, n, dim, int8)
+    pb = pyref.Builder(el, num_neighbors=nn, max_search=ms, layer_multiplier=mult, reinsert_elements=reinsert)
+    pb.build_partial(n)
+    ob = oracle.build_index(el, num_neighbors=nn, max_search=ms, layer_multiplier=mult, reinsert_elements=reinsert,
+                            n_threads=1)
+    assert [len(l) for l in pb.layers] == [l.shape[0] for l in ob.layers]
+    for got, want in zip(pb.rows(), ob.layers):
+        assert (got == want).all()
+
+
+def test_partial_builds_match_python_restatement(oracle):
+    """build_partial in steps and expected_num_elements, C oracle vs oracle/pyref.py::Builder."""
+    from oracle import pyref
+    rng = np.random.default_rng(77)
+    el = random_vectors(oracle, rng, 240, 6)
+    kw = dict(num_neighbors=8, max_search=12, layer_multiplier=5.0)
+    pb = pyref.Builder(el, expected_num_elements=400, **kw)
+    ob = oracle.Builder(el, expected_num_elements=400, **kw)
+    for step in (7, 60, 61, 240):
+        pb.build_partial(step)
+        ob.build_partial(step)
+        assert [len(l) for l in pb.layers] == ob.layer_lens()
+        for got, want in zip(pb.rows(), ob.get_index().layers):
+            assert (got == want).all(), step
