@@ -215,7 +215,11 @@ class Builder:
     mod.rs:943) ties are ordered by id, the convention the C oracle and the GPU builder share."""
 
     def __init__(self, elements, num_neighbors=30, max_search=200, layer_multiplier=15.0, reinsert_elements=True,
-                 expected_num_elements=None):
+                 expected_num_elements=None, batch_max=0, batch_div=8):
+        # batch_max > 0: the BATCHED schedule of the GPU builder (oracle/granne_oracle.h, gro_build_config):
+        # a batch's members search and select against the graph frozen at the start of the batch, then
+        # their link updates are applied in batch order
+        self.batch_max, self.batch_div = batch_max, batch_div
         self.elements = elements
         self.num_neighbors = num_neighbors
         self.max_search = max_search
@@ -263,23 +267,43 @@ class Builder:
             already = 0
         else:
             layer.extend([UNUSED] * self.num_neighbors for _ in range(num_elements - len(layer)))
-        order = range(len(layer) - 1, -1, -1) if reinsert else range(already, len(layer))
-        for idx in order:
-            self._index_element(nn, ms, prev_layers, layer, idx)
+        order = list(range(len(layer) - 1, -1, -1) if reinsert else range(already, len(layer)))
+        if self.batch_max > 0:
+            pos = 0
+            while pos < len(order):
+                n_in_graph = len(layer) if reinsert else already + pos
+                batch = min(max(1, n_in_graph // max(1, self.batch_div)), self.batch_max, len(order) - pos)
+                members = order[pos:pos + batch]
+                chosen = [self._select(nn, ms, prev_layers, layer, idx) for idx in members]  # graph frozen
+                for idx, neighbors in zip(members, chosen):
+                    if neighbors is not None:
+                        self._apply(layer, idx, neighbors)
+                pos += batch
+        else:
+            for idx in order:
+                self._index_element(nn, ms, prev_layers, layer, idx)
         for i in range(len(layer)):
             self._add_and_limit_neighbors(layer[i], i, [], nn)
 
     # mod.rs:805-846
     def _index_element(self, nn, ms, prev_layers, layer, idx):
+        neighbors = self._select(nn, ms, prev_layers, layer, idx)
+        if neighbors is not None:
+            self._apply(layer, idx, neighbors)
+
+    def _select(self, nn, ms, prev_layers, layer, idx):  # :812-832, reads the graph only
         el = self.elements
         if float(dist(el[idx], el[idx])) > EPS100:
-            return
+            return None
         found = search(prev_layers, el, el[idx], 1, 1)
         entrypoint = found[0][0] if found else 0
         candidates = [(i, d) for i, d in search_for_neighbors(layer, entrypoint, el, el[idx], ms) if i != idx]
         neighbors = self._select_neighbors(candidates, nn)
         if nn // 2 < len(neighbors) and neighbors[nn // 2][1] < EPS100:
-            return
+            return None
+        return neighbors
+
+    def _apply(self, layer, idx, neighbors):  # :834-845, the link updates
         if layer[idx][0] == UNUSED:
             for k, (j, _) in enumerate(neighbors[: len(layer[idx])]):  # initialize_node, :886-896
                 layer[idx][k] = j

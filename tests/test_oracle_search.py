@@ -384,3 +384,27 @@ def test_partial_builds_match_python_restatement(oracle):
         assert [len(l) for l in pb.layers] == ob.layer_lens()
         for got, want in zip(pb.rows(), ob.get_index().layers):
             assert (got == want).all(), step
+
+
+@pytest.mark.parametrize("n,dim,int8,nn,ms,mult,reinsert,bmax,bdiv", [
+    (220, 8, False, 10, 20, 6.0, True, 16, 8),
+    (180, 16, True, 8, 15, 5.0, True, 64, 4),
+    (200, 5, False, 6, 10, 4.0, False, 7, 2),
+])
+def test_batched_build_matches_python_restatement(oracle, n, dim, int8, nn, ms, mult, reinsert, bmax, bdiv):
+    """The batched insertion schedule (what the GPU builder runs; gro_build_config.batch_max) restated in
+    oracle/pyref.py::Builder: same graphs from the C oracle for any thread count, also across build_partial steps."""
+    from oracle import pyref
+    rng = np.random.default_rng(n + dim + bmax)
+    el = random_vectors(oracle, rng, n, dim, int8)
+    kw = dict(num_neighbors=nn, max_search=ms, layer_multiplier=mult, reinsert_elements=reinsert, batch_max=bmax,
+              batch_div=bdiv)
+    pb = pyref.Builder(el, **kw)
+    ob = oracle.Builder(el, n_threads=3, **kw)
+    for step in (n // 2, n):
+        pb.build_partial(step)
+        ob.build_partial(step)
+    want = ob.get_index().layers
+    assert [len(l) for l in pb.layers] == [l.shape[0] for l in want]
+    for got, w in zip(pb.rows(), want):
+        assert (got == w).all()
