@@ -13,6 +13,7 @@
 
 #include "../../include/granne_hip.h"
 #include "search_kernel.h"
+#include "walk_fast.h"
 #include "slow_kernel.h"
 #include "util_kernels.h"
 
@@ -475,23 +476,39 @@ static search_fn pick_s(uint32_t ef) {
     return search_kernel<DT, DIM, 4>;
 }
 
-// Granne::reorder's trail walks (max_search 1): the S = 1 walker in trail mode
-static search_fn pick_trail_kernel(int dtype, uint32_t dim) {
-    if (dtype == GRANNE_HIP_I8) return search_kernel<DT_I8, 0, 1, true>;
-    switch (dim) {
-    case 100: return search_kernel<DT_F32, 100, 1, true>;
-    case 200: return search_kernel<DT_F32, 200, 1, true>;
-    default: return search_kernel<DT_F32, 0, 1, true>;
-    }
+// the general walker (search_kernel.h): run-time dims, any row width
+static search_fn pick_trail_kernel(int dtype) { // Granne::reorder's trail walks (max_search 1)
+    return dtype == GRANNE_HIP_I8 ? (search_fn)search_kernel<DT_I8, 0, 1, true> : (search_fn)search_kernel<DT_F32, 0, 1, true>;
+}
+static search_fn pick_kernel(int dtype, uint32_t ef) {
+    return dtype == GRANNE_HIP_I8 ? pick_s<DT_I8, 0>(ef) : pick_s<DT_F32, 0>(ef);
 }
 
-static search_fn pick_kernel(int dtype, uint32_t dim, uint32_t ef) {
-    if (dtype == GRANNE_HIP_I8) return pick_s<DT_I8, 0>(ef);
-    switch (dim) {
-    case 100: return pick_s<DT_F32, 100>(ef);
-    case 200: return pick_s<DT_F32, 200>(ef);
-    default: return pick_s<DT_F32, 0>(ef);
+// the walker of the common shapes (walk_fast.h): every layer 32 ids wide on the device, ids within 31
+// bits, f32 rows of an instantiated dim or int8 rows of 128 bytes. The list holds 64*S keys and must
+// hold max_search of them; a few spare places keep distance ties at the boundary from handing walks
+// over (none at the top size).
+constexpr uint32_t FAST_MAX_SEARCH = 1024;
+static uint32_t fast_list_slots(uint32_t ef) { return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : 16u; }
+template <int DT, int DIM>
+static search_fn pick_fast_s(uint32_t S, bool trail) {
+    if (trail) return fast_kernel<DT, DIM, 1, true>;
+    switch (S) {
+    case 1: return fast_kernel<DT, DIM, 1>;
+    case 2: return fast_kernel<DT, DIM, 2>;
+    case 4: return fast_kernel<DT, DIM, 4>;
+    case 8: return fast_kernel<DT, DIM, 8>;
+    default: return fast_kernel<DT, DIM, 16>;
     }
+}
+static bool fast_shape(const SearchTarget* ix) {
+    if (ix->max_dev_width != 32 || ix->n_elements > WALK_MAX_ELEMENTS) return false;
+    if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128;
+    return (ix->dim == 100 || ix->dim == 200) && ix->row_bytes == ix->dim * 4;
+}
+static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail) {
+    if (ix->dtype == GRANNE_HIP_I8) return pick_fast_s<DT_I8, 0>(S, trail);
+    return ix->dim == 100 ? pick_fast_s<DT_F32, 100>(S, trail) : pick_fast_s<DT_F32, 200>(S, trail);
 }
 
 struct LaunchPlan {
@@ -501,7 +518,7 @@ struct LaunchPlan {
 // LDS plan. The visited table dominates; the f32 stage gets what keeps four walkers per CU
 // (160 KiB / 4) when that leaves it at least 16 rows, else up to 32 rows within 64 KiB, else
 // whatever fits in the CU's 160 KiB. GRANNE_HIP_MAXC overrides the stage rows (experiments).
-static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq) {
+static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, uint32_t fastS /* 0: general walker */) {
     LaunchPlan P;
     uint32_t want = ix->opt_visited_slots ? (uint32_t)ix->opt_visited_slots : next_pow2(ef * 64u);
     if (!ix->opt_visited_slots) {
@@ -517,7 +534,15 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq) 
     }
     P.visited_slots = want;
     P.upper_slots = want < 1024 ? want : 1024;
-    const bool reg_spec = ix->dtype == GRANNE_HIP_F32 && (ix->dim == 100 || ix->dim == 200); // templated f32 kernels
+    if (fastS) { // walk_fast.h: [query][64*S keys][visited front table]
+        P.maxc = 0;
+        P.lrow_bytes = 16;
+        P.stage_bytes = 0;
+        P.adjspec_bytes = 0;
+        P.lds_bytes = fast_lds_bytes(ix->row_bytes, fastS, P.visited_slots);
+        return P;
+    }
+    const bool reg_spec = false; // (the compile-time-dim f32 kernels moved to walk_fast.h)
     P.adjspec_bytes = (reg_spec || ix->dtype == GRANNE_HIP_I8) ? 0u : LDS_ADJSPEC_BYTES; // Walker::REGSPEC
     uint32_t fixed = lds_query_bytes(ix->row_bytes) + LDS_FIXED_BYTES + P.adjspec_bytes;
     if (ix->dtype == GRANNE_HIP_F32) {
@@ -565,15 +590,18 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
 
-    const bool all_slow = ix->opt_force_slow || ef > 256;
-    LaunchPlan plan = plan_launch(ix, ef > 256 ? 256 : ef, nq);
+    const bool fast = fast_shape(ix) && ef <= FAST_MAX_SEARCH;
+    const uint32_t fastS = fast ? fast_list_slots(ef) : 0u;
+    const uint32_t ef_walk = fast ? ef : (ef > 256 ? 256 : ef); // what the register/LDS walker is sized for
+    const bool all_slow = ix->opt_force_slow || (!fast && ef > 256);
+    LaunchPlan plan = plan_launch(ix, ef_walk, nq, fastS);
     if (plan.lds_bytes > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
 
     // visited-set overflow pool: one table per walker that can be resident at once (bounded by
     // LDS: 160 KiB per CU, and by 32 waves per CU), at most one per query
     uint32_t ovf_slots = 0, ovf_regions = 0;
     if (!all_slow && ix->opt_overflow_slots != 1) {
-        ovf_slots = ix->opt_overflow_slots ? next_pow2((uint32_t)ix->opt_overflow_slots) : next_pow2((ef > 256 ? 256 : ef) * 64u);
+        ovf_slots = ix->opt_overflow_slots ? next_pow2((uint32_t)ix->opt_overflow_slots) : next_pow2(ef_walk * 64u);
         if (!ix->opt_overflow_slots && ovf_slots < 4096) ovf_slots = 4096;
         if (ovf_slots < 512) ovf_slots = 512;
         if (ovf_slots > (1u << 20)) ovf_slots = 1u << 20;
@@ -645,7 +673,8 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.trail_out = d_trail;
     p.trail_layers = trail_layers;
 
-    search_fn fn = d_trail ? pick_trail_kernel(ix->dtype, ix->dim) : pick_kernel(ix->dtype, ix->dim, ef > 256 ? 256 : ef);
+    search_fn fn = fast ? pick_fast_kernel(ix, fastS, d_trail != nullptr)
+                        : (d_trail ? pick_trail_kernel(ix->dtype) : pick_kernel(ix->dtype, ef_walk));
     if (const char* e = getenv("GRANNE_HIP_LDS_PAD")) plan.lds_bytes += (uint32_t)atoi(e); // occupancy experiments
     if (plan.lds_bytes > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
     if (plan.lds_bytes > 32u * 1024u)

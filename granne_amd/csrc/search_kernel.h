@@ -1,22 +1,19 @@
-// search_kernel.h -- Granne::search as one gfx950 kernel: one wavefront walks one query through
-// every layer (find_entrypoint + search_for_neighbors, /root/reference/src/index/mod.rs:963-1037).
+// search_kernel.h -- Granne::search as one gfx950 kernel, the GENERAL shapes: one wavefront walks one
+// query through every layer (find_entrypoint + search_for_neighbors,
+// /root/reference/src/index/mod.rs:963-1037). The common shapes (every layer 32 ids wide; f32 rows
+// of a compile-time dim or int8 rows of 128 bytes) are served by walk_fast.h; this kernel takes the
+// rest: f32 with a run-time dim, other int8 row sizes, layers wider than 32 ids, ids beyond 31 bits.
 //
-// Per expansion (one iteration of the reference's `while let Some(..) = pq.pop()` loop), on the
-// fast path (layers of device width 32; f32 with a compile-time dim, or i8 with 128-byte rows --
-// fast_rows below):
+// Per expansion (one iteration of the reference's `while let Some(..) = pq.pop()` loop):
 //   1. the expanded node's adjacency row is already in registers when the node was the queue head
 //      one expansion earlier (prefetch), else it is read with one coalesced load, one id per lane;
-//   2. ALL loads of the expansion are issued from the neighbor ids alone, eight lanes per element
-//      row and 16 bytes per lane so that every requested 128-byte line is used in full, before the
-//      exact visited set (LDS front table + global overflow, wave_prims.h) is consulted under them;
-//   3. f32: the lane that loaded bytes 16*sub.. of a 128-byte block owns accumulators 4*sub..4*sub+3
-//      of the reference's 32 (dist.h explains why that association must be kept); the ordered sum
-//      runs down the eight lanes with row_shr DPP, the tail is folded by sequential fmas.
-//      i8: v_dot4_i32_i8 partial sums, xor-shuffle reduce, the reference's float tail;
+//   2. the exact visited set (LDS front table + global overflow, wave_prims.h) filters the ids; the
+//      fresh ones are compacted through LDS;
+//   3. f32: their rows are staged in LDS, one lane per candidate evaluates the reference's 32
+//      fused accumulators (dist.h explains why that association must be kept); i8: v_dot4_i32_i8
+//      partial sums over a power-of-two group of lanes per row, xor-shuffle reduce, float tail;
 //   4. candidate keys (dist,id) that pass the reference's filter enter the register-resident
-//      sorted queue (ballot rank + DPP shift, or one bulk merge through LDS).
-// Other shapes (runtime-dim f32, other i8 row sizes, layers wider than 32) take the general path:
-// candidates compacted through LDS, rows staged in LDS, one lane per candidate (distances()).
+//      sorted queue (ballot rank + DPP shift).
 // The walk is a strict restatement of the reference's control flow, so results are identical;
 // only memory (never logic) is parallel. One bounded structure can change results: the candidate
 // queue (64*S entries; dropping its largest entry is provably safe unless that entry ties with
@@ -89,11 +86,6 @@ constexpr uint32_t LDS_ADJSPEC_BYTES = 4096 + 16;        // 32x32 u32 + a 16-byt
 constexpr uint32_t COLSTAGE_ROW_BYTES = 144;             // column-streamed stage: 32 floats + pad = 9 x 16 B (odd)
 constexpr uint32_t COLSTAGE_BYTES = 32 * COLSTAGE_ROW_BYTES;
 
-#ifndef GRANNE_HIP_PQ_MERGE_MIN
-#define GRANNE_HIP_PQ_MERGE_MIN 4
-#endif
-constexpr uint32_t PQ_MERGE_MIN = GRANNE_HIP_PQ_MERGE_MIN; // candidates per expansion from which the bulk merge pays
-
 template <int DT, int DIM, int S>
 struct Walker {
     // ---- immutable per-launch state
@@ -108,12 +100,6 @@ struct Walker {
     int dy; // i8: sum of squares of the query
     // paths whose speculative adjacency rows stay in registers (everything but runtime-dim f32)
     static constexpr bool REGSPEC = (DT == DT_I8) || (DIM > 0);
-    static constexpr bool FASTF32 = (DT == DT_F32) && (DIM > 0);
-    static constexpr int NB = FASTF32 ? DIM / 32 : 0;          // full 32-float blocks of a row
-    static constexpr int TAILU = FASTF32 ? (DIM % 32) / 4 : 0; // 16-byte units of the tail
-    static_assert(TAILU <= 2, "fast f32 path: tail of at most 8 floats (dims 100, 200, multiples of 32)");
-    float qpc[FASTF32 ? (NB + (TAILU ? 1 : 0)) * 4 : 1]; // fast path: this lane's pieces of the query
-    uint4 qpiece;                                  // i8, 128-byte rows: this lane's 16 bytes of the query
     uint4 sa0, sa1, sa2, sa3; // REGSPEC: speculative adjacency rows stay in registers
     // ---- per-walk state
     VisitedSet vis;
@@ -121,7 +107,6 @@ struct Walker {
     SortedList<S> pq;  // `pq`, bounded at 64*S entries
     WalkStats st;
     bool bail; // visited table full or unsafe queue drop: hand over to the slow path
-    bool spec_on, spec_was_on; // see SearchParams::spec_ticks (wave-uniform)
 
     __device__ __forceinline__ Walker(const SearchParams& p_, uint8_t* smem) : p(p_) {
         lane = threadIdx.x;
@@ -136,8 +121,6 @@ struct Walker {
         dy = 0;
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
-        spec_on = p.spec_ticks != 0;
-        spec_was_on = false;
         vis.init_walker();
     }
 
@@ -147,19 +130,6 @@ struct Walker {
             const float* q = reinterpret_cast<const float*>(p.queries + (int64_t)qi * p.q_stride);
             float* l = reinterpret_cast<float*>(lds_q);
             for (uint32_t i = lane; i < p.row_bytes / 4; i += 64) l[i] = (i < p.dim) ? q[i] : 0.0f;
-            if constexpr (DT == DT_F32 && DIM > 0) {
-                // fast path pieces: block b -> q[32b + 4*(lane&7) ..+3]; tail -> q[32NB + 4*part ..+3]
-                const uint32_t sub = lane & 7u;
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) qpc[b * 4 + j] = q[b * 32 + sub * 4 + j];
-                if constexpr (TAILU > 0) {
-                    const uint32_t part = (TAILU == 2) ? (lane & 1u) : 0u;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) qpc[NB * 4 + j] = q[NB * 32 + part * 4 + j];
-                }
-            }
         } else {
             const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
             int8_t* l = reinterpret_cast<int8_t*>(lds_q);
@@ -173,7 +143,6 @@ struct Walker {
             dy = part; // exact i32, identical in every lane
         }
         __syncthreads();
-        if constexpr (DT == DT_I8) qpiece = *reinterpret_cast<const uint4*>(lds_q + (size_t)(lane & 7u) * 16u);
     }
 
     // distances of candidates cand[0..m) (m <= 64) to the query; lane c < m returns d(c)
@@ -325,246 +294,6 @@ struct Walker {
         as4[192u + lane < au ? 192u + lane : dump] = a3;
     }
 
-    // ---- the fast expansion (layers of device width 32; f32 with a known dim, or i8 with 128-B rows) --
-    // Lane layout: lane = 8*rip + sub. Row set i (0..3) is neighbor slot 8i + rip, and the eight lanes
-    // of a group hold that row 16 bytes each (per 128-byte block). Nothing is transposed through LDS:
-    //  f32: lane (row, sub) owns accumulators 4*sub..4*sub+3 of the reference's 32 (src/math.rs:17-26):
-    //       acc[j] = fma(x[64+j], q[64+j], fma(x[32+j], q[32+j], fma(x[j], q[j], 0))) -- chunk order kept;
-    //       the ordered sum ((0 + acc[0]) + acc[1]) + ... + acc[31] (math.rs:27-30) walks the group's
-    //       lanes with DPP row_shr:1, four adds per lane; the tail FMAs (math.rs:32-39) follow in order.
-    //  i8:  exact integer partial sums per lane (v_dot4_i32_i8), xor-shuffle reduction.
-    // All loads (rows of every valid neighbor, their adjacency rows speculatively) are issued from
-    // the neighbor ids alone, BEFORE the visited set is consulted, so the LDS compare-and-swap
-    // latency hides under the HBM round trip; distances of already visited neighbors are simply
-    // discarded (4 % of the rows on the benchmark graph).
-    __device__ __forceinline__ static float row_shr1(float v) {
-#if GRANNE_HIP_USE_DPP
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
-#else
-        return __shfl_up(v, 1, 64);
-#endif
-    }
-
-    // returns d(neighbor slot `lane`) for lane < nvalid; sets `fresh`
-    __device__ __forceinline__ float fast_rows(uint32_t nb, uint32_t nvalid, gptr_u32 adj, bool& fresh) {
-        const uint32_t sub = lane & 7u, rip = lane >> 3;
-        const uint32_t last = nvalid - 1;
-        const uint32_t id0 = (uint32_t)__shfl((int)nb, (int)min(rip, last), 64);
-        const uint32_t id1 = (uint32_t)__shfl((int)nb, (int)min(8u + rip, last), 64);
-        const uint32_t id2 = (uint32_t)__shfl((int)nb, (int)min(16u + rip, last), 64);
-        const uint32_t id3 = (uint32_t)__shfl((int)nb, (int)min(24u + rip, last), 64);
-        float d = 0.0f;
-        const uint64_t t_issue = __builtin_amdgcn_s_memrealtime();
-        spec_was_on = spec_on;
-        if constexpr (FASTF32) {
-            const uint8_t* e0 = p.elements + (size_t)id0 * p.row_bytes + sub * 16u;
-            const uint8_t* e1 = p.elements + (size_t)id1 * p.row_bytes + sub * 16u;
-            const uint8_t* e2 = p.elements + (size_t)id2 * p.row_bytes + sub * 16u;
-            const uint8_t* e3 = p.elements + (size_t)id3 * p.row_bytes + sub * 16u;
-#define GRANNE_FB_LOAD(B)                                                                              \
-    float4 v##B##_0 = make_float4(0, 0, 0, 0), v##B##_1 = v##B##_0, v##B##_2 = v##B##_0, v##B##_3 = v##B##_0; \
-    if constexpr ((B) < NB) {                                                                          \
-        v##B##_0 = *reinterpret_cast<const float4*>(e0 + (B) * 128);                                   \
-        v##B##_1 = *reinterpret_cast<const float4*>(e1 + (B) * 128);                                   \
-        v##B##_2 = *reinterpret_cast<const float4*>(e2 + (B) * 128);                                   \
-        v##B##_3 = *reinterpret_cast<const float4*>(e3 + (B) * 128);                                   \
-    }
-#define GRANNE_FOR_FB(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-            static_assert(NB <= 8, "extend GRANNE_FOR_FB");
-            GRANNE_FOR_FB(GRANNE_FB_LOAD)
-            // tail: TAILU == 1: lane T holds the tail of row T; TAILU == 2: lane L holds part L&1 of row L>>1
-            float4 vt = make_float4(0, 0, 0, 0);
-            if constexpr (TAILU > 0) {
-                const uint32_t trow = (TAILU == 2) ? (lane >> 1) : lane;
-                const uint32_t tpart = (TAILU == 2) ? (lane & 1u) : 0u;
-                const uint32_t idt = (uint32_t)__shfl((int)nb, (int)min(trow, last), 64);
-                vt = *reinterpret_cast<const float4*>(p.elements + (size_t)idt * p.row_bytes + NB * 128 + tpart * 16u);
-            }
-            uint4 a0 = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY), a1 = a0, a2 = a0, a3 = a0;
-            if (spec_on) {
-                a0 = load_global_u4(adj + (size_t)id0 * 32u + sub * 4u);
-                a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
-                a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
-                a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
-            }
-            fresh = vis.insert(nb, lane < nvalid, p.ovf); // visited.insert(neighbor_idx), mod.rs:1026 -- under the loads
-            {   // pin: everything above is issued (and the set updated) before anything below waits
-                float chk = vt.x;
-#define GRANNE_FB_CHK(B) chk += v##B##_0.x + v##B##_1.x + v##B##_2.x + v##B##_3.x;
-                GRANNE_FOR_FB(GRANNE_FB_CHK)
-#undef GRANNE_FB_CHK
-                asm volatile("" ::"v"(chk) : "memory");
-            }
-            sa0 = a0; sa1 = a1; sa2 = a2; sa3 = a3;
-            // this lane's four accumulators of each of its four rows
-#define GRANNE_FB_ACC(I)                                                                               \
-    float c##I##_0 = 0.0f, c##I##_1 = 0.0f, c##I##_2 = 0.0f, c##I##_3 = 0.0f;
-            GRANNE_FB_ACC(0) GRANNE_FB_ACC(1) GRANNE_FB_ACC(2) GRANNE_FB_ACC(3)
-#undef GRANNE_FB_ACC
-#define GRANNE_FB_FMA(B)                                                                               \
-    if constexpr ((B) < NB) {                                                                          \
-        c0_0 = __builtin_fmaf(v##B##_0.x, qpc[(B) * 4 + 0], c0_0); c0_1 = __builtin_fmaf(v##B##_0.y, qpc[(B) * 4 + 1], c0_1); \
-        c0_2 = __builtin_fmaf(v##B##_0.z, qpc[(B) * 4 + 2], c0_2); c0_3 = __builtin_fmaf(v##B##_0.w, qpc[(B) * 4 + 3], c0_3); \
-        c1_0 = __builtin_fmaf(v##B##_1.x, qpc[(B) * 4 + 0], c1_0); c1_1 = __builtin_fmaf(v##B##_1.y, qpc[(B) * 4 + 1], c1_1); \
-        c1_2 = __builtin_fmaf(v##B##_1.z, qpc[(B) * 4 + 2], c1_2); c1_3 = __builtin_fmaf(v##B##_1.w, qpc[(B) * 4 + 3], c1_3); \
-        c2_0 = __builtin_fmaf(v##B##_2.x, qpc[(B) * 4 + 0], c2_0); c2_1 = __builtin_fmaf(v##B##_2.y, qpc[(B) * 4 + 1], c2_1); \
-        c2_2 = __builtin_fmaf(v##B##_2.z, qpc[(B) * 4 + 2], c2_2); c2_3 = __builtin_fmaf(v##B##_2.w, qpc[(B) * 4 + 3], c2_3); \
-        c3_0 = __builtin_fmaf(v##B##_3.x, qpc[(B) * 4 + 0], c3_0); c3_1 = __builtin_fmaf(v##B##_3.y, qpc[(B) * 4 + 1], c3_1); \
-        c3_2 = __builtin_fmaf(v##B##_3.z, qpc[(B) * 4 + 2], c3_2); c3_3 = __builtin_fmaf(v##B##_3.w, qpc[(B) * 4 + 3], c3_3); \
-    }
-            GRANNE_FOR_FB(GRANNE_FB_FMA)
-#undef GRANNE_FB_FMA
-            {   // the gather has landed: how long did it take? (throttles the speculative adjacency fetch)
-                asm volatile("" ::"v"(c0_0), "v"(c1_1), "v"(c2_2), "v"(c3_3));
-                const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
-                spec_on = (uint32_t)(t_done - t_issue) < p.spec_ticks;
-            }
-#undef GRANNE_FB_LOAD
-#undef GRANNE_FOR_FB
-            // ordered sum over the 32 accumulators of a row: at step ps the lane with sub == ps adds its
-            // four accumulators onto what lane sub-1 produced at step ps-1. No predication is needed:
-            // every lane recomputes every step, a DPP read at step ps sees the neighbor's value of step
-            // ps-1 (registers are read before they are rewritten), so by induction lane s holds the
-            // correct prefix sum right after step s -- which is exactly when lane s+1 reads it -- and
-            // lane 7's value after the last step is the row's sum. (Lanes compute garbage before and
-            // after "their" step; nobody reads it.)
-            float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
-#pragma unroll
-            for (uint32_t ps = 0; ps < 8; ++ps) {
-                float t0 = (ps == 0) ? 0.0f : row_shr1(r0), t1 = (ps == 0) ? 0.0f : row_shr1(r1),
-                      t2 = (ps == 0) ? 0.0f : row_shr1(r2), t3 = (ps == 0) ? 0.0f : row_shr1(r3);
-                t0 = t0 + c0_0; t0 = t0 + c0_1; t0 = t0 + c0_2; t0 = t0 + c0_3;
-                t1 = t1 + c1_0; t1 = t1 + c1_1; t1 = t1 + c1_2; t1 = t1 + c1_3;
-                t2 = t2 + c2_0; t2 = t2 + c2_1; t2 = t2 + c2_2; t2 = t2 + c2_3;
-                t3 = t3 + c3_0; t3 = t3 + c3_1; t3 = t3 + c3_2; t3 = t3 + c3_3;
-                r0 = t0; r1 = t1; r2 = t2; r3 = t3;
-            }
-            // row R's sum sits in lane 8*(R&7)+7 of register r[R>>3]; bring it to the lane that holds
-            // the row's tail (or to lane R when there is no tail), then fold the tail in order
-            const uint32_t trow = (TAILU == 2) ? (lane >> 1) : (lane & 31u);
-            const int src = (int)(((trow & 7u) << 3) + 7u);
-            const float s0 = __shfl(r0, src, 64), s1 = __shfl(r1, src, 64), s2 = __shfl(r2, src, 64), s3 = __shfl(r3, src, 64);
-            const uint32_t set = trow >> 3;
-            float rt = set == 0 ? s0 : set == 1 ? s1 : set == 2 ? s2 : s3;
-            if constexpr (TAILU == 1) {
-                rt = __builtin_fmaf(vt.x, qpc[NB * 4 + 0], rt); rt = __builtin_fmaf(vt.y, qpc[NB * 4 + 1], rt);
-                rt = __builtin_fmaf(vt.z, qpc[NB * 4 + 2], rt); rt = __builtin_fmaf(vt.w, qpc[NB * 4 + 3], rt);
-                d = angular_from_dot(rt); // lane T < 32 = row T
-            } else if constexpr (TAILU == 2) {
-                float u = rt; // part 0 lanes (even): floats 0..3 of the tail
-                u = __builtin_fmaf(vt.x, qpc[NB * 4 + 0], u); u = __builtin_fmaf(vt.y, qpc[NB * 4 + 1], u);
-                u = __builtin_fmaf(vt.z, qpc[NB * 4 + 2], u); u = __builtin_fmaf(vt.w, qpc[NB * 4 + 3], u);
-                float w = row_shr1(u); // part 1 lanes (odd) continue from their even neighbor
-                w = __builtin_fmaf(vt.x, qpc[NB * 4 + 0], w); w = __builtin_fmaf(vt.y, qpc[NB * 4 + 1], w);
-                w = __builtin_fmaf(vt.z, qpc[NB * 4 + 2], w); w = __builtin_fmaf(vt.w, qpc[NB * 4 + 3], w);
-                const float full_r = __shfl(w, (int)((lane & 31u) * 2u + 1u), 64); // row T's result -> lane T
-                d = angular_from_dot(full_r);
-            } else {
-                d = angular_from_dot(rt);
-            }
-        } else {
-            // i8, 128-byte rows
-            const uint4 x0 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id0 * 128u + sub * 16u);
-            const uint4 x1 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id1 * 128u + sub * 16u);
-            const uint4 x2 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id2 * 128u + sub * 16u);
-            const uint4 x3 = *reinterpret_cast<const uint4*>(p.elements + (size_t)id3 * 128u + sub * 16u);
-            uint4 a0 = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY), a1 = a0, a2 = a0, a3 = a0;
-            if (spec_on) {
-                a0 = load_global_u4(adj + (size_t)id0 * 32u + sub * 4u);
-                a1 = load_global_u4(adj + (size_t)id1 * 32u + sub * 4u);
-                a2 = load_global_u4(adj + (size_t)id2 * 32u + sub * 4u);
-                a3 = load_global_u4(adj + (size_t)id3 * 32u + sub * 4u);
-            }
-            fresh = vis.insert(nb, lane < nvalid, p.ovf);
-            {
-                uint32_t chk = x0.x ^ x1.x ^ x2.x ^ x3.x;
-                asm volatile("" ::"v"(chk) : "memory");
-                const uint64_t t_done = __builtin_amdgcn_s_memrealtime();
-                spec_on = (uint32_t)(t_done - t_issue) < p.spec_ticks;
-            }
-            sa0 = a0; sa1 = a1; sa2 = a2; sa3 = a3;
-            const uint4 y = qpiece;
-#define GRANNE_I8_ROW(X, OUT)                                                                          \
-    float OUT;                                                                                         \
-    {                                                                                                  \
-        int r = dot4_i8(X.x, y.x, 0);                                                                  \
-        r = dot4_i8(X.y, y.y, r); r = dot4_i8(X.z, y.z, r); r = dot4_i8(X.w, y.w, r);                  \
-        int dx = dot4_i8(X.x, X.x, 0);                                                                 \
-        dx = dot4_i8(X.y, X.y, dx); dx = dot4_i8(X.z, X.z, dx); dx = dot4_i8(X.w, X.w, dx);            \
-        r += __shfl_xor(r, 4, 64); dx += __shfl_xor(dx, 4, 64);                                        \
-        r += __shfl_xor(r, 2, 64); dx += __shfl_xor(dx, 2, 64);                                        \
-        r += __shfl_xor(r, 1, 64); dx += __shfl_xor(dx, 1, 64);                                        \
-        OUT = angular_int_from_sums(r, dx, dy);                                                        \
-    }
-            GRANNE_I8_ROW(x0, g0) GRANNE_I8_ROW(x1, g1) GRANNE_I8_ROW(x2, g2) GRANNE_I8_ROW(x3, g3)
-#undef GRANNE_I8_ROW
-            const uint32_t trow = lane & 31u;
-            const int src = (int)((trow & 7u) << 3);
-            const float s0 = __shfl(g0, src, 64), s1 = __shfl(g1, src, 64), s2 = __shfl(g2, src, 64), s3 = __shfl(g3, src, 64);
-            const uint32_t set = trow >> 3;
-            d = set == 0 ? s0 : set == 1 ? s1 : set == 2 ? s2 : s3;
-        }
-        return d;
-    }
-
-    // mod.rs:1029-1031 + pq.push for per-lane candidates (lanes with active hold d, id)
-    // pq.push for several candidates at once (S == 1: the queue is one key per lane). Every queue
-    // entry counts the candidates below it, every candidate its rank in the queue plus its rank
-    // among the candidates; the 64 + m keys are scattered to their final places through LDS and
-    // the first 64 read back. Same survivors as m sequential pushes; a real key that falls off is
-    // safe under the argument in pq_push, taken against the final queue.
-    __device__ __forceinline__ void pq_merge(uint64_t pm, uint32_t m, bool pass, uint64_t ck, uint32_t ef) {
-        static_assert(S == 1, "one key per lane");
-        const uint64_t mine = pq.key[0];
-        uint32_t above = 0; // queue lanes: candidates that sort after my key
-        uint32_t mypos = 0; // candidate lanes: final position
-        for (uint64_t it = pm; it; it &= it - 1) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(it);
-            const uint64_t K = readlane64(ck, src);
-            const bool below = mine < K;
-            above += below ? 1u : 0u;
-            const uint32_t pos = (uint32_t)__popcll(wave_ballot(below)) + (uint32_t)__popcll(wave_ballot(pass && ck < K));
-            if (lane == src) mypos = pos;
-        }
-        const uint32_t newpos = lane + (m - above);
-        uint64_t* slot = reinterpret_cast<uint64_t*>(cand); // cand + dout = 64 x 8 bytes, idle on this path
-        if (newpos < 64u) slot[newpos] = mine;
-        if (pass && mypos < 64u) slot[mypos] = ck;
-        const bool lost_q = newpos >= 64u && mine != KEY_INF;
-        const bool lost_c = pass && mypos >= 64u;
-        __syncthreads();
-        pq.key[0] = slot[lane];
-        __syncthreads();
-        if (wave_ballot(lost_q || lost_c)) {
-            const float kth = key_dist(pq.get(ef - 1));
-            if (wave_ballot((lost_q && key_dist(mine) == kth) || (lost_c && key_dist(ck) == kth))) bail = true;
-        }
-    }
-
-    __device__ __forceinline__ void offer_lanes(bool active, float d, uint32_t id, bool full, float worst, uint32_t ef) {
-        uint64_t ck = make_key(d, id);
-        bool pass = active && (!full || d < worst);
-        uint64_t lastk = pq.get(64u * S - 1);
-        if (lastk != KEY_INF) {
-            bool dropnow = pass && ck > lastk;
-            if (wave_ballot(dropnow && d == key_dist(pq.get(ef - 1)))) bail = true;
-            pass = pass && !dropnow;
-        }
-        uint64_t pm = wave_ballot(pass);
-        if constexpr (S == 1) {
-            const uint32_t m = (uint32_t)__popcll(pm);
-            if (m >= PQ_MERGE_MIN) {
-                pq_merge(pm, m, pass, ck, ef);
-                return;
-            }
-        }
-        while (pm) {
-            uint32_t src = (uint32_t)__builtin_ctzll(pm);
-            pm &= pm - 1;
-            pq_push(readlane64(ck, src), ef);
-        }
-    }
-
     // mod.rs:1029-1031 + pq.push for the candidates of one expansion (lane c < m holds d, cid)
     __device__ __forceinline__ void offer_candidates(uint32_t m, float d, uint32_t cid, bool full, float worst,
                                                      uint32_t ef) {
@@ -596,25 +325,13 @@ struct Walker {
         uint32_t n_popped = 0;
 
         const bool narrow = p.spec && L.width == 32 && (DT == DT_I8 || DIM > 0 || p.maxc >= 32);
-        // the LDS-free fast expansion: f32 with a compile-time dim, or i8 with 128-byte rows
-        const bool fastp = narrow && (FASTF32 || (DT == DT_I8 && p.row_bytes == 128));
         const gptr_u32 adjg = (gptr_u32)L.adj;
         // speculative adjacency state (narrow layers)
         uint32_t specA_id = ID_EMPTY, specA_nb = ID_EMPTY; // row of the queue head, one id per lane
         uint32_t specB_m = 0, specB_cid = ID_EMPTY;        // last expansion's candidates (rows in sa* / adjspec)
 
         // distance to the entry point (mod.rs:1012-1016)
-        if (fastp) {
-            bool fresh0;
-            const uint32_t nb0 = (lane == 0) ? entrypoint : ID_EMPTY;
-            float d0 = fast_rows(nb0, 1, adjg, fresh0); // also fetches the entry point's adjacency row
-            vis.count = 1;
-            st.n_dist += 1;
-            specB_m = spec_was_on ? 1u : 0u;
-            specB_cid = nb0;
-            uint64_t k0 = readlane64(make_key(d0, entrypoint), 0);
-            pq.insert_at(0, k0, lane);
-        } else {
+        {
             if (lane == 0) cand[0] = entrypoint;
             vis.insert(entrypoint, lane == 0, p.ovf);
             vis.count = 1;
@@ -681,18 +398,7 @@ struct Walker {
                 uint64_t unused = wave_ballot(nb == ID_EMPTY);
                 uint32_t nvalid = unused ? (uint32_t)__builtin_ctzll(unused) : 64u;
                 st.n_adj += nvalid;
-                if (fastp) {
-                    if (nvalid) {
-                        bool fresh;
-                        float d = fast_rows(nb, nvalid, adjg, fresh); // mod.rs:1026-1027
-                        const uint32_t m = (uint32_t)__popcll(wave_ballot(fresh));
-                        vis.added(m);
-                        st.n_dist += m;
-                        specB_m = spec_was_on ? nvalid : 0u;
-                        specB_cid = (lane < nvalid) ? nb : ID_EMPTY;
-                        offer_lanes(fresh, d, nb, full, worst, ef);
-                    }
-                } else {
+                {
                     bool fresh = vis.insert(nb, lane < nvalid, p.ovf); // visited.insert(neighbor_idx), mod.rs:1026
                     uint64_t fm = wave_ballot(fresh);
                     uint32_t m = (uint32_t)__popcll(fm);

@@ -1,0 +1,508 @@
+// walk_fast.h -- the walker of the common shapes (every layer 32 ids wide on the device; f32 rows
+// of a compile-time dim, or int8 rows of 128 bytes): one wavefront per query, all layers in one
+// launch (Granne::search -> search_internal -> find_entrypoint -> search_for_neighbors,
+// /root/reference/src/index/mod.rs:140-150, 963-1037).
+//
+// Lane layout: lane = 2*R + h. R (0..31) is a neighbor slot of the expanded node, the two lanes of a
+// pair hold that neighbor's element row, h selecting the 64-byte half of every 128-byte block.
+//  f32: lane (R,h) owns accumulators 16h..16h+15 of the reference's 32 (src/math.rs:17-26) and
+//       applies the 32-wide chunks in order with explicit fmas; the ordered sum
+//       ((0 + acc[0]) + acc[1]) + ... + acc[31] (math.rs:27-30) is 16 adds in the even lane, one
+//       DPP row_shr:1 hand-over, 16 adds in the odd lane; the tail fmas (math.rs:32-39) follow in
+//       the odd lane. 33 VALU ops for the sum of 32 rows, no LDS, no shuffle network.
+//  i8:  v_dot4_i32_i8 partial sums of r and dx per half row, one quad_perm DPP exchange each, then
+//       the reference's float tail (angular_int.rs:52-58) once per lane; sqrt(dy) is the query's
+//       and is taken once per query (same operation on the same input: same bits).
+// All row loads of an expansion are issued from the neighbor ids alone before the exact visited
+// set (LDS front table + global overflow, wave_prims.h) is consulted under them.
+//
+// The reference's two heaps (`res`: the max_search best popped nodes, `pq`: the unbounded
+// candidate queue, mod.rs:1006-1007) are ONE ascending list of 64*S keys in registers, each key
+// (dist bits | id | expanded flag):
+//   next node to expand = the first entry whose flag is clear (= pq.pop(): the smallest queued key);
+//   break  <=>  #{entries with dist < d_x} >= max_search. Every such entry precedes x and is
+//               therefore expanded, so this is `res.len() == max_search && d_x > res.peek().dist`
+//               (mod.rs:1019): the max_search-th smallest popped distance is strictly smaller;
+//   res.push(x) = set the flag: `res` IS the first max_search flagged entries of the list;
+//   the enqueue filter `res.len() < max_search || d < res.peek().dist` (mod.rs:1029) reads the
+//               max_search-th flagged entry when the list holds that many;
+//   a candidate with max_search entries strictly closer can never be expanded (when it would reach the
+//               head, max_search closer nodes have been popped and the loop breaks), so it is not
+//               inserted; an entry pushed off the end of the list is dead for the same reason unless
+//               its distance TIES with entry max_search-1 -- then the walk is abandoned and the
+//               query handed, untouched, to the exact global-memory walker (slow_kernel.h).
+// tools/model_unified.py replays this list against the two heaps on tie-heavy random graphs.
+#pragma once
+
+#include "search_kernel.h"
+
+namespace granne_hip {
+
+// ---- list keys: dist bits (32) | id (31) | expanded (1) ----------------------------------------
+__device__ __forceinline__ uint64_t wkey(float d, uint32_t id) {
+    return ((uint64_t)__float_as_uint(d) << 32) | ((uint64_t)id << 1);
+}
+__device__ __forceinline__ uint32_t wkey_hi(uint64_t k) { return (uint32_t)(k >> 32); }
+__device__ __forceinline__ uint32_t wkey_id(uint64_t k) { return ((uint32_t)k) >> 1; }
+__device__ __forceinline__ float wkey_dist(uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); }
+constexpr uint32_t WPOS_NONE = 0xFFFFFFFFu;
+constexpr uint64_t WALK_MAX_ELEMENTS = 1ull << 31; // ids must fit 31 bits
+
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) { // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// value of the other lane of the pair (lane ^ 1)
+__device__ __forceinline__ int pair_swap(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+}
+// lane i receives lane i-1's value within its row of 16 (odd lanes: their even partner)
+__device__ __forceinline__ float from_lower_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+}
+
+template <int S>
+struct WalkList : SortedList<S> {
+    using SortedList<S>::key;
+    static constexpr uint32_t CAP = 64u * S;
+
+    // position of the first entry whose expanded flag is clear (KEY_INF has it set)
+    __device__ __forceinline__ bool first_unexpanded(uint32_t& pos) const {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint64_t um = wave_ballot((((uint32_t)key[s]) & 1u) == 0u);
+            if (um) {
+                pos = (uint32_t)s * 64u + (uint32_t)__builtin_ctzll(um);
+                return true;
+            }
+        }
+        return false;
+    }
+    // number of entries whose distance is strictly smaller than dbits (wave-uniform)
+    __device__ __forceinline__ uint32_t count_closer(uint32_t dbits) const {
+        uint32_t c = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) c += (uint32_t)__popcll(wave_ballot(wkey_hi(key[s]) < dbits));
+        return c;
+    }
+    __device__ __forceinline__ void mark_expanded(uint32_t pos, uint32_t lane) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if ((uint32_t)s * 64u + lane == pos) key[s] |= 1ull;
+    }
+    // position of the n-th (n >= 1) expanded real entry, WPOS_NONE when there are fewer
+    __device__ __forceinline__ uint32_t nth_expanded(uint32_t n) const {
+        uint32_t before = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool f = (((uint32_t)key[s]) & 1u) && wkey_hi(key[s]) != 0xFFFFFFFFu;
+            const uint64_t em = wave_ballot(f);
+            const uint32_t c = (uint32_t)__popcll(em);
+            if (before + c >= n) {
+                const uint64_t hit = wave_ballot(f && mbcnt64(em) == n - 1u - before);
+                return (uint32_t)s * 64u + (uint32_t)__builtin_ctzll(hit);
+            }
+            before += c;
+        }
+        return WPOS_NONE;
+    }
+};
+
+template <int DT, int DIM, int S>
+struct FastWalker {
+    static constexpr bool F32 = (DT == DT_F32);
+    static constexpr int NB = F32 ? DIM / 32 : 0;        // full 32-float chunks of a row
+    static constexpr int TU = F32 ? (DIM % 32) / 4 : 0;  // 16-byte units of the tail
+    static constexpr bool QREG = F32 && (NB * 16 + TU * 4 <= 64); // this lane's query pieces live in VGPRs
+    static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u;
+    static constexpr uint32_t CAP = 64u * S;
+    static_assert(!F32 || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
+
+    const SearchParams& p;
+    uint32_t lane, h, R;
+    uint8_t* lds_q;       // the query (f32 without QREG: read per expansion; i8: staging)
+    uint64_t* mslot;      // CAP keys: scatter space of the bulk merge
+    uint32_t* vis_tab;
+    float qh[QREG ? NB * 16 : 1];
+    float qt[(QREG && TU) ? TU * 4 : 1];
+    uint4 qi8[F32 ? 1 : 4]; // i8: bytes 64h..64h+63 of the query
+    float sy;               // i8: sqrt(sum of squares of the query) as f32
+    VisitedSet vis;
+    WalkList<S> L;
+    WalkStats st;
+    bool bail;
+
+    __device__ __forceinline__ FastWalker(const SearchParams& p_, uint8_t* smem) : p(p_) {
+        lane = threadIdx.x;
+        h = lane & 1u;
+        R = lane >> 1;
+        const uint32_t qb = lds_query_bytes(p.row_bytes);
+        lds_q = smem;
+        mslot = reinterpret_cast<uint64_t*>(smem + qb);
+        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + CAP * 8u);
+        st.n_dist = st.n_expand = st.n_adj = 0;
+        bail = false;
+        sy = 0.0f;
+        vis.init_walker();
+    }
+
+    __device__ __forceinline__ void load_query(uint32_t qi) {
+        if constexpr (F32) {
+            const float* q = reinterpret_cast<const float*>(p.queries + (int64_t)qi * p.q_stride);
+            if constexpr (QREG) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) qh[b * 16 + j] = q[b * 32 + h * 16 + j];
+#pragma unroll
+                for (int j = 0; j < TU * 4; ++j) qt[j] = q[NB * 32 + j];
+            } else {
+                float* l = reinterpret_cast<float*>(lds_q);
+                for (uint32_t i = lane; i < (uint32_t)DIM; i += 64) l[i] = q[i];
+                __syncthreads();
+            }
+        } else {
+            const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
+            int8_t* l = reinterpret_cast<int8_t*>(lds_q);
+            int part = 0;
+            for (uint32_t i = lane; i < 128u; i += 64) {
+                const int v = (i < p.dim) ? (int)q[i] : 0;
+                l[i] = (int8_t)v;
+                part += v * v;
+            }
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            sy = __builtin_sqrtf((float)part); // sqrt(dy), angular_int.rs:53
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) qi8[k] = *reinterpret_cast<const uint4*>(lds_q + h * 64u + k * 16u);
+        }
+    }
+
+    // Distances of the (up to 32) rows idl to the query; lanes of a pair pass the same idl. The
+    // visited set is updated under the loads: `fresh` is valid in EVEN lanes (ins_active), the
+    // returned distance in ODD lanes.
+    __device__ __forceinline__ float gather(uint32_t idl, uint32_t ins_id, bool ins_active, bool& fresh) {
+        float d;
+        if constexpr (F32) {
+            const uint8_t* row = p.elements + (size_t)idl * ROWB;
+            const uint8_t* e = row + h * 64u;
+            float4 v[NB][4];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[b][k] = *reinterpret_cast<const float4*>(e + b * 128 + k * 16);
+            float4 vt[TU ? TU : 1];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) vt[u] = *reinterpret_cast<const float4*>(row + NB * 128 + u * 16);
+            asm volatile("" ::: "memory"); // every load above is issued before the set is touched
+            fresh = vis.insert(ins_id, ins_active, p.ovf); // visited.insert(neighbor_idx), mod.rs:1026
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float q0, q1, q2, q3;
+                    if constexpr (QREG) {
+                        q0 = qh[b * 16 + k * 4 + 0]; q1 = qh[b * 16 + k * 4 + 1];
+                        q2 = qh[b * 16 + k * 4 + 2]; q3 = qh[b * 16 + k * 4 + 3];
+                    } else {
+                        const float4 qq = *reinterpret_cast<const float4*>(lds_q + b * 128 + h * 64u + k * 16);
+                        q0 = qq.x; q1 = qq.y; q2 = qq.z; q3 = qq.w;
+                    }
+                    acc[k * 4 + 0] = __builtin_fmaf(v[b][k].x, q0, acc[k * 4 + 0]);
+                    acc[k * 4 + 1] = __builtin_fmaf(v[b][k].y, q1, acc[k * 4 + 1]);
+                    acc[k * 4 + 2] = __builtin_fmaf(v[b][k].z, q2, acc[k * 4 + 2]);
+                    acc[k * 4 + 3] = __builtin_fmaf(v[b][k].w, q3, acc[k * 4 + 3]);
+                }
+            }
+            // ordered sum: even lane 0.0 + acc[0] + ... + acc[15]; odd lane continues with its 16
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s = s + acc[j];
+            float r = from_lower_f(s);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) r = r + acc[j];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                float q0, q1, q2, q3;
+                if constexpr (QREG) {
+                    q0 = qt[u * 4 + 0]; q1 = qt[u * 4 + 1]; q2 = qt[u * 4 + 2]; q3 = qt[u * 4 + 3];
+                } else {
+                    const float4 qq = *reinterpret_cast<const float4*>(lds_q + NB * 128 + u * 16);
+                    q0 = qq.x; q1 = qq.y; q2 = qq.z; q3 = qq.w;
+                }
+                r = __builtin_fmaf(vt[u].x, q0, r);
+                r = __builtin_fmaf(vt[u].y, q1, r);
+                r = __builtin_fmaf(vt[u].z, q2, r);
+                r = __builtin_fmaf(vt[u].w, q3, r);
+            }
+            d = angular_from_dot(r);
+        } else {
+            const uint8_t* e = p.elements + (size_t)idl * 128u + h * 64u;
+            uint4 x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const uint4*>(e + k * 16);
+            asm volatile("" ::: "memory");
+            fresh = vis.insert(ins_id, ins_active, p.ovf);
+            int r = 0, dx = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r = dot4_i8(x[k].x, qi8[k].x, r); r = dot4_i8(x[k].y, qi8[k].y, r);
+                r = dot4_i8(x[k].z, qi8[k].z, r); r = dot4_i8(x[k].w, qi8[k].w, r);
+                dx = dot4_i8(x[k].x, x[k].x, dx); dx = dot4_i8(x[k].y, x[k].y, dx);
+                dx = dot4_i8(x[k].z, x[k].z, dx); dx = dot4_i8(x[k].w, x[k].w, dx);
+            }
+            r += pair_swap(r);
+            dx += pair_swap(dx);
+            // angular_int.rs:52-58 with sqrt(dy) hoisted
+            float q = (float)r / (__builtin_sqrtf((float)dx) * sy);
+            if (q != q) q = 0.0f;
+            const float t = 1.0f - q;
+            d = (0.0f <= t) ? t : 0.0f;
+        }
+        return d;
+    }
+
+    // the entry that falls off the end of the list: dead unless it ties with entry ef-1
+    __device__ __forceinline__ void check_dropped(uint64_t dropped, uint32_t ef) {
+        if (wkey_hi(dropped) != 0xFFFFFFFFu && wkey_hi(dropped) == wkey_hi(L.get(ef - 1))) bail = true;
+    }
+
+    // insert the candidates of the lanes in pm (bulk): every list entry counts the candidates
+    // below it, every candidate its rank in the list plus its rank among the candidates; the keys
+    // are scattered to their final places through LDS and the first CAP read back.
+    __device__ __forceinline__ void merge(uint64_t pm, uint32_t m, bool pass, uint64_t ck, uint32_t ef) {
+        uint32_t above[S]; // list entries: candidates that sort after my key
+#pragma unroll
+        for (int s = 0; s < S; ++s) above[s] = 0;
+        uint32_t mypos = 0;
+        for (uint64_t it = pm; it; it &= it - 1) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(it);
+            const uint64_t K = readlane64(ck, src);
+            uint32_t pos = (uint32_t)__popcll(wave_ballot(pass && ck < K));
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const bool below = L.key[s] < K;
+                above[s] += below ? 1u : 0u;
+                pos += (uint32_t)__popcll(wave_ballot(below));
+            }
+            if (lane == src) mypos = pos;
+        }
+        uint32_t lostd[S]; // dist bits of a real entry pushed off the end, else 0xFFFFFFFF
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t newpos = (uint32_t)s * 64u + lane + (m - above[s]);
+            const uint64_t mine = L.key[s];
+            if (newpos < CAP) mslot[newpos] = mine;
+            lostd[s] = (newpos >= CAP) ? wkey_hi(mine) : 0xFFFFFFFFu;
+        }
+        if (pass && mypos < CAP) mslot[mypos] = ck;
+        const uint32_t lostc = (pass && mypos >= CAP) ? wkey_hi(ck) : 0xFFFFFFFFu;
+        asm volatile("" ::: "memory"); // one wave: LDS executes its accesses in program order
+#pragma unroll
+        for (int s = 0; s < S; ++s) L.key[s] = mslot[(uint32_t)s * 64u + lane];
+        asm volatile("" ::: "memory");
+        bool any = lostc != 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = 0; s < S; ++s) any = any || lostd[s] != 0xFFFFFFFFu;
+        if (wave_ballot(any)) {
+            const uint32_t kth = wkey_hi(L.get(ef - 1));
+            bool tie = lostc == kth;
+#pragma unroll
+            for (int s = 0; s < S; ++s) tie = tie || lostd[s] == kth;
+            if (wave_ballot(tie && kth != 0xFFFFFFFFu)) bail = true;
+        }
+    }
+
+    // mod.rs:1029-1031 for the candidates of one expansion: `cand` lanes hold (d, id)
+    __device__ __forceinline__ void offer(bool cand, float d, uint32_t id, uint32_t ef) {
+        const uint32_t dbits = __float_as_uint(d);
+        // `res` does not change during an expansion, so neither do the two thresholds
+        const uint32_t w = L.nth_expanded(ef); // res.peek(): the max_search-th popped node
+        bool pass = cand;
+        if (w != WPOS_NONE) pass = pass && dbits < wkey_hi(L.get(w)); // d < worst.dist, mod.rs:1029
+        const uint32_t theta = wkey_hi(L.get(ef - 1));
+        if (theta != 0xFFFFFFFFu) pass = pass && dbits <= theta; // else: max_search entries are strictly closer
+        const uint64_t ck = wkey(d, id);
+        uint64_t pm = wave_ballot(pass);
+        const uint32_t m = (uint32_t)__popcll(pm);
+        if (m == 0) return;
+        if (m >= (S == 1 ? 3u : 2u)) {
+            merge(pm, m, pass, ck, ef);
+            return;
+        }
+        while (pm) {
+            const uint32_t src = (uint32_t)__builtin_ctzll(pm);
+            pm &= pm - 1;
+            const uint64_t K = readlane64(ck, src);
+            const uint32_t r = L.rank(K);
+            uint64_t dropped;
+            if (r >= CAP) {
+                dropped = K;
+            } else {
+                dropped = L.get(CAP - 1);
+                L.insert_at(r, K, lane);
+            }
+            check_dropped(dropped, ef);
+        }
+    }
+
+    // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries
+    __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots) {
+        vis.reset(vis_tab, slots, lane);
+        L.init();
+        __syncthreads();
+        const gptr_u32 adjg = (gptr_u32)Ly.adj;
+
+        {   // distance to the entry point (mod.rs:1012-1016)
+            bool fresh0;
+            const float d0 = gather(entrypoint, entrypoint, lane == 0, fresh0);
+            vis.count = 1;
+            st.n_dist += 1;
+            const uint64_t k0 = readlane64(wkey(d0, entrypoint), 1);
+            L.insert_at(0, k0, lane);
+        }
+        uint32_t pre_id = ID_EMPTY, pre_nb = ID_EMPTY; // adjacency row fetched ahead for the expected next head
+
+        for (;;) {
+            uint32_t pos;
+            if (!L.first_unexpanded(pos)) break;          // pq.pop() on an empty queue, mod.rs:1018
+            const uint64_t x = L.get(pos);
+            if (L.count_closer(wkey_hi(x)) >= ef) break;   // mod.rs:1019-1021
+            L.mark_expanded(pos, lane);                    // res.push((d, idx)), mod.rs:1023
+            st.n_expand += 1;
+
+            // layer.get_neighbors(idx), mod.rs:1025 / 540-552: row prefix until UNUSED, one id per pair
+            const uint32_t xid = wkey_id(x);
+            uint32_t nb;
+            if (pre_id == xid) nb = pre_nb;
+            else nb = adjg[(size_t)xid * 32u + R];
+            const uint64_t unused = wave_ballot(nb == ID_EMPTY);
+            // The row has been waited for; the fetch-ahead below must not be hoisted above that wait
+            // (loads return in order: a younger load in flight would turn the wait into a full drain).
+            asm volatile("" ::"s"(unused) : "memory");
+            {   // fetch ahead the row of the node that is the head now (it stays the head unless a
+                // candidate of this expansion sorts before it); always one load, so that the wait
+                // counts of the gather below are static
+                uint32_t p2;
+                pre_id = L.first_unexpanded(p2) ? wkey_id(L.get(p2)) : xid;
+                pre_nb = adjg[(size_t)pre_id * 32u + R];
+            }
+            const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
+            st.n_adj += nvalid;
+            if (nvalid) {
+                const uint32_t last_id = readlane32(nb, 2u * (nvalid - 1u));
+                const uint32_t idl = (R < nvalid) ? nb : last_id; // lanes beyond the row re-read its last neighbor
+                bool fresh;
+                const float d = gather(idl, nb, h == 0u && R < nvalid, fresh); // mod.rs:1026-1027
+                const uint64_t fm = wave_ballot(fresh);
+                const uint32_t mf = (uint32_t)__popcll(fm);
+                vis.added(mf);
+                st.n_dist += mf;
+                const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
+                offer(cand, d, nb, ef);
+            }
+            if (!vis.make_room(p.ovf, lane)) bail = true;
+            if (bail) return;
+        }
+    }
+};
+
+template <int DT, int DIM, int S, bool TRAIL>
+__device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint32_t qi, uint8_t* smem) {
+    const uint32_t lane = threadIdx.x;
+    if (p.force_slow) {
+        if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+        return;
+    }
+    FastWalker<DT, DIM, S> w(p, smem);
+    w.load_query(qi);
+
+    if constexpr (TRAIL) { // find_entrypoint_trail (reorder.rs:180-208): every walk starts at node 0
+        const uint32_t take = min(min(p.trail_layers, TRAIL_WIDTH), p.n_layers);
+        uint32_t mine = 0;
+        for (uint32_t l = 0; l < take; ++l) {
+            w.search_layer(p.layers[l], 0u, 1u, p.upper_slots);
+            if (w.bail) break;
+            const uint32_t found = wkey_id(w.L.get(0));
+            if (lane == l) mine = found;
+        }
+        w.vis.release(p.ovf, lane);
+        if (w.bail) {
+            if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+        } else if (lane < TRAIL_WIDTH) {
+            p.trail_out[(size_t)qi * TRAIL_WIDTH + lane] = mine;
+        }
+        return;
+    } else {
+        uint32_t entrypoint = 0; // mod.rs:989
+        for (uint32_t l = 0; l < p.n_layers; ++l) {
+            const LayerDev Ly = p.layers[l];
+            const bool bottom = (l + 1 == p.n_layers);
+            w.search_layer(Ly, entrypoint, bottom ? p.ef : 1u, bottom ? p.visited_slots : p.upper_slots);
+            if (w.bail) break;
+            if (!bottom) entrypoint = wkey_id(w.L.get(0)); // res[0].0, mod.rs:993: the smallest popped key
+        }
+        w.vis.release(p.ovf, lane);
+        if (w.bail) { // hand the untouched query to the exact global-memory walker
+            if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+            return;
+        }
+        // res = the first max_search expanded entries; .take(num_neighbors), mod.rs:974-977
+        uint32_t total = 0;
+        uint32_t rank[S];
+        bool flag[S];
+        if (p.n_layers > 0) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                flag[s] = (((uint32_t)w.L.key[s]) & 1u) && wkey_hi(w.L.key[s]) != 0xFFFFFFFFu;
+                const uint64_t em = wave_ballot(flag[s]);
+                rank[s] = total + mbcnt64(em);
+                total += (uint32_t)__popcll(em);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s) { flag[s] = false; rank[s] = 0; }
+        }
+        const uint32_t count = min(min(total, p.ef), p.k);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (flag[s] && rank[s] < count) {
+                p.out_ids[(size_t)qi * p.k + rank[s]] = (uint64_t)wkey_id(w.L.key[s]);
+                p.out_dists[(size_t)qi * p.k + rank[s]] = wkey_dist(w.L.key[s]);
+            }
+        }
+        for (uint32_t e = count + lane; e < p.k; e += 64) {
+            p.out_ids[(size_t)qi * p.k + e] = ~0ull;
+            p.out_dists[(size_t)qi * p.k + e] = __builtin_inff();
+        }
+        if (lane == 0) {
+            p.out_counts[qi] = count;
+            if (p.out_stats) {
+                p.out_stats[(size_t)qi * 3 + 0] = w.st.n_dist;
+                p.out_stats[(size_t)qi * 3 + 1] = w.st.n_expand;
+                p.out_stats[(size_t)qi * 3 + 2] = w.st.n_adj;
+            }
+        }
+    }
+}
+
+// Block b walks query b (one wavefront). LDS: [query][CAP keys of merge space][visited front table].
+// waves per SIMD the register allocator is asked to keep possible (__launch_bounds__'s second
+// argument is per SIMD on AMD): i8 5 (<= 96 VGPRs), f32 3 (<= 168), long lists and long rows 2
+constexpr int fast_waves_per_simd(int DT, int DIM, int S) {
+    return S >= 8 ? 2 : (DT == DT_I8 ? (S <= 2 ? 5 : 4) : ((DIM > 128 && S > 1) ? 2 : 3));
+}
+
+template <int DT, int DIM, int S, bool TRAIL = false>
+__global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S)) void fast_kernel(const SearchParams p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    if (blockIdx.x < p.nq) fast_walk_one<DT, DIM, S, TRAIL>(p, blockIdx.x, smem);
+}
+
+__host__ __device__ inline uint32_t fast_lds_bytes(uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {
+    return lds_query_bytes(row_bytes) + 64u * S * 8u + visited_slots * 4u;
+}
+
+} // namespace granne_hip

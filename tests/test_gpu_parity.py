@@ -293,10 +293,28 @@ def test_slow_path_equals_fast_path(ga, oracle):
         gix.set_option(_lib.OPT_FORCE_SLOW, 1)
         assert_same(oix, gix, q, 50, 10)
         assert gix.last_slow_count() == 40
-        assert_same(oix, gix, q, 300, 50)  # max_search > 256 always takes the exact walker
-        gix.set_option(_lib.OPT_FORCE_SLOW, 0)
         assert_same(oix, gix, q, 300, 50)
+        gix.set_option(_lib.OPT_FORCE_SLOW, 0)
+        assert_same(oix, gix, q, 300, 50)  # the register walker takes max_search up to 1024 (walk_fast.h)
+        assert gix.last_slow_count() == 0
+        assert_same(oix, gix, q, 1100, 50)  # beyond that: always the exact global-memory walker
         assert gix.last_slow_count() == 40
+
+
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("ms", [61, 64, 125, 128, 253, 300, 512, 1000, 1024])
+def test_large_max_search_stays_on_the_register_walker(ga, oracle, int8, ms):
+    """The reference takes any max_search (src/index/mod.rs:1006-1010). Up to 1024 the walk stays in
+    registers/LDS (lists of 64..1024 keys); only distance ties at the list's end may hand a walk over."""
+    rng = np.random.default_rng(1000 + ms)
+    el = prep(oracle, random_floats(rng, 4000, 100), int8)
+    oix = oracle.build_index(el, num_neighbors=30, max_search=40, n_threads=4)
+    gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 48, 100), int8)
+    assert_same(oix, gix, q, ms, 20)
+    assert_same(oix, gix, q, ms, ms)
+    if not int8:
+        assert gix.last_slow_count() == 0
 
 
 def test_visited_table_overflow_hands_over(ga, oracle):

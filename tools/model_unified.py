@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""CPU model of the walker's single sorted list (walk_fast.h) against the reference's two heaps.
+
+search_for_neighbors (src/index/mod.rs:999-1037) keeps `res` (the max_search best popped nodes)
+and `pq` (the unbounded candidate queue). The device walker keeps ONE ascending list of `cap`
+keys (dist, id) with an `expanded` flag per entry:
+  * next node to expand  = first unexpanded entry x;
+  * break                <=> #{entries with dist < d_x} >= max_search (they all precede x, so they
+                             are all expanded: exactly `res.len() == max_search && d_x > res.peek().dist`);
+  * enqueue filter       = the reference's, evaluated on the list: when >= max_search expanded
+                           entries are in the list, `worst` is the max_search-th of them;
+  * dead candidates      (>= max_search entries strictly closer) are not inserted;
+  * an entry that falls off the end is provably dead unless it ties with entry max_search-1:
+    then the walk is abandoned (handed to the exact global-memory walker).
+This script replays both on random graphs -- including integer distances full of ties -- and
+asserts equal results and counters whenever the model does not bail.  Not product code.
+"""
+import bisect
+import random
+import sys
+
+
+def reference(adj, dist, ep, ef):
+    import heapq
+    res, pq, visited = [], [(dist(ep), ep)], {ep}
+    n_dist, n_expand, n_adj = 1, 0, 0
+    while pq:
+        d, x = heapq.heappop(pq)
+        if len(res) >= ef and d > -res[0][0]:
+            break
+        if len(res) < ef:
+            heapq.heappush(res, (-d, -x))
+        elif (d, x) < (-res[0][0], -res[0][1]):
+            heapq.heapreplace(res, (-d, -x))
+        n_expand += 1
+        n_adj += len(adj[x])
+        for n in adj[x]:
+            if n not in visited:
+                visited.add(n)
+                dn = dist(n)
+                n_dist += 1
+                if len(res) < ef or dn < -res[0][0]:
+                    heapq.heappush(pq, (dn, n))
+    return sorted((-a, -b) for a, b in res), (n_dist, n_expand, n_adj)
+
+
+def unified(adj, dist, ep, ef, cap):
+    L = [[dist(ep), ep, False]]  # ascending by (dist, id); third field = expanded
+    visited = {ep}
+    n_dist, n_expand, n_adj = 1, 0, 0
+    while True:
+        p = next((i for i, e in enumerate(L) if not e[2]), None)
+        if p is None:
+            break
+        dx, x = L[p][0], L[p][1]
+        if sum(1 for e in L if e[0] < dx) >= ef:
+            break
+        L[p][2] = True
+        n_expand += 1
+        n_adj += len(adj[x])
+        # the filter of this expansion is frozen (res does not change during an expansion)
+        exp = [e for e in L if e[2]]
+        worst = exp[ef - 1][0] if len(exp) >= ef else None
+        theta = L[ef - 1][0] if len(L) >= ef else None
+        cands = []
+        for n in adj[x]:
+            if n not in visited:
+                visited.add(n)
+                dn = dist(n)
+                n_dist += 1
+                if worst is not None and not dn < worst:
+                    continue
+                if theta is not None and dn > theta:
+                    continue  # dead: max_search entries are strictly closer
+                cands.append((dn, n))
+        for dn, n in cands:
+            keys = [(e[0], e[1]) for e in L]
+            L.insert(bisect.bisect_left(keys, (dn, n)), [dn, n, False])
+            while len(L) > cap:
+                y = L.pop()
+                if y[0] == L[ef - 1][0]:
+                    return None, None  # bail: not provably dead
+    exp = [(e[0], e[1]) for e in L if e[2]]
+    return exp[:ef], (n_dist, n_expand, n_adj)
+
+
+def main():
+    rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    trials = bails = 0
+    for it in range(4000):
+        n = rnd.choice([5, 20, 80, 300, 1000])
+        deg = rnd.choice([2, 4, 8, 15, 30])
+        ef = rnd.choice([1, 1, 2, 5, 10, 50, 60, 64])
+        cap = 64
+        adj = [rnd.sample(range(n), min(deg, n)) for _ in range(n)]
+        mode = rnd.choice(["float", "int_small", "int_tiny", "dup"])
+        if mode == "float":
+            dv = [rnd.random() for _ in range(n)]
+        elif mode == "int_small":
+            dv = [rnd.randrange(50) / 50.0 for _ in range(n)]
+        elif mode == "int_tiny":
+            dv = [rnd.randrange(4) / 4.0 for _ in range(n)]
+        else:
+            base = [rnd.random() for _ in range(max(1, n // 4))]
+            dv = [base[rnd.randrange(len(base))] for _ in range(n)]
+        dist = dv.__getitem__
+        ep = rnd.randrange(n)
+        r0, c0 = reference(adj, dist, ep, ef)
+        r1, c1 = unified(adj, dist, ep, ef, cap)
+        trials += 1
+        if r1 is None:
+            bails += 1
+            continue
+        assert r0 == r1, (it, mode, n, deg, ef, r0[:5], r1[:5])
+        assert c0 == c1, (it, mode, n, deg, ef, c0, c1)
+    print("ok: %d walks equal, %d bailed (ties at the boundary)" % (trials - bails, bails))
+
+
+if __name__ == "__main__":
+    main()
