@@ -8,6 +8,7 @@ from . import build as _build
 
 F32, I8 = 0, 1
 UNUSED = 0xFFFFFFFF
+BUILD_ALL = 0xFFFFFFFFFFFFFFFF  # GRANNE_HIP_BUILD_ALL: Builder::build()
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OVERFLOW, ERR_IO = -1, -2, -3, -4, -5
@@ -82,6 +83,15 @@ SIGNATURES = {
     "granne_hip_index_file_info": (i32, [vp, u64, C.POINTER(u32), vp, vp, u32]),
     "granne_hip_index_file_decode_layer": (i32, [vp, u64, u32, vp, vp]),
     "granne_hip_merge_topk_device": (i32, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, i32, vp]),
+    "granne_hip_packed_topk_bytes": (u64, [u32, u32]),
+    "granne_hip_search_batch_packed_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp]),
+    "granne_hip_merge_topk_packed_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, i32, vp]),
+    "granne_hip_sharded_create": (i32, [C.POINTER(vp), vp, vp, u32]),
+    "granne_hip_sharded_destroy": (None, [vp]),
+    "granne_hip_sharded_num_shards": (u32, [vp]),
+    "granne_hip_sharded_len": (u64, [vp]),
+    "granne_hip_sharded_search_batch": (i32, [vp, vp, u32, u32, u32, vp, vp, vp]),
+    "granne_hip_sharded_search": (i32, [vp, vp, u32, u32, vp, vp, C.POINTER(u32)]),
     "granne_hip_build_config_default": (None, [vp]),
     "granne_hip_builder_create": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, i32]),
     "granne_hip_builder_create_device": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, i32, vp]),

@@ -4,7 +4,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import BuildConfig, check, lib
+from ._lib import BUILD_ALL, BuildConfig, check, lib
 from .index import _ELEMENT_TYPES, Granne, _p, normalize, quantize
 
 
@@ -106,7 +106,7 @@ class GranneBuilder:
     def build(self, num_elements=None):
         """GranneBuilder.build (py/src/lib.rs:499-507): all elements, or the first num_elements."""
         self._ensure()
-        check(lib().granne_hip_builder_build(self._h, 0 if num_elements is None else int(num_elements)))
+        check(lib().granne_hip_builder_build(self._h, BUILD_ALL if num_elements is None else int(num_elements)))
 
     def __len__(self):
         self._ensure()

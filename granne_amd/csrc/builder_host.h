@@ -428,8 +428,8 @@ static int index_elements_in_last_layer(granne_hip_builder* b, uint64_t max_num_
 // build_partial, src/index/mod.rs:374-402
 extern "C" int granne_hip_builder_build(granne_hip_builder* b, uint64_t num_elements) {
     if (!b) return fail(GRANNE_HIP_ERR_INVALID, "builder is null");
-    if (num_elements == 0) num_elements = b->n_elements; // build()
-    if (num_elements == 0) return GRANNE_HIP_OK;
+    if (num_elements == GRANNE_HIP_BUILD_ALL) num_elements = b->n_elements; // Builder::build(), mod.rs:370-372
+    if (num_elements == 0) return GRANNE_HIP_OK; // build_partial(0) is a no-op, mod.rs:375
     if (num_elements > b->n_elements) return fail(GRANNE_HIP_ERR_INVALID, "Cannot index more elements than exist.");
     if (!b->layers.empty() && num_elements < b->layers.back().len)
         return fail(GRANNE_HIP_ERR_INVALID, "Cannot index fewer elements than already in index.");

@@ -47,15 +47,24 @@ static bool json_find(const std::string& js, const char* key, size_t* pos) {
     *pos = p + 1;
     return true;
 }
+// decimal digits at js[p..] -> *out; false on overflow of u64 (a header that long is corrupt)
+static bool json_digits(const std::string& js, size_t* p, uint64_t* out) {
+    uint64_t v = 0;
+    while (*p < js.size() && isdigit((unsigned char)js[*p])) {
+        const uint64_t d = (uint64_t)(js[*p] - '0');
+        if (v > (UINT64_MAX - d) / 10) return false;
+        v = v * 10 + d;
+        ++*p;
+    }
+    *out = v;
+    return true;
+}
 static bool json_number(const std::string& js, const char* key, uint64_t* out) {
     size_t p;
     if (!json_find(js, key, &p)) return false;
     while (p < js.size() && isspace((unsigned char)js[p])) ++p;
     if (p >= js.size() || !isdigit((unsigned char)js[p])) return false;
-    uint64_t v = 0;
-    while (p < js.size() && isdigit((unsigned char)js[p])) v = v * 10 + (uint64_t)(js[p++] - '0');
-    *out = v;
-    return true;
+    return json_digits(js, &p, out);
 }
 static bool json_array(const std::string& js, const char* key, std::vector<uint64_t>* out) {
     size_t p;
@@ -70,7 +79,7 @@ static bool json_array(const std::string& js, const char* key, std::vector<uint6
         if (js[p] == ']') return true;
         if (!isdigit((unsigned char)js[p])) return false;
         uint64_t v = 0;
-        while (p < js.size() && isdigit((unsigned char)js[p])) v = v * 10 + (uint64_t)(js[p++] - '0');
+        if (!json_digits(js, &p, &v)) return false;
         out->push_back(v);
     }
 }
@@ -150,7 +159,7 @@ struct DecodedLayer {
 static int decode_layer(const uint8_t* blob, size_t size, uint64_t expect_len, DecodedLayer* L, std::string* err) {
     if (size < 8) { *err = "layer blob too small"; return -1; }
     uint64_t off_bytes = rd_u64(blob);
-    if (off_bytes % CHUNK_BYTES != 0 || 8 + off_bytes > size) { *err = "bad offsets size in layer blob"; return -1; }
+    if (off_bytes % CHUNK_BYTES != 0 || off_bytes > size - 8) { *err = "bad offsets size in layer blob"; return -1; }
     const uint8_t* chunks = blob + 8;
     size_t n_chunks = off_bytes / CHUNK_BYTES;
     const uint8_t* data = chunks + off_bytes;
@@ -197,7 +206,7 @@ static int decode_index(const uint8_t* buf, size_t len, std::vector<DecodedLayer
     size_t start = METADATA_LEN;
     layers->resize(num_layers);
     for (uint64_t l = 0; l < num_layers; ++l) {
-        if (start + sizes[l] > len) { *err = "index file truncated"; return -1; }
+        if (sizes[l] > len - start) { *err = "index file truncated"; return -1; } // no wrap: start <= len
         if (decode_layer(buf + start, sizes[l], counts[l], &(*layers)[l], err)) return -1;
         start += sizes[l];
     }
@@ -313,7 +322,7 @@ extern "C" int granne_hip_index_load(granne_hip_index** out, const void* index_b
     uint64_t dim = granne_file::rd_u64(eb);
     uint64_t esz = elem_size(dtype);
     uint64_t payload = elements_len - 8;
-    if (dim == 0 || dim > 0xFFFFFFFFull || (payload / esz) % dim != 0)
+    if (dim == 0 || dim > 0xFFFFFFFFull || payload % esz != 0 || (payload / esz) % dim != 0)
         return fail(GRANNE_HIP_ERR_IO, "elements file: width %llu does not divide the data", (unsigned long long)dim);
     uint64_t n = payload / esz / dim;
     std::vector<granne_file::DecodedLayer> layers;

@@ -97,6 +97,18 @@ struct granne_hip_index {
     uint64_t opt_slow_blocks = 16;
     uint64_t opt_overflow_slots = 0; // 0 auto, 1 off, else slots per overflow table
     std::atomic<uint64_t> last_slow_count{0};
+    // host-pointer searches (granne_hip_search / _search_batch): a stream, a device buffer and a pinned
+    // staging buffer per concurrent caller, kept for the life of the index -- the reference's API is one
+    // query per call (src/index/mod.rs:140-150), so a call must not pay stream creation and hipMalloc
+    struct HostCall {
+        hipStream_t stream = nullptr;
+        uint8_t* d_buf = nullptr;
+        size_t d_cap = 0;
+        uint8_t* h_pin = nullptr;
+        size_t h_cap = 0;
+    };
+    std::mutex call_mu;
+    std::vector<HostCall*> call_free;
 };
 
 static inline uint32_t elem_size(int dtype) { return dtype == GRANNE_HIP_F32 ? 4u : 1u; }
@@ -150,6 +162,12 @@ static void destroy_index(granne_hip_index* ix) {
     for (auto& L : ix->layers)
         if (L.d_adj) (void)hipFree(L.d_adj);
     if (ix->d_layers) (void)hipFree(ix->d_layers);
+    for (auto* c : ix->call_free) {
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->d_buf) (void)hipFree(c->d_buf);
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
+        delete c;
+    }
     delete ix;
 }
 
@@ -228,9 +246,21 @@ extern "C" int granne_hip_index_create_device(granne_hip_index** out, const void
     ix->n_elements = n_elements;
     ix->row_bytes = device_row_bytes(dim, dtype);
     rc = upload_elements_from_device(ix, d_elements, s);
-    for (uint32_t l = 0; rc == 0 && l < n_layers; ++l)
+    uint32_t* d_bad = nullptr; // neighbor ids outside their layer (the file loader checks the same on the host)
+    if (rc == 0 && hipMalloc((void**)&d_bad, 4) != hipSuccess) rc = fail(GRANNE_HIP_ERR_HIP, "hipMalloc failed");
+    if (rc == 0 && hipMemsetAsync(d_bad, 0, 4, s) != hipSuccess) rc = fail(GRANNE_HIP_ERR_HIP, "hipMemsetAsync failed");
+    for (uint32_t l = 0; rc == 0 && l < n_layers; ++l) {
         rc = add_layer_from_device_rows(ix, layer_len[l], layer_width[l], d_layer_rows[l], s);
-    if (rc == 0) rc = finish_layers(ix, s);
+        const uint64_t total = layer_len[l] * layer_width[l];
+        if (rc == 0 && total)
+            hipLaunchKernelGGL(check_adj_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, d_layer_rows[l], total,
+                               layer_len[l], d_bad);
+    }
+    if (rc == 0) rc = finish_layers(ix, s); // synchronises s
+    uint32_t bad = 0;
+    if (rc == 0 && hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(GRANNE_HIP_ERR_HIP, "hipMemcpy failed");
+    if (d_bad) (void)hipFree(d_bad);
+    if (rc == 0 && bad) rc = fail(GRANNE_HIP_ERR_INVALID, "%u neighbor ids lie outside their layer", bad);
     if (rc) {
         destroy_index(ix);
         return rc;
@@ -310,6 +340,8 @@ extern "C" int granne_hip_index_create_csr(granne_hip_index** out, const void* e
                 if (d > 0xFFFF) return fail(GRANNE_HIP_ERR_INVALID, "layer %u: degree too large", l);
                 if (d > maxdeg) maxdeg = (uint32_t)d;
             }
+            for (uint64_t t = 0; t < off[len]; ++t)
+                if (layer_ids[l][t] >= len) return fail(GRANNE_HIP_ERR_INVALID, "layer %u: neighbor id outside the layer", l);
             LayerHost L;
             L.len = len;
             L.width = maxdeg;
@@ -582,13 +614,18 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
                          uint32_t k, uint64_t* d_ids, float* d_dists, uint32_t* d_counts, uint64_t* d_stats,
                          uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */,
                          uint32_t* d_trail = nullptr /* [nq][8]: trail mode, no search outputs */,
-                         uint32_t trail_layers = 0, hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr) {
+                         uint32_t trail_layers = 0, hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr,
+                         uint32_t* h_status_async = nullptr /* pinned u32[4]: the launch's header words, stream-ordered, no sync */) {
     if (ef == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
     if (nq == 0) return GRANNE_HIP_OK;
-    if (k == 0) return fail(GRANNE_HIP_ERR_INVALID, "num_neighbors must be > 0");
-    if (!d_queries || (!d_trail && (!d_ids || !d_dists || !d_counts))) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+    if (k == 0 && !d_trail) { // .take(0): every result is empty (src/index/mod.rs:974-977)
+        if (!d_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+        HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nq * 4, s));
+        return GRANNE_HIP_OK;
+    }
+    if (!d_queries || (!d_trail && (!d_ids || !d_dists || !d_counts))) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
 
     const bool fast = fast_shape(ix) && ef <= FAST_MAX_SEARCH;
     const uint32_t fastS = fast ? fast_list_slots(ef) : 0u;
@@ -699,6 +736,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
         hipLaunchKernelGGL(slow_kernel<DT_I8>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
     HIP_TRY(hipGetLastError());
 
+    if (h_status_async) HIP_TRY(hipMemcpyAsync(h_status_async, scratch, 16, hipMemcpyDeviceToHost, s));
     if (h_slow_count) {
         uint32_t hs[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(hs, scratch, 16, hipMemcpyDeviceToHost, s));
@@ -746,51 +784,118 @@ extern "C" int granne_hip_event_elapsed_ms(void* before, void* after, float* out
     return GRANNE_HIP_OK;
 }
 
-extern "C" int granne_hip_search_batch(const granne_hip_index* ix, const void* queries, uint32_t nq, uint32_t max_search,
+// borrow / return a host-call context (see granne_hip_index::HostCall)
+static granne_hip_index::HostCall* host_call_acquire(granne_hip_index* ix) {
+    {
+        std::lock_guard<std::mutex> lk(ix->call_mu);
+        if (!ix->call_free.empty()) {
+            auto* c = ix->call_free.back();
+            ix->call_free.pop_back();
+            return c;
+        }
+    }
+    auto* c = new granne_hip_index::HostCall();
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+static void host_call_release(granne_hip_index* ix, granne_hip_index::HostCall* c) {
+    std::lock_guard<std::mutex> lk(ix->call_mu);
+    ix->call_free.push_back(c);
+}
+
+extern "C" int granne_hip_search_batch(const granne_hip_index* cix, const void* queries, uint32_t nq, uint32_t max_search,
                                        uint32_t num_neighbors, uint64_t* out_ids, float* out_dists, uint32_t* out_counts,
                                        uint64_t* out_stats) {
-    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (!cix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    granne_hip_index* ix = const_cast<granne_hip_index*>(cix);
     if (max_search == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
     if (nq == 0) return GRANNE_HIP_OK;
-    if (num_neighbors == 0) return fail(GRANNE_HIP_ERR_INVALID, "num_neighbors must be > 0");
+    if (num_neighbors == 0) { // .take(0), src/index/mod.rs:974-977
+        if (!out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+        memset(out_counts, 0, (size_t)nq * 4);
+        return GRANNE_HIP_OK;
+    }
     if (!queries || !out_ids || !out_dists || !out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
 
+    // device layout: [queries][ids][dists][counts][stats]; the four outputs are contiguous so that a
+    // small batch comes back in one copy
     const size_t k = num_neighbors;
-    size_t qb = (size_t)nq * ix->dim * elem_size(ix->dtype);
-    size_t o_q = 0;
-    size_t o_ids = (qb + 255) & ~(size_t)255;
-    size_t o_d = o_ids + (size_t)nq * k * 8;
-    size_t o_c = o_d + (((size_t)nq * k * 4 + 15) & ~(size_t)15);
-    size_t o_s = o_c + (((size_t)nq * 4 + 15) & ~(size_t)15);
-    size_t total = o_s + (size_t)nq * 24;
-    uint8_t* buf = nullptr;
-    hipStream_t s = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    int rc = GRANNE_HIP_OK;
-    auto body = [&]() -> int {
-        HIP_TRY(hipMalloc((void**)&buf, total));
-        HIP_TRY(hipMemcpyAsync(buf + o_q, queries, qb, hipMemcpyHostToDevice, s));
-        uint32_t slow[2] = {0, 0};
-        SearchTarget T = target_of(ix);
-        int r = search_launch(&T, buf + o_q, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
-                              (uint64_t*)(buf + o_ids), (float*)(buf + o_d), (uint32_t*)(buf + o_c),
-                              (uint64_t*)(buf + o_s), nullptr, s, slow);
-        if (r) return r;
-        const_cast<granne_hip_index*>(ix)->last_slow_count.store(slow[0]);
-        if (slow[1]) return fail(GRANNE_HIP_ERR_OVERFLOW, "exact-search scratch exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)");
+    const size_t qb = (size_t)nq * ix->dim * elem_size(ix->dtype);
+    const size_t o_ids = (qb + 255) & ~(size_t)255;
+    const size_t o_d = o_ids + (size_t)nq * k * 8;
+    const size_t o_c = o_d + (((size_t)nq * k * 4 + 15) & ~(size_t)15);
+    const size_t o_s = o_c + (((size_t)nq * 4 + 15) & ~(size_t)15);
+    const size_t total = o_s + (size_t)nq * 24;
+    const bool staged = total <= (256u << 10); // small calls go through the pinned buffer: two DMA copies per call
+
+    granne_hip_index::HostCall* c = host_call_acquire(ix);
+    if (!c) return fail(GRANNE_HIP_ERR_HIP, "cannot create a stream");
+    struct Release {
+        granne_hip_index* ix;
+        granne_hip_index::HostCall* c;
+        ~Release() { host_call_release(ix, c); }
+    } release{ix, c};
+    if (c->d_cap < total) {
+        if (c->d_buf) (void)hipFree(c->d_buf);
+        c->d_buf = nullptr;
+        c->d_cap = 0;
+        const size_t want = total < (64u << 10) ? (64u << 10) : total;
+        HIP_TRY(hipMalloc((void**)&c->d_buf, want));
+        c->d_cap = want;
+    }
+    if (staged && c->h_cap < total) {
+        if (c->h_pin) (void)hipHostFree(c->h_pin);
+        c->h_pin = nullptr;
+        c->h_cap = 0;
+        HIP_TRY(hipHostMalloc((void**)&c->h_pin, (256u << 10) + 64, hipHostMallocDefault));
+        c->h_cap = 256u << 10;
+    }
+    hipStream_t s = c->stream;
+    uint8_t* buf = c->d_buf;
+    if (staged) {
+        memcpy(c->h_pin, queries, qb);
+        HIP_TRY(hipMemcpyAsync(buf, c->h_pin, qb, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(buf, queries, qb, hipMemcpyHostToDevice, s));
+    }
+    uint32_t slow[2] = {0, 0};
+    SearchTarget T = target_of(ix);
+    int r = search_launch(&T, buf, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
+                          (uint64_t*)(buf + o_ids), (float*)(buf + o_d), (uint32_t*)(buf + o_c), (uint64_t*)(buf + o_s),
+                          nullptr, s, staged ? nullptr : slow, nullptr, 0, nullptr, nullptr,
+                          staged ? (uint32_t*)(c->h_pin + total) : nullptr);
+    if (r) {
+        (void)hipStreamSynchronize(s);
+        return r;
+    }
+    if (staged) {
+        // outputs and the launch's status words (written to h_pin + total by search_launch) in stream order
+        HIP_TRY(hipMemcpyAsync(c->h_pin + o_ids, buf + o_ids, total - o_ids, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const uint32_t* hs = (const uint32_t*)(c->h_pin + total);
+        slow[0] = hs[0];
+        slow[1] = hs[1];
+    }
+    ix->last_slow_count.store(slow[0]);
+    if (slow[1]) return fail(GRANNE_HIP_ERR_OVERFLOW, "exact-search scratch exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)");
+    if (staged) {
+        memcpy(out_ids, c->h_pin + o_ids, (size_t)nq * k * 8);
+        memcpy(out_dists, c->h_pin + o_d, (size_t)nq * k * 4);
+        memcpy(out_counts, c->h_pin + o_c, (size_t)nq * 4);
+        if (out_stats) memcpy(out_stats, c->h_pin + o_s, (size_t)nq * 24);
+    } else {
         HIP_TRY(hipMemcpyAsync(out_ids, buf + o_ids, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(out_dists, buf + o_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(out_counts, buf + o_c, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
         if (out_stats) HIP_TRY(hipMemcpyAsync(out_stats, buf + o_s, (size_t)nq * 24, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        return GRANNE_HIP_OK;
-    };
-    rc = body();
-    if (buf) (void)hipFree(buf);
-    (void)hipStreamDestroy(s);
-    return rc;
+    }
+    return GRANNE_HIP_OK;
 }
 
 extern "C" int granne_hip_search(const granne_hip_index* ix, const void* query, uint32_t max_search,
@@ -880,21 +985,32 @@ extern "C" int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_
     return GRANNE_HIP_OK;
 }
 
-extern "C" int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, const uint32_t* d_counts,
-                                            const uint64_t* shard_offsets, uint32_t n_shards, uint32_t nq, uint32_t k,
-                                            uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
-                                            int device_id, void* stream) {
+// the per-shard top-k of a batch in ONE buffer: [nq*k u64 ids][nq*k f32 dists][nq u32 counts], padded to
+// 16 bytes -- what one rank contributes to the all-gather of the partitioned mode
+static inline size_t packed_dists_off(uint32_t nq, uint32_t k) { return (size_t)nq * k * 8; }
+static inline size_t packed_counts_off(uint32_t nq, uint32_t k) { return (size_t)nq * k * 12; }
+extern "C" uint64_t granne_hip_packed_topk_bytes(uint32_t nq, uint32_t k) {
+    return ((uint64_t)nq * k * 12 + (uint64_t)nq * 4 + 15) & ~(uint64_t)15;
+}
+
+static int merge_launch(const uint8_t* ids, const uint8_t* dists, const uint8_t* counts, uint64_t ids_stride,
+                        uint64_t dists_stride, uint64_t counts_stride, const uint64_t* shard_offsets, uint32_t n_shards,
+                        uint32_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                        int device_id, void* stream) {
     if (nq == 0) return GRANNE_HIP_OK;
-    if (!d_ids || !d_dists || !d_counts || !shard_offsets || !d_out_ids || !d_out_dists || !d_out_counts)
+    if (!ids || !dists || !counts || !shard_offsets || !d_out_ids || !d_out_dists || !d_out_counts)
         return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
     if (n_shards == 0 || n_shards > 64) return fail(GRANNE_HIP_ERR_INVALID, "n_shards must be in [1, 64]");
     if (k == 0 || (uint64_t)n_shards * k > 4096) return fail(GRANNE_HIP_ERR_INVALID, "n_shards * k must be in [1, 4096]");
     DeviceGuard g(device_id);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
     MergeParams P;
-    P.ids = d_ids;
-    P.dists = d_dists;
-    P.counts = d_counts;
+    P.ids = ids;
+    P.dists = dists;
+    P.counts = counts;
+    P.ids_stride = ids_stride;
+    P.dists_stride = dists_stride;
+    P.counts_stride = counts_stride;
     for (uint32_t s = 0; s < 64; ++s) P.offsets[s] = s < n_shards ? shard_offsets[s] : 0;
     P.n_shards = n_shards;
     P.nq = nq;
@@ -907,6 +1023,37 @@ extern "C" int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* 
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(64), lds, (hipStream_t)stream, P);
     HIP_TRY(hipGetLastError());
     return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, const uint32_t* d_counts,
+                                            const uint64_t* shard_offsets, uint32_t n_shards, uint32_t nq, uint32_t k,
+                                            uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                                            int device_id, void* stream) {
+    return merge_launch((const uint8_t*)d_ids, (const uint8_t*)d_dists, (const uint8_t*)d_counts, (uint64_t)nq * k * 8,
+                        (uint64_t)nq * k * 4, (uint64_t)nq * 4, shard_offsets, n_shards, nq, k, d_out_ids, d_out_dists,
+                        d_out_counts, device_id, stream);
+}
+
+extern "C" int granne_hip_merge_topk_packed_device(const void* d_packed, const uint64_t* shard_offsets, uint32_t n_shards,
+                                                   uint32_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_dists,
+                                                   uint32_t* d_out_counts, int device_id, void* stream) {
+    const uint8_t* base = (const uint8_t*)d_packed;
+    const uint64_t stride = granne_hip_packed_topk_bytes(nq, k);
+    if (!base && nq) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    return merge_launch(base, base + packed_dists_off(nq, k), base + packed_counts_off(nq, k), stride, stride, stride,
+                        shard_offsets, n_shards, nq, k, d_out_ids, d_out_dists, d_out_counts, device_id, stream);
+}
+
+extern "C" int granne_hip_search_batch_packed_device(const granne_hip_index* ix, const void* d_queries, uint32_t nq,
+                                                     uint32_t max_search, uint32_t num_neighbors, void* d_packed,
+                                                     uint32_t* d_status, void* stream) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (!d_packed && nq) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (num_neighbors == 0) return fail(GRANNE_HIP_ERR_INVALID, "num_neighbors must be > 0 for a packed result");
+    uint8_t* base = (uint8_t*)d_packed;
+    return granne_hip_search_batch_device(ix, d_queries, nq, max_search, num_neighbors, (uint64_t*)base,
+                                          (float*)(base + packed_dists_off(nq, num_neighbors)),
+                                          (uint32_t*)(base + packed_counts_off(nq, num_neighbors)), nullptr, d_status, stream);
 }
 
 // host conveniences -------------------------------------------------------------------------------
@@ -998,3 +1145,8 @@ extern "C" int granne_hip_dist_pairs(const granne_hip_index* ix, const void* que
 // granne's file formats
 // ------------------------------------------------------------------------------------------------
 #include "fileformat_host.h"
+
+// ------------------------------------------------------------------------------------------------
+// partitioned indexes driven by one host process
+// ------------------------------------------------------------------------------------------------
+#include "sharded_host.h"

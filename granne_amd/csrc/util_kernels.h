@@ -41,6 +41,19 @@ __global__ void relayout_adj_kernel(const uint32_t* __restrict__ src, uint32_t* 
     }
 }
 
+// neighbor ids of a layer must be nodes of that layer (the walk indexes the layer's rows with them):
+// counts the entries that are neither UNUSED nor < limit
+__global__ void check_adj_kernel(const uint32_t* __restrict__ rows, uint64_t total, uint64_t limit,
+                                 uint32_t* __restrict__ bad) {
+    uint32_t mine = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = rows[t];
+        mine += (v != 0xFFFFFFFFu && (uint64_t)v >= limit) ? 1u : 0u;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
 // CSR adjacency -> [len][W], UNUSED padded
 __global__ void csr_to_adj_kernel(const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ ids,
                                   uint32_t* __restrict__ dst, uint64_t len, uint32_t W) {
@@ -235,9 +248,13 @@ __global__ __launch_bounds__(256) void dists_kernel(const uint8_t* __restrict__ 
 }
 
 struct MergeParams {
-    const uint64_t* ids;
-    const float* dists;
-    const uint32_t* counts;
+    // shard s: ids at ids + s * ids_stride bytes ([nq][k] u64), dists and counts likewise. The plain
+    // form passes three [n_shards][...] arrays, the packed form three offsets into records of one
+    // stride (granne_hip_packed_topk_bytes).
+    const uint8_t* ids;
+    const uint8_t* dists;
+    const uint8_t* counts;
+    uint64_t ids_stride, dists_stride, counts_stride;
     uint64_t offsets[64];
     uint32_t n_shards, nq, k;
     uint64_t* out_ids;
@@ -256,10 +273,13 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const MergeParams P) {
     const uint32_t C = P.n_shards * P.k;
     for (uint32_t c = lane; c < C; c += 64) {
         uint32_t s = c / P.k, j = c - s * P.k;
-        bool ok = j < P.counts[(size_t)s * P.nq + q];
-        size_t src = ((size_t)s * P.nq + q) * P.k + j;
-        kd[c] = ok ? __float_as_uint(P.dists[src]) : 0xFFFFFFFFu;
-        ki[c] = ok ? P.ids[src] + P.offsets[s] : ~0ull;
+        const uint32_t* cnt = reinterpret_cast<const uint32_t*>(P.counts + (size_t)s * P.counts_stride);
+        const uint64_t* sid = reinterpret_cast<const uint64_t*>(P.ids + (size_t)s * P.ids_stride);
+        const float* sd = reinterpret_cast<const float*>(P.dists + (size_t)s * P.dists_stride);
+        bool ok = j < cnt[q];
+        size_t src = (size_t)q * P.k + j;
+        kd[c] = ok ? __float_as_uint(sd[src]) : 0xFFFFFFFFu;
+        ki[c] = ok ? sid[src] + P.offsets[s] : ~0ull;
     }
     __syncthreads();
     uint32_t total = 0;

@@ -1,99 +1,134 @@
-"""Partitioned (sharded) search: the element set is split into independent indexes, one per
-rank / GPU; every rank answers the same query batch on its shard, the per-shard top-k lists are
-exchanged with ONE all-gather (nq*k*(8+4) bytes per rank: 120 KB at nq=1024, k=10 -- latency, not
-bandwidth, over xGMI) and merged by (dist, global id). SURVEY.md 8e; the reference's own
-sharding helper splits elements the same way (src/elements/embeddings/parsing.rs:63-100).
+"""Partitioned (sharded) search, one process per GPU.
 
-One process per GPU with torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
-tests). The local search and the merge default to the HIP kernels behind the C ABI; they are
-constructor parameters only so that tests/test_sharded_gloo.py can drive the exchange logic on a
-GPU-less box with stand-ins from oracle/ -- this module itself contains no CPU implementation.
+The element set is split into independent indexes (the reference's own shard helper splits
+elements the same way, src/elements/embeddings/parsing.rs:63-100); a rank holds one or more
+shards on its GPU. Every rank answers the same query batch on its shards, writing each shard's
+top-k into ONE packed buffer ([nq*k u64 local ids][nq*k f32 dists][nq u32 counts]:
+granne_hip_packed_topk_bytes); ONE all-gather of those buffers is the exchange step
+(124 KB per shard at nq = 1024, k = 10 -- latency-, not bandwidth-bound over xGMI), then the merge
+kernel ranks the n_shards*k candidates of each query by (dist, global id). SURVEY.md 8e.
+
+torch.distributed supplies the collective (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
+tests). The local search and the merge are the HIP kernels behind the C ABI; they are constructor
+parameters only so that tests/test_sharded_gloo.py can drive the exchange logic on a GPU-less box
+with stand-ins from oracle/ -- this module itself contains no CPU implementation. A host that
+drives several GPUs from one process uses granne_hip_sharded_* (include/granne_hip.h) instead.
 """
 import ctypes as C
 
 import numpy as np
 
 
-def shard_bounds(n_elements, world_size):
+def shard_bounds(n_elements, n_shards):
     """Shard g owns ids [g*ceil(n/G), min(n, (g+1)*ceil(n/G)))  (SURVEY.md 8e)."""
-    per = -(-n_elements // world_size)
-    return [(min(n_elements, g * per), min(n_elements, (g + 1) * per)) for g in range(world_size)]
+    per = -(-n_elements // n_shards)
+    return [(min(n_elements, g * per), min(n_elements, (g + 1) * per)) for g in range(n_shards)]
+
+
+def packed_bytes(nq, k):
+    return (nq * k * 12 + nq * 4 + 15) & ~15
 
 
 class ShardedGranne:
-    """`local_index`: this rank's granne_amd.Granne over its shard (local ids). `offset`: the
-    shard's first global id. Collective: every rank must call search_batch with the same queries."""
+    """`local_indexes`: this rank's granne_amd.Granne objects (local ids), in global shard order
+    rank*len(local_indexes) + i. `all_offsets`: the first global id of EVERY shard of the job (known
+    to every rank: shard_bounds is deterministic), world*len(local_indexes) entries.
+    Collective: every rank must call search_batch with the same queries."""
 
-    def __init__(self, local_index, offset, group=None, local_search=None, merge=None):
+    def __init__(self, local_indexes, all_offsets, group=None, local_search=None, merge=None):
         import torch.distributed as dist
         self.dist = dist
-        self.index = local_index
+        self.indexes = list(local_indexes) if isinstance(local_indexes, (list, tuple)) else [local_indexes]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.offset = int(offset)
+        self.local = len(self.indexes)
+        self.offsets = [int(o) for o in all_offsets]
+        if len(self.offsets) != self.world * self.local:
+            raise ValueError("need one offset per shard of the job: %d ranks x %d shards" % (self.world, self.local))
+        self._on_gpu = local_search is None
         self._local_search = local_search or self._gpu_local_search
         self._merge = merge or self._gpu_merge
-        self._offsets = None
+        self._streams = None
+        self._status = None
+        self.timings = None  # set by search_batch(timed=True): HIP-event ms of search / exchange / merge
 
     # ---- defaults: HIP kernels through the C ABI, tensors on this rank's GPU ---------------------
-    def _gpu_local_search(self, queries, max_search, k):
-        import torch
-        q = queries if torch.is_tensor(queries) else torch.from_numpy(np.ascontiguousarray(queries))
-        q = q.cuda().contiguous()
-        nq = q.shape[0]
-        ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
-        ds = torch.empty((nq, k), dtype=torch.float32, device="cuda")
-        cnt = torch.empty(nq, dtype=torch.int32, device="cuda")
-        self.index.search_batch_device(q.data_ptr(), nq, max_search, k, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(),
-                                       0, 0, torch.cuda.current_stream().cuda_stream)
-        return ids, ds, cnt
-
-    def _gpu_merge(self, ids, ds, cnt, offsets, k):
+    def _gpu_local_search(self, queries, max_search, k, out):
+        """Every local shard searches the batch on a stream of its own; results land in out[i] (packed)."""
         import torch
         from ._lib import check, lib
-        G, nq, _ = ids.shape
-        out_ids = torch.empty((nq, k), dtype=torch.int64, device=ids.device)
-        out_d = torch.empty((nq, k), dtype=torch.float32, device=ids.device)
-        out_c = torch.empty(nq, dtype=torch.int32, device=ids.device)
-        off = (C.c_uint64 * G)(*[int(o) for o in offsets])
-        check(lib().granne_hip_merge_topk_device(C.c_void_p(ids.data_ptr()), C.c_void_p(ds.data_ptr()),
-                                                 C.c_void_p(cnt.data_ptr()), off, G, nq, k,
-                                                 C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_d.data_ptr()),
-                                                 C.c_void_p(out_c.data_ptr()), ids.device.index or 0,
-                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        q = queries if torch.is_tensor(queries) else torch.from_numpy(np.ascontiguousarray(queries))
+        dev = torch.device("cuda", self.indexes[0].device)
+        q = q.to(dev).contiguous()
+        nq = q.shape[0]
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in self.indexes]
+            self._status = torch.zeros((self.local, 4), dtype=torch.int32, device=dev)
+        cur = torch.cuda.current_stream(dev)
+        self._status.zero_()
+        for i, ix in enumerate(self.indexes):
+            s = self._streams[i]
+            s.wait_stream(cur)  # the queries (and `out`) are ready on the caller's stream
+            check(lib().granne_hip_search_batch_packed_device(ix._h, C.c_void_p(q.data_ptr()), nq, int(max_search), int(k),
+                                                              C.c_void_p(out[i].data_ptr()),
+                                                              C.c_void_p(self._status[i].data_ptr()),
+                                                              C.c_void_p(s.cuda_stream)))
+        for s in self._streams:
+            cur.wait_stream(s)
+        return q
+
+    def _gpu_merge(self, gathered, offsets, nq, k):
+        import torch
+        from ._lib import check, lib
+        G = len(offsets)
+        dev = gathered.device
+        out_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        out_c = torch.empty(nq, dtype=torch.int32, device=dev)
+        off = (C.c_uint64 * G)(*offsets)
+        check(lib().granne_hip_merge_topk_packed_device(C.c_void_p(gathered.data_ptr()), off, G, nq, k,
+                                                        C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_d.data_ptr()),
+                                                        C.c_void_p(out_c.data_ptr()), dev.index or 0,
+                                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return out_ids, out_d, out_c
 
-    # ---- the exchange --------------------------------------------------------------------------------
-    def _all_offsets(self, device):
-        import torch
-        if self._offsets is None:
-            mine = torch.tensor([self.offset], dtype=torch.int64, device=device)
-            if self.world > 1:
-                allv = [torch.empty_like(mine) for _ in range(self.world)]
-                self.dist.all_gather(allv, mine, group=self.group)
-                self._offsets = [int(t.item()) for t in allv]
-            else:
-                self._offsets = [self.offset]
-        return self._offsets
-
-    def search_batch(self, queries, max_search, k):
+    # ---- search + the one exchange step + merge ---------------------------------------------------------
+    def search_batch(self, queries, max_search, k, check_status=True, timed=False):
         """Returns (ids [nq,k] global, dists [nq,k], counts [nq]) -- identical on every rank."""
         import torch
-        ids, ds, cnt = self._local_search(queries, max_search, k)
-        offsets = self._all_offsets(ids.device)
+        nq = int(queries.shape[0])
+        pb = packed_bytes(nq, k)
+        on_gpu = self._on_gpu
+        dev = torch.device("cuda", self.indexes[0].device) if on_gpu else torch.device("cpu")
+        mine = torch.empty((self.local, pb), dtype=torch.uint8, device=dev)  # this rank's shards write here
+        gathered = torch.empty((self.world, self.local, pb), dtype=torch.uint8, device=dev) if self.world > 1 else mine[None]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (timed and on_gpu) else None
+        if ev:
+            ev[0].record()
+        self._local_search(queries, max_search, k, mine)
+        if ev:
+            ev[1].record()
         if self.world > 1:
-            g_ids = torch.empty((self.world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
-            g_ds = torch.empty((self.world,) + tuple(ds.shape), dtype=ds.dtype, device=ds.device)
-            g_cnt = torch.empty((self.world,) + tuple(cnt.shape), dtype=cnt.dtype, device=cnt.device)
-            # one exchange step: all-gather of the per-shard top-k (ids, dists, counts)
-            # (views of one contiguous [world][...] buffer: the same layout on RCCL and on gloo)
-            self.dist.all_gather(list(g_ids.unbind(0)), ids.contiguous(), group=self.group)
-            self.dist.all_gather(list(g_ds.unbind(0)), ds.contiguous(), group=self.group)
-            self.dist.all_gather(list(g_cnt.unbind(0)), cnt.contiguous(), group=self.group)
-        else:
-            g_ids, g_ds, g_cnt = ids[None], ds[None], cnt[None]
-        return self._merge(g_ids, g_ds, g_cnt, offsets, k)
+            # ONE collective: every rank's packed results (ids, dists and counts together)
+            self.dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=self.group)
+        if ev:
+            ev[2].record()
+        out = self._merge(gathered.view(self.world * self.local, pb), self.offsets, nq, k)
+        if ev:
+            ev[3].record()
+            torch.cuda.synchronize(dev)
+            self.timings = {"search_ms": ev[0].elapsed_time(ev[1]), "exchange_ms": ev[1].elapsed_time(ev[2]),
+                            "merge_ms": ev[2].elapsed_time(ev[3])}
+        if check_status and on_gpu and self._status is not None:
+            # a shard whose exact-search scratch ran out wrote empty results: report, never merge silently
+            if int(self._status[:, 0].sum().item()) != 0:
+                from ._lib import ERR_OVERFLOW, GranneHipError
+                raise GranneHipError(ERR_OVERFLOW, "a shard's exact-search scratch is exhausted (raise OPT_SLOW_SLOTS)")
+        return out
+
+    def exchange_bytes_per_rank(self, nq, k):
+        return self.local * packed_bytes(nq, k)
 
 
 def replica_query_rows(rank, world_size, n_batches, batch):

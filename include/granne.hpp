@@ -213,7 +213,7 @@ public:
     void push(const typename Elements::Element& element) {
         check(granne_hip_builder_append(b_.get(), element.as_slice(), 1));
     }
-    void build() { check(granne_hip_builder_build(b_.get(), 0)); }
+    void build() { check(granne_hip_builder_build(b_.get(), GRANNE_HIP_BUILD_ALL)); }
     void build_partial(size_t num_elements) {
         if (num_elements == 0) return; // mod.rs:375-377
         check(granne_hip_builder_build(b_.get(), num_elements));

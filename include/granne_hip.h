@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GRANNE_HIP_ABI_VERSION 1
+#define GRANNE_HIP_ABI_VERSION 2
 
 /* element scalar types: granne::angular::Vectors (f32, rows normalised) and
  * granne::angular_int::Vectors (i8, rows quantised) -- src/elements/angular.rs:53,
@@ -235,6 +235,41 @@ int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, co
                                  uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
                                  int device_id, void* stream);
 
+/* The per-shard top-k of one batch as ONE buffer -- what a rank contributes to the single exchange
+ * step of the partitioned mode (one all-gather, or one peer copy):
+ *   [nq*k u64 local ids][nq*k f32 dists][nq u32 counts], padded to 16 bytes.                      */
+uint64_t granne_hip_packed_topk_bytes(uint32_t nq, uint32_t k);
+/* granne_hip_search_batch_device writing that buffer (d_packed: granne_hip_packed_topk_bytes). */
+int granne_hip_search_batch_packed_device(const granne_hip_index* index, const void* d_queries, uint32_t nq,
+                                          uint32_t max_search, uint32_t num_neighbors, void* d_packed,
+                                          uint32_t* d_status, void* stream);
+/* granne_hip_merge_topk_device over n_shards such buffers laid end to end (the all-gather's output). */
+int granne_hip_merge_topk_packed_device(const void* d_packed, const uint64_t* shard_offsets, uint32_t n_shards,
+                                        uint32_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_dists,
+                                        uint32_t* d_out_counts, int device_id, void* stream);
+
+/* ---- a partitioned index driven by one host process ----------------------------------------------
+ * SURVEY.md 8b's `device_ids / n_devices / partitioned`: shard s is a granne_hip_index of its own
+ * (created on whatever device it should live on: granne_hip_index_create*, _load*, a builder's
+ * get_index) over the elements [id_offsets[s], id_offsets[s] + len_s) of the whole set, with local ids.
+ * granne_hip_sharded_search_batch = Granne::search on every shard + the merge: each shard searches the
+ * same batch on its own device and stream, its packed top-k goes to shard 0's device (peer copy over
+ * xGMI), merge by (dist, global id). Results equal the per-shard searches merged on the host.
+ * The handle BORROWS the shard indexes (destroy them after it). One search at a time per handle.
+ * n_shards <= 64, n_shards * num_neighbors <= 4096.                                              */
+typedef struct granne_hip_sharded granne_hip_sharded;
+int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_index* const* shards,
+                              const uint64_t* id_offsets, uint32_t n_shards);
+void granne_hip_sharded_destroy(granne_hip_sharded* sharded);
+uint32_t granne_hip_sharded_num_shards(const granne_hip_sharded* sharded);
+uint64_t granne_hip_sharded_len(const granne_hip_sharded* sharded);
+/* queries / outputs: HOST buffers; out_ids are global ids, ascending (dist, id), [nq][num_neighbors]. */
+int granne_hip_sharded_search_batch(granne_hip_sharded* sharded, const void* queries, uint32_t nq,
+                                    uint32_t max_search, uint32_t num_neighbors, uint64_t* out_ids,
+                                    float* out_dists, uint32_t* out_counts);
+int granne_hip_sharded_search(granne_hip_sharded* sharded, const void* query, uint32_t max_search,
+                              uint32_t num_neighbors, uint64_t* out_ids, float* out_dists, uint32_t* out_count);
+
 /* ---- GranneBuilder on the GPU ------------------------------------------------------------------
  * Mirrors GranneBuilder / BuildConfig / Builder (src/index/mod.rs:198-531): the same layer
  * pyramid (compute_num_elements_in_layer :634-643), the same per-element work (index_element
@@ -280,8 +315,9 @@ int granne_hip_builder_append(granne_hip_builder* builder, const void* elements,
  * granne_hip_builder_build then continues from len() as the reference does. */
 int granne_hip_builder_load_index(granne_hip_builder* builder, const void* index_bytes, uint64_t index_len);
 
-/* Builder::build_partial(num_elements) (src/index/mod.rs:374-402); num_elements == 0 means
- * Builder::build() = all elements. Synchronous. */
+/* Builder::build_partial(num_elements) (src/index/mod.rs:374-402); num_elements == 0 returns at once
+ * as the reference does (:375); GRANNE_HIP_BUILD_ALL is Builder::build() = all elements. Synchronous. */
+#define GRANNE_HIP_BUILD_ALL UINT64_MAX
 int granne_hip_builder_build(granne_hip_builder* builder, uint64_t num_elements);
 uint64_t granne_hip_builder_len(const granne_hip_builder* builder);          /* indexed elements */
 uint64_t granne_hip_builder_num_elements(const granne_hip_builder* builder);

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.granne_hip_abi_version() == 1
+    assert lib.granne_hip_abi_version() == 2
 
 
 def test_library_contains_gfx950_code_object():

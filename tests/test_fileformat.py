@@ -118,3 +118,37 @@ def test_oracle_built_index_roundtrips_through_the_file(lib, tmp_path, oracle):
     for layer, nodes in zip(ix.layers, dec):
         for row, ids in zip(layer, nodes):
             assert sorted(int(x) for x in row if x != UNUSED) == ids
+
+
+def test_corrupt_header_sizes_are_rejected_not_wrapped(lib, tmp_path):
+    """A layer_sizes entry near 2^64 must not wrap the bounds check, and a digit string that overflows
+    u64 must not be read modulo 2^64 (the reference panics safely on the slice bounds, io.rs:75-84)."""
+    rng = np.random.default_rng(5)
+    layers = random_layers(rng, [3, 40], 6, lambda n: n)
+    buf = bytearray(product_write_index(lib, str(tmp_path / "ok.granne"), layers))
+    head = bytes(buf[:1024]).decode()
+    meta = json.loads(head[6:].strip())
+    good = meta["layer_sizes"][1]
+
+    def with_sizes(sizes_text):
+        h = head.replace('"layer_sizes":[%d,%d]' % (meta["layer_sizes"][0], good), '"layer_sizes":%s' % sizes_text)
+        assert h != head
+        h = h.rstrip(" ")
+        assert len(h) <= 1024
+        return h.encode().ljust(1024, b" ") + bytes(buf[1024:])
+
+    def info(b):
+        a = np.frombuffer(b, np.uint8)
+        n = C.c_uint32()
+        lens = (C.c_uint64 * 64)()
+        nids = (C.c_uint64 * 64)()
+        return lib.granne_hip_index_file_info(a.ctypes.data_as(C.c_void_p), a.size, C.byref(n), lens, nids, 64)
+
+    assert info(bytes(buf)) == 0
+    first = meta["layer_sizes"][0]
+    # start + size wraps to a small number in u64
+    assert info(with_sizes("[%d,%d]" % (first, 2 ** 64 - 1024 - first + 8))) == _lib.ERR_IO
+    assert info(with_sizes("[%d,%d]" % (first, 2 ** 64 - 1))) == _lib.ERR_IO
+    # 2^64 + good reads as `good` modulo 2^64
+    assert info(with_sizes("[%d,%d]" % (first, 2 ** 64 + good))) == _lib.ERR_IO
+    assert info(with_sizes("[%d,%d]" % (first, good + 1))) == _lib.ERR_IO  # plain truncation

@@ -495,3 +495,26 @@ def test_timed_search_records_events_around_the_kernel(ga, oracle):
     lib.granne_hip_event_destroy(e1)
     want = oix.search_batch(q, 50, 10)
     assert (ids.cpu().numpy().astype(np.uint64) == want[0]).all() and ds.cpu().numpy().tobytes() == want[1].tobytes()
+
+
+def test_num_neighbors_zero_is_an_empty_result(ga, oracle):
+    """`.take(0)` (src/index/mod.rs:974-977): no results, no error."""
+    rng = np.random.default_rng(31)
+    el = prep(oracle, random_floats(rng, 300, 100), False)
+    oix = oracle.build_index(el, num_neighbors=10, max_search=20, n_threads=2)
+    gix = ga.Granne("angular", el, oix.layers)
+    ids, ds, cnt = gix.search_batch(el[:5], 20, 0)
+    assert ids.shape == (5, 0) and ds.shape == (5, 0) and (cnt == 0).all()
+    assert gix.search(el[0], 20, 0) == []
+
+
+def test_neighbor_ids_outside_their_layer_are_rejected(ga, oracle):
+    from granne_amd import _lib
+    rng = np.random.default_rng(32)
+    el = prep(oracle, random_floats(rng, 300, 100), False)
+    oix = oracle.build_index(el, num_neighbors=10, max_search=20, n_threads=2)
+    layers = [l.copy() for l in oix.layers]
+    layers[0][0, 0] = layers[0].shape[0]  # first id past the top layer
+    with pytest.raises(_lib.GranneHipError) as e:
+        ga.Granne("angular", el, layers)
+    assert e.value.code == _lib.ERR_INVALID

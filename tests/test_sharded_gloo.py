@@ -1,7 +1,8 @@
 """The N > 1 path on CPU: two processes, gloo backend, world_size 2.
 
-Partitioned mode: each rank owns an id range and its own index; every rank answers
-the same query batch; ONE all-gather of the per-shard top-k; merge by (dist, global id). The local
+Partitioned mode: each rank owns id ranges and their indexes (two shards per rank
+here); every rank answers the same query batch; ONE all-gather of the packed per-shard top-k (ids,
+dists and counts in one buffer); merge by (dist, global id). The local
 search and the merge are injected here (the CPU oracle and a numpy merge) because there is no GPU:
 what is under test is granne_amd.sharded's exchange logic -- offsets, all-gather layout, ordering,
 identical results on every rank -- against a single-process recomputation.
@@ -14,12 +15,13 @@ import sys
 import numpy as np
 import pytest
 
-from oracle.merge import merge_topk_numpy
+from oracle.merge import merge_topk_numpy, pack_topk, unpack_topk
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOCAL = 2  # shards per rank
 
 
 def _free_port():
@@ -47,21 +49,34 @@ def _worker(rank, world, port, out_dir):
     from oracle import oracle as orc
     from granne_amd import sharded
     el, q = _data()
-    lo, hi = sharded.shard_bounds(len(el), world)[rank]
-    local = orc.build_index(np.ascontiguousarray(el[lo:hi]), num_neighbors=8, max_search=20)
+    bounds = sharded.shard_bounds(len(el), world * LOCAL)
+    mine = bounds[rank * LOCAL:(rank + 1) * LOCAL]
+    local = [orc.build_index(np.ascontiguousarray(el[lo:hi]), num_neighbors=8, max_search=20) for lo, hi in mine]
+    calls = {"all_gather": 0}
+    real = dist.all_gather_into_tensor
 
-    def local_search(queries, max_search, k):  # CPU stand-in for the HIP search: same outputs
-        ids, ds, cnt, _ = local.search_batch(np.asarray(queries), max_search, k)
-        return (torch.from_numpy(ids.astype(np.int64)), torch.from_numpy(ds), torch.from_numpy(cnt.astype(np.int32)))
+    def counting(*a, **kw):
+        calls["all_gather"] += 1
+        return real(*a, **kw)
+    dist.all_gather_into_tensor = counting
 
-    def merge(g_ids, g_ds, g_cnt, offsets, k):
-        i, d, c = merge_topk_numpy(g_ids.numpy().astype(np.uint64), g_ds.numpy(), g_cnt.numpy(), offsets, k)
+    def local_search(queries, max_search, k, out):  # CPU stand-in for the HIP searches: same packed outputs
+        for i, ix in enumerate(local):
+            ids, ds, cnt, _ = ix.search_batch(np.asarray(queries), max_search, k)
+            out[i].copy_(torch.from_numpy(pack_topk(ids, ds, cnt)))
+
+    def merge(gathered, offsets, nq, k):
+        parts = [unpack_topk(gathered[g].numpy(), nq, k) for g in range(gathered.shape[0])]
+        i, d, c = merge_topk_numpy(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]),
+                                   np.stack([p[2] for p in parts]), offsets, k)
         return torch.from_numpy(i.astype(np.int64)), torch.from_numpy(d), torch.from_numpy(c.astype(np.int32))
 
-    sg = sharded.ShardedGranne(None, lo, local_search=local_search, merge=merge)
+    sg = sharded.ShardedGranne([None] * LOCAL, [b[0] for b in bounds], local_search=local_search, merge=merge)
     ids, ds, cnt = sg.search_batch(q, 20, 5)
+    assert calls["all_gather"] == 1, "the exchange is ONE collective per batch"
+    assert sg.exchange_bytes_per_rank(len(q), 5) == LOCAL * ((len(q) * 5 * 12 + len(q) * 4 + 15) & ~15)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ids=ids.numpy(), ds=ds.numpy(), cnt=cnt.numpy(),
-             offsets=np.array(sg._offsets))
+             offsets=np.array(sg.offsets))
     # replica mode: disjoint query rows, all rows covered
     r0, per = sharded.replica_query_rows(rank, world, 3, 8)
     t = torch.tensor([r0, per], dtype=torch.int64)
@@ -83,7 +98,7 @@ def test_partitioned_search_two_ranks_gloo(tmp_path, oracle):
     # equals a single-process recomputation: per-shard CPU search + merge
     from granne_amd import sharded
     el, q = _data()
-    bounds = sharded.shard_bounds(len(el), world)
+    bounds = sharded.shard_bounds(len(el), world * LOCAL)
     assert r[0]["offsets"].tolist() == [b[0] for b in bounds]
     per_shard = []
     for lo, hi in bounds:
