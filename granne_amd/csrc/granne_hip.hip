@@ -518,10 +518,11 @@ static search_fn pick_kernel(int dtype, uint32_t ef) {
 
 // the walker of the common shapes (walk_fast.h): every layer 32 ids wide on the device, ids within 31
 // bits, f32 rows of an instantiated dim or int8 rows of 128 bytes. The list holds 64*S keys and must
-// hold max_search of them; a few spare places keep distance ties at the boundary from handing walks
-// over (none at the top size).
+// hold max_search of them plus a few spare places: two distances of a walk tie surprisingly often (4000
+// candidates share 2^23 float values), and a tie between entry max_search-1 and an entry pushed off the
+// end hands the walk over -- with spare places that takes a run of ties.
 constexpr uint32_t FAST_MAX_SEARCH = 1024;
-static uint32_t fast_list_slots(uint32_t ef) { return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : 16u; }
+static uint32_t fast_list_slots(uint32_t ef) { return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : 17u; }
 template <int DT, int DIM>
 static search_fn pick_fast_s(uint32_t S, bool trail) {
     if (trail) return fast_kernel<DT, DIM, 1, true>;
@@ -530,7 +531,7 @@ static search_fn pick_fast_s(uint32_t S, bool trail) {
     case 2: return fast_kernel<DT, DIM, 2>;
     case 4: return fast_kernel<DT, DIM, 4>;
     case 8: return fast_kernel<DT, DIM, 8>;
-    default: return fast_kernel<DT, DIM, 16>;
+    default: return fast_kernel<DT, DIM, 17>;
     }
 }
 static bool fast_shape(const SearchTarget* ix) {

@@ -84,10 +84,66 @@ struct WalkList : SortedList<S> {
         for (int s = 0; s < S; ++s) c += (uint32_t)__popcll(wave_ballot(wkey_hi(key[s]) < dbits));
         return c;
     }
-    __device__ __forceinline__ void mark_expanded(uint32_t pos, uint32_t lane) {
+    // Reading entry e (wave-uniform index) out of the registers means selecting a register by a run-time
+    // slot. Short lists do it with a tree of uniform branches (two readlanes at the leaf). Long lists
+    // (S >= 8) keep a mirror of the list in LDS -- the scatter space of the bulk merge, which holds exactly
+    // the list after every merge -- and read the entry from there: one broadcast ds_read instead of 4*S
+    // scalar selects. The mirror is kept in step by init / set_first / mark_expanded / merge.
+    static constexpr bool MIRROR = S >= 8;
+    uint64_t* mir;
+    template <int LO, int HI>
+    __device__ __forceinline__ uint64_t get_rec(uint32_t slot, uint32_t l) const {
+        if constexpr (HI - LO == 1) {
+            return readlane64(key[LO], l);
+        } else {
+            constexpr int MID = (LO + HI) / 2;
+            return slot < (uint32_t)MID ? get_rec<LO, MID>(slot, l) : get_rec<MID, HI>(slot, l);
+        }
+    }
+    __device__ __forceinline__ uint64_t at(uint32_t e) const {
+        if constexpr (MIRROR) {
+            const uint64_t v = mir[e];
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+            return ((uint64_t)hi << 32) | lo;
+        } else {
+            return get_rec<0, S>(e >> 6, e & 63u);
+        }
+    }
+    template <int LO, int HI>
+    __device__ __forceinline__ void mark_rec(uint32_t slot, bool mine) {
+        if constexpr (HI - LO == 1) {
+            if (mine) key[LO] |= 1ull;
+        } else {
+            constexpr int MID = (LO + HI) / 2;
+            if (slot < (uint32_t)MID) mark_rec<LO, MID>(slot, mine);
+            else mark_rec<MID, HI>(slot, mine);
+        }
+    }
+    // set the expanded flag of entry pos, whose key is x
+    __device__ __forceinline__ void mark_expanded(uint32_t pos, uint64_t x, uint32_t lane) {
+        if constexpr (MIRROR) {
 #pragma unroll
-        for (int s = 0; s < S; ++s)
-            if ((uint32_t)s * 64u + lane == pos) key[s] |= 1ull;
+            for (int s = 0; s < S; ++s) key[s] |= ((uint32_t)s * 64u + lane == pos) ? 1ull : 0ull;
+            if (lane == 0) mir[pos] = x | 1ull;
+        } else {
+            mark_rec<0, S>(pos >> 6, lane == (pos & 63u));
+        }
+    }
+    __device__ __forceinline__ void init_list(uint64_t* mirror, uint32_t lane) {
+        mir = mirror;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            key[s] = KEY_INF;
+            if constexpr (MIRROR) mir[(uint32_t)s * 64u + lane] = KEY_INF;
+        }
+    }
+    // the first entry of an empty list
+    __device__ __forceinline__ void set_first(uint64_t k0, uint32_t lane) {
+        if (lane == 0) {
+            key[0] = k0;
+            if constexpr (MIRROR) mir[0] = k0;
+        }
     }
     // position of the n-th (n >= 1) expanded real entry, WPOS_NONE when there are fewer
     __device__ __forceinline__ uint32_t nth_expanded(uint32_t n) const {
@@ -266,7 +322,7 @@ struct FastWalker {
 
     // the entry that falls off the end of the list: dead unless it ties with entry ef-1
     __device__ __forceinline__ void check_dropped(uint64_t dropped, uint32_t ef) {
-        if (wkey_hi(dropped) != 0xFFFFFFFFu && wkey_hi(dropped) == wkey_hi(L.get(ef - 1))) bail = true;
+        if (wkey_hi(dropped) != 0xFFFFFFFFu && wkey_hi(dropped) == wkey_hi(L.at(ef - 1))) bail = true;
     }
 
     // insert the candidates of the lanes in pm (bulk): every list entry counts the candidates
@@ -307,7 +363,7 @@ struct FastWalker {
 #pragma unroll
         for (int s = 0; s < S; ++s) any = any || lostd[s] != 0xFFFFFFFFu;
         if (wave_ballot(any)) {
-            const uint32_t kth = wkey_hi(L.get(ef - 1));
+            const uint32_t kth = wkey_hi(L.at(ef - 1));
             bool tie = lostc == kth;
 #pragma unroll
             for (int s = 0; s < S; ++s) tie = tie || lostd[s] == kth;
@@ -318,17 +374,25 @@ struct FastWalker {
     // mod.rs:1029-1031 for the candidates of one expansion: `cand` lanes hold (d, id)
     __device__ __forceinline__ void offer(bool cand, float d, uint32_t id, uint32_t ef) {
         const uint32_t dbits = __float_as_uint(d);
-        // `res` does not change during an expansion, so neither do the two thresholds
-        const uint32_t w = L.nth_expanded(ef); // res.peek(): the max_search-th popped node
+        // `res` does not change during an expansion, so neither do the two thresholds:
+        //   theta = dist of entry max_search-1; a candidate beyond it has max_search entries strictly closer: dead;
+        //   worst = res.peek().dist = dist of the max_search-th EXPANDED entry (mod.rs:1029), >= theta.
+        // d <= theta < worst needs no second look; only a candidate that ties with theta can still fail
+        // `d < worst`, and only then is the max_search-th expanded entry looked up.
+        const uint32_t theta = wkey_hi(L.at(ef - 1));
         bool pass = cand;
-        if (w != WPOS_NONE) pass = pass && dbits < wkey_hi(L.get(w)); // d < worst.dist, mod.rs:1029
-        const uint32_t theta = wkey_hi(L.get(ef - 1));
-        if (theta != 0xFFFFFFFFu) pass = pass && dbits <= theta; // else: max_search entries are strictly closer
+        if (theta != 0xFFFFFFFFu) {
+            pass = pass && dbits <= theta;
+            if (wave_ballot(pass && dbits == theta)) {
+                const uint32_t w = L.nth_expanded(ef); // res.peek(): the max_search-th popped node
+                if (w != WPOS_NONE) pass = pass && dbits < wkey_hi(L.at(w));
+            }
+        }
         const uint64_t ck = wkey(d, id);
         uint64_t pm = wave_ballot(pass);
         const uint32_t m = (uint32_t)__popcll(pm);
         if (m == 0) return;
-        if (m >= (S == 1 ? 3u : 2u)) {
+        if (WalkList<S>::MIRROR || m >= (S == 1 ? 3u : 2u)) { // long lists: always the bulk merge (it keeps the LDS mirror)
             merge(pm, m, pass, ck, ef);
             return;
         }
@@ -341,7 +405,7 @@ struct FastWalker {
             if (r >= CAP) {
                 dropped = K;
             } else {
-                dropped = L.get(CAP - 1);
+                dropped = L.at(CAP - 1);
                 L.insert_at(r, K, lane);
             }
             check_dropped(dropped, ef);
@@ -351,7 +415,7 @@ struct FastWalker {
     // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots) {
         vis.reset(vis_tab, slots, lane);
-        L.init();
+        L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;
 
@@ -361,16 +425,18 @@ struct FastWalker {
             vis.count = 1;
             st.n_dist += 1;
             const uint64_t k0 = readlane64(wkey(d0, entrypoint), 1);
-            L.insert_at(0, k0, lane);
+            L.set_first(k0, lane);
         }
         uint32_t pre_id = ID_EMPTY, pre_nb = ID_EMPTY; // adjacency row fetched ahead for the expected next head
 
         for (;;) {
             uint32_t pos;
             if (!L.first_unexpanded(pos)) break;          // pq.pop() on an empty queue, mod.rs:1018
-            const uint64_t x = L.get(pos);
-            if (L.count_closer(wkey_hi(x)) >= ef) break;   // mod.rs:1019-1021
-            L.mark_expanded(pos, lane);                    // res.push((d, idx)), mod.rs:1023
+            const uint64_t x = L.at(pos);
+            // mod.rs:1019-1021. Every entry before x is expanded and at most as far; #{closer} = pos - #{ties
+            // before x}, so the count is only taken when pos alone does not already decide
+            if (pos >= ef && L.count_closer(wkey_hi(x)) >= ef) break;
+            L.mark_expanded(pos, x, lane);                 // res.push((d, idx)), mod.rs:1023
             st.n_expand += 1;
 
             // layer.get_neighbors(idx), mod.rs:1025 / 540-552: row prefix until UNUSED, one id per pair
@@ -386,7 +452,7 @@ struct FastWalker {
                 // candidate of this expansion sorts before it); always one load, so that the wait
                 // counts of the gather below are static
                 uint32_t p2;
-                pre_id = L.first_unexpanded(p2) ? wkey_id(L.get(p2)) : xid;
+                pre_id = L.first_unexpanded(p2) ? wkey_id(L.at(p2)) : xid;
                 pre_nb = adjg[(size_t)pre_id * 32u + R];
             }
             const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
@@ -425,7 +491,7 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
         for (uint32_t l = 0; l < take; ++l) {
             w.search_layer(p.layers[l], 0u, 1u, p.upper_slots);
             if (w.bail) break;
-            const uint32_t found = wkey_id(w.L.get(0));
+            const uint32_t found = wkey_id(w.L.at(0));
             if (lane == l) mine = found;
         }
         w.vis.release(p.ovf, lane);
@@ -442,7 +508,7 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
             const bool bottom = (l + 1 == p.n_layers);
             w.search_layer(Ly, entrypoint, bottom ? p.ef : 1u, bottom ? p.visited_slots : p.upper_slots);
             if (w.bail) break;
-            if (!bottom) entrypoint = wkey_id(w.L.get(0)); // res[0].0, mod.rs:993: the smallest popped key
+            if (!bottom) entrypoint = wkey_id(w.L.at(0)); // res[0].0, mod.rs:993: the smallest popped key
         }
         w.vis.release(p.ovf, lane);
         if (w.bail) { // hand the untouched query to the exact global-memory walker
