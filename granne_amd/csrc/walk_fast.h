@@ -168,9 +168,14 @@ struct FastWalker {
     static constexpr bool F32 = (DT == DT_F32);
     static constexpr int NB = F32 ? DIM / 32 : 0;        // full 32-float chunks of a row
     static constexpr int TU = F32 ? (DIM % 32) / 4 : 0;  // 16-byte units of the tail
-    static constexpr bool QREG = F32 && (NB * 16 + TU * 4 <= 64); // this lane's query pieces live in VGPRs
+    // this lane's query pieces live in VGPRs for the short list; longer lists need the registers and read
+    // the query from LDS (13 ds_read_b128 per expansion at 100-d, issued under the row loads)
+    static constexpr bool QREG = F32 && (NB * 16 + TU * 4 <= 64) && S == 1;
     static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u;
     static constexpr uint32_t CAP = 64u * S;
+    // The next expansion's rows are issued before the merge where their registers (52 VGPRs for 100-d f32) fit
+    // beside the merge's; with longer lists only the (one-register) adjacency fetch is hoisted.
+    static constexpr bool EARLY_ROWS = !F32 || S == 1;
     static_assert(!F32 || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
     const SearchParams& p;
@@ -233,24 +238,36 @@ struct FastWalker {
         }
     }
 
-    // Distances of the (up to 32) rows idl to the query; lanes of a pair pass the same idl. The
-    // visited set is updated under the loads: `fresh` is valid in EVEN lanes (ins_active), the
-    // returned distance in ODD lanes.
-    __device__ __forceinline__ float gather(uint32_t idl, uint32_t ins_id, bool ins_active, bool& fresh) {
-        float d;
+    // The element rows of one expansion in flight: lane (R,h) holds half h of row R.
+    struct RowRegs {
+        float4 v[NB ? NB : 1][4];
+        float4 vt[TU ? TU : 1];
+        uint4 x[4];
+    };
+
+    // Issue every load of the rows idl (lanes of a pair pass the same idl). Nothing is waited for.
+    __device__ __forceinline__ void issue_rows(uint32_t idl, RowRegs& rr) {
         if constexpr (F32) {
             const uint8_t* row = p.elements + (size_t)idl * ROWB;
             const uint8_t* e = row + h * 64u;
-            float4 v[NB][4];
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[b][k] = *reinterpret_cast<const float4*>(e + b * 128 + k * 16);
-            float4 vt[TU ? TU : 1];
+                for (int k = 0; k < 4; ++k) rr.v[b][k] = *reinterpret_cast<const float4*>(e + b * 128 + k * 16);
 #pragma unroll
-            for (int u = 0; u < TU; ++u) vt[u] = *reinterpret_cast<const float4*>(row + NB * 128 + u * 16);
-            asm volatile("" ::: "memory"); // every load above is issued before the set is touched
-            fresh = vis.insert(ins_id, ins_active, p.ovf); // visited.insert(neighbor_idx), mod.rs:1026
+            for (int u = 0; u < TU; ++u) rr.vt[u] = *reinterpret_cast<const float4*>(row + NB * 128 + u * 16);
+        } else {
+            const uint8_t* e = p.elements + (size_t)idl * 128u + h * 64u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr.x[k] = *reinterpret_cast<const uint4*>(e + k * 16);
+        }
+        asm volatile("" ::: "memory"); // the loads are issued here, whatever follows runs under them
+    }
+
+    // Distances of the rows in rr to the query: valid in ODD lanes.
+    __device__ __forceinline__ float finish_rows(const RowRegs& rr) {
+        float d;
+        if constexpr (F32) {
             float acc[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -266,10 +283,10 @@ struct FastWalker {
                         const float4 qq = *reinterpret_cast<const float4*>(lds_q + b * 128 + h * 64u + k * 16);
                         q0 = qq.x; q1 = qq.y; q2 = qq.z; q3 = qq.w;
                     }
-                    acc[k * 4 + 0] = __builtin_fmaf(v[b][k].x, q0, acc[k * 4 + 0]);
-                    acc[k * 4 + 1] = __builtin_fmaf(v[b][k].y, q1, acc[k * 4 + 1]);
-                    acc[k * 4 + 2] = __builtin_fmaf(v[b][k].z, q2, acc[k * 4 + 2]);
-                    acc[k * 4 + 3] = __builtin_fmaf(v[b][k].w, q3, acc[k * 4 + 3]);
+                    acc[k * 4 + 0] = __builtin_fmaf(rr.v[b][k].x, q0, acc[k * 4 + 0]);
+                    acc[k * 4 + 1] = __builtin_fmaf(rr.v[b][k].y, q1, acc[k * 4 + 1]);
+                    acc[k * 4 + 2] = __builtin_fmaf(rr.v[b][k].z, q2, acc[k * 4 + 2]);
+                    acc[k * 4 + 3] = __builtin_fmaf(rr.v[b][k].w, q3, acc[k * 4 + 3]);
                 }
             }
             // ordered sum: even lane 0.0 + acc[0] + ... + acc[15]; odd lane continues with its 16
@@ -288,26 +305,20 @@ struct FastWalker {
                     const float4 qq = *reinterpret_cast<const float4*>(lds_q + NB * 128 + u * 16);
                     q0 = qq.x; q1 = qq.y; q2 = qq.z; q3 = qq.w;
                 }
-                r = __builtin_fmaf(vt[u].x, q0, r);
-                r = __builtin_fmaf(vt[u].y, q1, r);
-                r = __builtin_fmaf(vt[u].z, q2, r);
-                r = __builtin_fmaf(vt[u].w, q3, r);
+                r = __builtin_fmaf(rr.vt[u].x, q0, r);
+                r = __builtin_fmaf(rr.vt[u].y, q1, r);
+                r = __builtin_fmaf(rr.vt[u].z, q2, r);
+                r = __builtin_fmaf(rr.vt[u].w, q3, r);
             }
             d = angular_from_dot(r);
         } else {
-            const uint8_t* e = p.elements + (size_t)idl * 128u + h * 64u;
-            uint4 x[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const uint4*>(e + k * 16);
-            asm volatile("" ::: "memory");
-            fresh = vis.insert(ins_id, ins_active, p.ovf);
             int r = 0, dx = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                r = dot4_i8(x[k].x, qi8[k].x, r); r = dot4_i8(x[k].y, qi8[k].y, r);
-                r = dot4_i8(x[k].z, qi8[k].z, r); r = dot4_i8(x[k].w, qi8[k].w, r);
-                dx = dot4_i8(x[k].x, x[k].x, dx); dx = dot4_i8(x[k].y, x[k].y, dx);
-                dx = dot4_i8(x[k].z, x[k].z, dx); dx = dot4_i8(x[k].w, x[k].w, dx);
+                r = dot4_i8(rr.x[k].x, qi8[k].x, r); r = dot4_i8(rr.x[k].y, qi8[k].y, r);
+                r = dot4_i8(rr.x[k].z, qi8[k].z, r); r = dot4_i8(rr.x[k].w, qi8[k].w, r);
+                dx = dot4_i8(rr.x[k].x, rr.x[k].x, dx); dx = dot4_i8(rr.x[k].y, rr.x[k].y, dx);
+                dx = dot4_i8(rr.x[k].z, rr.x[k].z, dx); dx = dot4_i8(rr.x[k].w, rr.x[k].w, dx);
             }
             r += pair_swap(r);
             dx += pair_swap(dx);
@@ -371,8 +382,8 @@ struct FastWalker {
         }
     }
 
-    // mod.rs:1029-1031 for the candidates of one expansion: `cand` lanes hold (d, id)
-    __device__ __forceinline__ void offer(bool cand, float d, uint32_t id, uint32_t ef) {
+    // mod.rs:1029 for the candidates of one expansion (`cand` lanes hold a distance): which of them enter the list
+    __device__ __forceinline__ bool filter(bool cand, float d, uint32_t ef) {
         const uint32_t dbits = __float_as_uint(d);
         // `res` does not change during an expansion, so neither do the two thresholds:
         //   theta = dist of entry max_search-1; a candidate beyond it has max_search entries strictly closer: dead;
@@ -388,8 +399,11 @@ struct FastWalker {
                 if (w != WPOS_NONE) pass = pass && dbits < wkey_hi(L.at(w));
             }
         }
-        const uint64_t ck = wkey(d, id);
-        uint64_t pm = wave_ballot(pass);
+        return pass;
+    }
+
+    // pq.push (mod.rs:1030) of the lanes in pm
+    __device__ __forceinline__ void insert(uint64_t pm, bool pass, uint64_t ck, uint32_t ef) {
         const uint32_t m = (uint32_t)__popcll(pm);
         if (m == 0) return;
         if (WalkList<S>::MIRROR || m >= (S == 1 ? 3u : 2u)) { // long lists: always the bulk merge (it keeps the LDS mirror)
@@ -412,65 +426,121 @@ struct FastWalker {
         }
     }
 
-    // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries
+    // Neighbor row `nb` (one id per pair, UNUSED-terminated) -> issue the gather of its rows. Returns the
+    // number of valid ids (mod.rs:540-552: prefix until UNUSED).
+    __device__ __forceinline__ uint32_t start_expansion(uint32_t nb, RowRegs& rr) {
+        const uint64_t unused = wave_ballot(nb == ID_EMPTY);
+        const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
+        if (nvalid) {
+            const uint32_t last_id = readlane32(nb, 2u * (nvalid - 1u));
+            issue_rows((R < nvalid) ? nb : last_id, rr); // lanes beyond the row re-read its last neighbor
+        }
+        return nvalid;
+    }
+
+    // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
+    //
+    // The loop is software-pipelined around the one thing that is known early: once the distances of an
+    // expansion are in, the NEXT node to expand is decided before the candidates are merged -- it is the
+    // smallest of (the list's first unexpanded entry y, the candidates that pass the filter), because
+    // merging changes nothing that sorts before that minimum. So the first memory operation of the next
+    // expansion (y's rows when its adjacency row was fetched ahead, else the adjacency row of the winning
+    // candidate) is issued BEFORE the merge and runs under it. Nothing is speculative: every load issued
+    // is a load the walk needs, except the single expansion a terminating walk has in flight.
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots) {
         vis.reset(vis_tab, slots, lane);
         L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;
+        RowRegs rr;
 
-        {   // distance to the entry point (mod.rs:1012-1016)
-            bool fresh0;
-            const float d0 = gather(entrypoint, entrypoint, lane == 0, fresh0);
-            vis.count = 1;
-            st.n_dist += 1;
-            const uint64_t k0 = readlane64(wkey(d0, entrypoint), 1);
-            L.set_first(k0, lane);
-        }
-        uint32_t pre_id = ID_EMPTY, pre_nb = ID_EMPTY; // adjacency row fetched ahead for the expected next head
+        // distance to the entry point (mod.rs:1012-1016); pq.pop() returns it, res.push, its row is read
+        issue_rows(entrypoint, rr);
+        uint32_t nb = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
+        vis.insert(entrypoint, lane == 0, p.ovf);
+        vis.count = 1;
+        const float d0 = finish_rows(rr);
+        st.n_dist += 1;
+        const uint64_t k0 = readlane64(wkey(d0, entrypoint), 1);
+        L.set_first(k0 | 1ull, lane); // popped at once: an empty res takes it, nothing precedes it (mod.rs:1018-1023)
+        st.n_expand += 1;
+        uint32_t nvalid = start_expansion(nb, rr);
+        st.n_adj += nvalid;
+        uint32_t pre_id = ID_EMPTY, pre_nb = ID_EMPTY; // adjacency row fetched ahead for the first unexpanded entry
 
         for (;;) {
-            uint32_t pos;
-            if (!L.first_unexpanded(pos)) break;          // pq.pop() on an empty queue, mod.rs:1018
-            const uint64_t x = L.at(pos);
-            // mod.rs:1019-1021. Every entry before x is expanded and at most as far; #{closer} = pos - #{ties
-            // before x}, so the count is only taken when pos alone does not already decide
-            if (pos >= ef && L.count_closer(wkey_hi(x)) >= ef) break;
-            L.mark_expanded(pos, x, lane);                 // res.push((d, idx)), mod.rs:1023
-            st.n_expand += 1;
-
-            // layer.get_neighbors(idx), mod.rs:1025 / 540-552: row prefix until UNUSED, one id per pair
-            const uint32_t xid = wkey_id(x);
-            uint32_t nb;
-            if (pre_id == xid) nb = pre_nb;
-            else nb = adjg[(size_t)xid * 32u + R];
-            const uint64_t unused = wave_ballot(nb == ID_EMPTY);
-            // The row has been waited for; the fetch-ahead below must not be hoisted above that wait
-            // (loads return in order: a younger load in flight would turn the wait into a full drain).
-            asm volatile("" ::"s"(unused) : "memory");
-            {   // fetch ahead the row of the node that is the head now (it stays the head unless a
-                // candidate of this expansion sorts before it); always one load, so that the wait
-                // counts of the gather below are static
-                uint32_t p2;
-                pre_id = L.first_unexpanded(p2) ? wkey_id(L.at(p2)) : xid;
-                pre_nb = adjg[(size_t)pre_id * 32u + R];
-            }
-            const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
-            st.n_adj += nvalid;
+            // ---- the expansion in flight: visited set under the loads, then the distances (mod.rs:1026-1027)
+            bool cand = false;
+            float d = 0.0f;
             if (nvalid) {
-                const uint32_t last_id = readlane32(nb, 2u * (nvalid - 1u));
-                const uint32_t idl = (R < nvalid) ? nb : last_id; // lanes beyond the row re-read its last neighbor
-                bool fresh;
-                const float d = gather(idl, nb, h == 0u && R < nvalid, fresh); // mod.rs:1026-1027
+                const bool fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
+                d = finish_rows(rr);
                 const uint64_t fm = wave_ballot(fresh);
                 const uint32_t mf = (uint32_t)__popcll(fm);
                 vis.added(mf);
                 st.n_dist += mf;
-                const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
-                offer(cand, d, nb, ef);
+                cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
             }
             if (!vis.make_room(p.ovf, lane)) bail = true;
             if (bail) return;
+            const bool pass = filter(cand, d, ef);
+            const uint64_t ck = wkey(d, nb);
+            const uint64_t pm = wave_ballot(pass);
+
+            // ---- who is expanded next?
+            uint32_t ypos = 0;
+            const bool has_y = L.first_unexpanded(ypos);
+            const uint64_t ykey = has_y ? L.at(ypos) : KEY_INF;
+            uint64_t beat = wave_ballot(pass && ck < ykey); // ykey = KEY_INF: every passing candidate
+            uint32_t next_id;
+            bool adj_known = false;
+            uint32_t nb_next = ID_EMPTY;
+            if (beat) {
+                uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
+                for (;;) { // the smallest passing key (usually one or two rounds)
+                    beat = wave_ballot(pass && ck < K);
+                    if (!beat) break;
+                    K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
+                }
+                next_id = wkey_id(K); // it passed `d <= theta`: fewer than max_search entries are closer, no break
+                nb_next = adjg[(size_t)next_id * 32u + R];
+            } else {
+                if (!has_y) break; // pq.pop() on an empty queue, mod.rs:1018 (candidates that sort after nothing: none)
+                // mod.rs:1019-1021 for y. Every entry before y is expanded and at most as far; #{closer} =
+                // ypos - #{ties before y}, so the count is only taken when ypos alone does not decide. No
+                // candidate of this expansion sorts before y: the merge below changes neither number.
+                if (ypos >= ef && L.count_closer(wkey_hi(ykey)) >= ef) break;
+                next_id = wkey_id(ykey);
+                if (pre_id == next_id) {
+                    nb_next = pre_nb;
+                    adj_known = EARLY_ROWS;
+                } else {
+                    nb_next = adjg[(size_t)next_id * 32u + R];
+                }
+            }
+            uint32_t nvalid_next = 0;
+            if (adj_known) nvalid_next = start_expansion(nb_next, rr); // the next gather runs under the merge
+
+            // ---- pq.push of this expansion's candidates (mod.rs:1029-1031)
+            insert(pm, pass, ck, ef);
+            if (bail) return;
+
+            // ---- pq.pop() + res.push of the next node (mod.rs:1018-1023): it is the first unexpanded entry now
+            uint32_t pos = 0;
+            L.first_unexpanded(pos);
+            const uint64_t x = L.at(pos);
+            L.mark_expanded(pos, x, lane);
+            st.n_expand += 1;
+            if (!adj_known) nvalid_next = start_expansion(nb_next, rr); // waits for the adjacency row issued before the merge
+            st.n_adj += nvalid_next;
+            {   // fetch ahead the adjacency row of the entry that is first in line now (it is expanded next unless
+                // a candidate of the coming expansion sorts before it); always one load: static wait counts
+                uint32_t p2;
+                pre_id = L.first_unexpanded(p2) ? wkey_id(L.at(p2)) : next_id;
+                pre_nb = adjg[(size_t)pre_id * 32u + R];
+            }
+            nb = nb_next;
+            nvalid = nvalid_next;
         }
     }
 };
@@ -555,10 +625,13 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
 }
 
 // Block b walks query b (one wavefront). LDS: [query][CAP keys of merge space][visited front table].
-// waves per SIMD the register allocator is asked to keep possible (__launch_bounds__'s second
-// argument is per SIMD on AMD): i8 5 (<= 96 VGPRs), f32 3 (<= 168), long lists and long rows 2
+// waves per SIMD the register allocator is asked to keep possible (__launch_bounds__'s second argument is
+// per SIMD on AMD; 5 waves = 96 VGPRs, 4 = 128, 3 = 168, 2 = 256). Chosen from the unconstrained
+// allocation of each instantiation so that none spills (tools/isa_report.py prints both).
 constexpr int fast_waves_per_simd(int DT, int DIM, int S) {
-    return S >= 8 ? 2 : (DT == DT_I8 ? (S <= 2 ? 5 : 4) : ((DIM > 128 && S > 1) ? 2 : 3));
+    if (DT == DT_I8) return S == 1 ? 5 : S <= 4 ? 4 : S == 8 ? 3 : 2;
+    if (DIM > 128) return S == 1 ? 3 : 2;
+    return S == 1 ? 3 : S == 2 ? 4 : S <= 8 ? 3 : 2;
 }
 
 template <int DT, int DIM, int S, bool TRAIL = false>

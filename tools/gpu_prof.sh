@@ -9,7 +9,7 @@ PASSES=${2:-"trace pmc1 pmc3 pmc4"}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 10 --cpu-batches 0 --no-recall ${BENCH_ARGS:-}"
+BENCH="python $ROOT/bench.py --steps 10 --cpu-batches 0 --no-recall --no-extras ${BENCH_ARGS:-}"
 cd /tmp
 for P in $PASSES; do
   case $P in

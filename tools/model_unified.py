@@ -45,20 +45,14 @@ def reference(adj, dist, ep, ef):
 
 
 def unified(adj, dist, ep, ef, cap):
-    L = [[dist(ep), ep, False]]  # ascending by (dist, id); third field = expanded
+    """The list walker with walk_fast.h's control flow: the next node is decided (and its break test
+    taken) BEFORE the candidates of the current expansion are merged."""
+    L = [[dist(ep), ep, True]]  # ascending by (dist, id); third field = expanded. The entry point is popped at once
     visited = {ep}
-    n_dist, n_expand, n_adj = 1, 0, 0
+    n_dist, n_expand, n_adj = 1, 1, len(adj[ep])
+    x = ep
     while True:
-        p = next((i for i, e in enumerate(L) if not e[2]), None)
-        if p is None:
-            break
-        dx, x = L[p][0], L[p][1]
-        if sum(1 for e in L if e[0] < dx) >= ef:
-            break
-        L[p][2] = True
-        n_expand += 1
-        n_adj += len(adj[x])
-        # the filter of this expansion is frozen (res does not change during an expansion)
+        # expansion of x (already flagged): the filter is frozen (res does not change during an expansion)
         exp = [e for e in L if e[2]]
         worst = exp[ef - 1][0] if len(exp) >= ef else None
         theta = L[ef - 1][0] if len(L) >= ef else None
@@ -73,6 +67,18 @@ def unified(adj, dist, ep, ef, cap):
                 if theta is not None and dn > theta:
                     continue  # dead: max_search entries are strictly closer
                 cands.append((dn, n))
+        # who is next? (before the merge)
+        ypos = next((i for i, e in enumerate(L) if not e[2]), None)
+        ykey = (L[ypos][0], L[ypos][1]) if ypos is not None else (float("inf"), 1 << 62)
+        beat = [c for c in cands if c < ykey]
+        if beat:
+            nxt = min(beat)[1]
+        else:
+            if ypos is None:
+                break
+            if ypos >= ef and sum(1 for e in L if e[0] < ykey[0]) >= ef:
+                break
+            nxt = ykey[1]
         for dn, n in cands:
             keys = [(e[0], e[1]) for e in L]
             L.insert(bisect.bisect_left(keys, (dn, n)), [dn, n, False])
@@ -80,6 +86,12 @@ def unified(adj, dist, ep, ef, cap):
                 y = L.pop()
                 if y[0] == L[ef - 1][0]:
                     return None, None  # bail: not provably dead
+        p = next(i for i, e in enumerate(L) if not e[2])
+        assert L[p][1] == nxt, "the decision taken before the merge must name the first unexpanded entry after it"
+        L[p][2] = True
+        x = nxt
+        n_expand += 1
+        n_adj += len(adj[x])
     exp = [(e[0], e[1]) for e in L if e[2]]
     return exp[:ef], (n_dist, n_expand, n_adj)
 
