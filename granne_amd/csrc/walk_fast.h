@@ -426,16 +426,16 @@ struct FastWalker {
         }
     }
 
-    // Neighbor row `nb` (one id per pair, UNUSED-terminated) -> issue the gather of its rows. Returns the
-    // number of valid ids (mod.rs:540-552: prefix until UNUSED).
-    __device__ __forceinline__ uint32_t start_expansion(uint32_t nb, RowRegs& rr) {
-        const uint64_t unused = wave_ballot(nb == ID_EMPTY);
-        const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
-        if (nvalid) {
-            const uint32_t last_id = readlane32(nb, 2u * (nvalid - 1u));
-            issue_rows((R < nvalid) ? nb : last_id, rr); // lanes beyond the row re-read its last neighbor
-        }
-        return nvalid;
+    // pq.push of an expansion's candidates (mod.rs:1029-1031), then pq.pop() + res.push of the next node
+    // (mod.rs:1018-1023): after the merge it is the first unexpanded entry of the list
+    __device__ __forceinline__ void merge_and_pop(uint64_t pm, bool pass, uint64_t ck, uint32_t ef) {
+        insert(pm, pass, ck, ef);
+        if (bail) return;
+        uint32_t pos = 0;
+        L.first_unexpanded(pos);
+        const uint64_t x = L.at(pos);
+        L.mark_expanded(pos, x, lane);
+        st.n_expand += 1;
     }
 
     // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
@@ -444,57 +444,83 @@ struct FastWalker {
     // expansion are in, the NEXT node to expand is decided before the candidates are merged -- it is the
     // smallest of (the list's first unexpanded entry y, the candidates that pass the filter), because
     // merging changes nothing that sorts before that minimum. So the first memory operation of the next
-    // expansion (y's rows when its adjacency row was fetched ahead, else the adjacency row of the winning
-    // candidate) is issued BEFORE the merge and runs under it. Nothing is speculative: every load issued
-    // is a load the walk needs, except the single expansion a terminating walk has in flight.
+    // expansion is issued BEFORE the merge and runs under it: y's element rows when y's adjacency row was
+    // fetched ahead (the merge then follows the row loads), else the adjacency row of the winning
+    // candidate (the merge then precedes the row loads). Nothing is speculative: every load issued is a
+    // load the walk needs. The row loads have ONE site in the loop -- two sites would meet in a phi and the
+    // register copies at the join would wait for the data right after issuing it.
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots) {
         vis.reset(vis_tab, slots, lane);
         L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;
-        RowRegs rr;
 
-        // distance to the entry point (mod.rs:1012-1016); pq.pop() returns it, res.push, its row is read
-        issue_rows(entrypoint, rr);
-        uint32_t nb = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
-        vis.insert(entrypoint, lane == 0, p.ovf);
-        vis.count = 1;
-        const float d0 = finish_rows(rr);
-        st.n_dist += 1;
-        const uint64_t k0 = readlane64(wkey(d0, entrypoint), 1);
-        L.set_first(k0 | 1ull, lane); // popped at once: an empty res takes it, nothing precedes it (mod.rs:1018-1023)
-        st.n_expand += 1;
-        uint32_t nvalid = start_expansion(nb, rr);
-        st.n_adj += nvalid;
+        // state handed from one expansion to the next
+        uint32_t next_id = entrypoint;   // the node popped next
+        uint32_t nb_next;                // its adjacency row, one id per pair (maybe still in flight)
+        bool adj_known = false;          // true: nb_next was fetched ahead, the rows go out before the merge
+        bool pass = false;               // candidates of the finished expansion that enter the list
+        uint64_t ck = 0;
+        uint64_t pm = 0;
         uint32_t pre_id = ID_EMPTY, pre_nb = ID_EMPTY; // adjacency row fetched ahead for the first unexpanded entry
 
+        {   // distance to the entry point (mod.rs:1012-1016); the first pop of the loop takes it
+            RowRegs r0;
+            issue_rows(entrypoint, r0);
+            nb_next = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
+            vis.insert(entrypoint, lane == 0, p.ovf);
+            vis.count = 1;
+            const float d0 = finish_rows(r0);
+            st.n_dist += 1;
+            L.set_first(readlane64(wkey(d0, entrypoint), 1), lane);
+        }
+
+        RowRegs rr;
         for (;;) {
-            // ---- the expansion in flight: visited set under the loads, then the distances (mod.rs:1026-1027)
-            bool cand = false;
-            float d = 0.0f;
-            if (nvalid) {
-                const bool fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
-                d = finish_rows(rr);
-                const uint64_t fm = wave_ballot(fresh);
-                const uint32_t mf = (uint32_t)__popcll(fm);
-                vis.added(mf);
-                st.n_dist += mf;
-                cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
+            // ---- A: the adjacency row of the next node is still in flight: merge and pop under it
+            if (!adj_known) {
+                merge_and_pop(pm, pass, ck, ef);
+                if (bail) return;
             }
+            // ---- B: layer.get_neighbors (mod.rs:1025 / 540-552: prefix until UNUSED) and the row loads -- the one site
+            const uint32_t nb = nb_next;
+            const uint64_t unused = wave_ballot(nb == ID_EMPTY);
+            const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
+            {   // lanes beyond the row re-read its last neighbor (an empty row: the node itself)
+                const uint32_t last_id = nvalid ? readlane32(nb, 2u * (nvalid - 1u)) : next_id;
+                issue_rows((R < nvalid) ? nb : last_id, rr);
+            }
+            // ---- C: the adjacency row was fetched ahead: merge and pop under the row loads
+            if (adj_known) {
+                merge_and_pop(pm, pass, ck, ef);
+                if (bail) return;
+            }
+            st.n_adj += nvalid;
+            {   // fetch ahead the adjacency row of the entry that is first in line now (it is expanded next unless
+                // a candidate of this expansion sorts before it); always one load: static wait counts
+                uint32_t p2;
+                pre_id = L.first_unexpanded(p2) ? wkey_id(L.at(p2)) : next_id;
+                pre_nb = adjg[(size_t)pre_id * 32u + R];
+            }
+            // ---- D: visited set under the loads, then the distances (mod.rs:1026-1027)
+            const bool fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
+            const float d = finish_rows(rr);
+            const uint64_t fm = wave_ballot(fresh);
+            const uint32_t mf = (uint32_t)__popcll(fm);
+            vis.added(mf);
+            st.n_dist += mf;
+            const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
             if (!vis.make_room(p.ovf, lane)) bail = true;
             if (bail) return;
-            const bool pass = filter(cand, d, ef);
-            const uint64_t ck = wkey(d, nb);
-            const uint64_t pm = wave_ballot(pass);
+            pass = filter(cand, d, ef);
+            ck = wkey(d, nb);
+            pm = wave_ballot(pass);
 
-            // ---- who is expanded next?
+            // ---- E: who is expanded next? Its first load is issued here, before the merge
             uint32_t ypos = 0;
             const bool has_y = L.first_unexpanded(ypos);
             const uint64_t ykey = has_y ? L.at(ypos) : KEY_INF;
             uint64_t beat = wave_ballot(pass && ck < ykey); // ykey = KEY_INF: every passing candidate
-            uint32_t next_id;
-            bool adj_known = false;
-            uint32_t nb_next = ID_EMPTY;
             if (beat) {
                 uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
                 for (;;) { // the smallest passing key (usually one or two rounds)
@@ -503,44 +529,23 @@ struct FastWalker {
                     K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
                 }
                 next_id = wkey_id(K); // it passed `d <= theta`: fewer than max_search entries are closer, no break
+                adj_known = false;
                 nb_next = adjg[(size_t)next_id * 32u + R];
             } else {
-                if (!has_y) break; // pq.pop() on an empty queue, mod.rs:1018 (candidates that sort after nothing: none)
+                if (!has_y) break; // pq.pop() on an empty queue, mod.rs:1018
                 // mod.rs:1019-1021 for y. Every entry before y is expanded and at most as far; #{closer} =
                 // ypos - #{ties before y}, so the count is only taken when ypos alone does not decide. No
-                // candidate of this expansion sorts before y: the merge below changes neither number.
+                // candidate of this expansion sorts before y: the pending merge changes neither number.
                 if (ypos >= ef && L.count_closer(wkey_hi(ykey)) >= ef) break;
                 next_id = wkey_id(ykey);
-                if (pre_id == next_id) {
+                if (EARLY_ROWS && pre_id == next_id) {
+                    adj_known = true;
                     nb_next = pre_nb;
-                    adj_known = EARLY_ROWS;
                 } else {
-                    nb_next = adjg[(size_t)next_id * 32u + R];
+                    adj_known = false;
+                    nb_next = (pre_id == next_id) ? pre_nb : adjg[(size_t)next_id * 32u + R];
                 }
             }
-            uint32_t nvalid_next = 0;
-            if (adj_known) nvalid_next = start_expansion(nb_next, rr); // the next gather runs under the merge
-
-            // ---- pq.push of this expansion's candidates (mod.rs:1029-1031)
-            insert(pm, pass, ck, ef);
-            if (bail) return;
-
-            // ---- pq.pop() + res.push of the next node (mod.rs:1018-1023): it is the first unexpanded entry now
-            uint32_t pos = 0;
-            L.first_unexpanded(pos);
-            const uint64_t x = L.at(pos);
-            L.mark_expanded(pos, x, lane);
-            st.n_expand += 1;
-            if (!adj_known) nvalid_next = start_expansion(nb_next, rr); // waits for the adjacency row issued before the merge
-            st.n_adj += nvalid_next;
-            {   // fetch ahead the adjacency row of the entry that is first in line now (it is expanded next unless
-                // a candidate of the coming expansion sorts before it); always one load: static wait counts
-                uint32_t p2;
-                pre_id = L.first_unexpanded(p2) ? wkey_id(L.at(p2)) : next_id;
-                pre_nb = adjg[(size_t)pre_id * 32u + R];
-            }
-            nb = nb_next;
-            nvalid = nvalid_next;
         }
     }
 };
