@@ -560,6 +560,10 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         // holds is better off with small tables (more walkers per CU; measured on the 10M build:
         // 37.7 s vs 45.4 s), one batch of a thousand queries with fewer spills (ef 200: 508k vs 421k q/s)
         uint32_t cap = nq >= 4096 ? 4096u : 8192u;
+        // long lists (max_search > 252) walk ~20x max_search nodes: most inserts land in the overflow table
+        // whatever the front table's size, and a 32 KB front table beside the list's LDS mirror leaves room
+        // for only three walkers per CU (768 of a batch of 1024 resident: the batch runs in two rounds)
+        if (fastS >= 8) cap = 4096u;
         if (const char* e = getenv("GRANNE_HIP_VISITED_CAP")) cap = next_pow2((uint32_t)atoi(e)); // experiments
         if (cap < 1024) cap = 1024;
         if (cap > 32768) cap = 32768;
