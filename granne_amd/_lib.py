@@ -115,7 +115,7 @@ def lib():
     """The loaded library. Raises if it has not been built (python -m granne_amd.build)."""
     global _lib
     if _lib is None:
-        path = _build.LIB_PATH
+        path = os.environ.get("GRANNE_HIP_LIB") or _build.LIB_PATH  # GRANNE_HIP_LIB: kernel experiments (tools/sweep.py)
         if not os.path.exists(path):
             raise GranneHipError(ERR_NO_DEVICE, "libgranne_hip.so is not built: run `python -m granne_amd.build` "
                                  "(no CPU fallback exists)")

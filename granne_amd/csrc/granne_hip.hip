@@ -531,17 +531,22 @@ static search_fn pick_fast_s(uint32_t S, bool trail) {
     case 2: return fast_kernel<DT, DIM, 2>;
     case 4: return fast_kernel<DT, DIM, 4>;
     case 8: return fast_kernel<DT, DIM, 8>;
-    default: return fast_kernel<DT, DIM, 17>;
+    default:
+        if constexpr (DT == DT_F32 && DIM == 0) return fast_kernel<DT, DIM, 8>; // not reached: max_search <= 508 there
+        else return fast_kernel<DT, DIM, 17>;
     }
 }
 static bool fast_shape(const SearchTarget* ix) {
     if (ix->max_dev_width != 32 || ix->n_elements > WALK_MAX_ELEMENTS) return false;
     if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128;
-    return (ix->dim == 100 || ix->dim == 200) && ix->row_bytes == ix->dim * 4;
+    return ix->dim >= 32; // 100 and 200 fully unrolled, any other dim with at least one 32-float chunk streamed
 }
+static bool fast_generic(const SearchTarget* ix) { return ix->dtype == GRANNE_HIP_F32 && ix->dim != 100 && ix->dim != 200; }
 static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail) {
     if (ix->dtype == GRANNE_HIP_I8) return pick_fast_s<DT_I8, 0>(S, trail);
-    return ix->dim == 100 ? pick_fast_s<DT_F32, 100>(S, trail) : pick_fast_s<DT_F32, 200>(S, trail);
+    if (ix->dim == 100) return pick_fast_s<DT_F32, 100>(S, trail);
+    if (ix->dim == 200) return pick_fast_s<DT_F32, 200>(S, trail);
+    return pick_fast_s<DT_F32, 0>(S, trail);
 }
 
 struct LaunchPlan {
@@ -576,7 +581,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         P.lrow_bytes = 16;
         P.stage_bytes = 0;
         P.adjspec_bytes = 0;
-        P.lds_bytes = fast_lds_bytes(ix->row_bytes, fastS, P.visited_slots);
+        P.lds_bytes = fast_lds_bytes(fast_generic(ix), ix->dim, ix->row_bytes, fastS, P.visited_slots);
         return P;
     }
     const bool reg_spec = false; // (the compile-time-dim f32 kernels moved to walk_fast.h)
@@ -632,7 +637,8 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     }
     if (!d_queries || (!d_trail && (!d_ids || !d_dists || !d_counts))) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
 
-    const bool fast = fast_shape(ix) && ef <= FAST_MAX_SEARCH;
+    // (the streamed run-time-dim walker is instantiated up to 8 x 64 keys: beyond that the exact walker)
+    const bool fast = fast_shape(ix) && ef <= (fast_generic(ix) ? 508u : FAST_MAX_SEARCH);
     const uint32_t fastS = fast ? fast_list_slots(ef) : 0u;
     const uint32_t ef_walk = fast ? ef : (ef > 256 ? 256 : ef); // what the register/LDS walker is sized for
     const bool all_slow = ix->opt_force_slow || (!fast && ef > 256);

@@ -163,20 +163,36 @@ struct WalkList : SortedList<S> {
     }
 };
 
+// LDS bytes of the query. Compile-time dims and i8: the row itself. Run-time f32 dims (DIM == 0): full
+// 32-float chunks padded with zero chunks to a whole number of groups of three, then one 128-byte tail block.
+constexpr uint32_t GEN_GROUP = 3; // chunks whose loads are in flight together (12 x 16 bytes per lane)
+__host__ __device__ inline uint32_t fast_query_bytes(bool gen, uint32_t dim, uint32_t row_bytes) {
+    if (!gen) return lds_query_bytes(row_bytes);
+    const uint32_t nbk = dim / 32u;
+    const uint32_t ngroups = (nbk + GEN_GROUP - 1u) / GEN_GROUP;
+    return ngroups * GEN_GROUP * 128u + 128u;
+}
+
 template <int DT, int DIM, int S>
 struct FastWalker {
     static constexpr bool F32 = (DT == DT_F32);
-    static constexpr int NB = F32 ? DIM / 32 : 0;        // full 32-float chunks of a row
+    // DIM == 0: any f32 dim >= 32, known at run time. The chunks stream through the registers in groups of
+    // GEN_GROUP (the first group's loads are the ones issued ahead), the query is read from LDS.
+    static constexpr bool GEN = F32 && DIM == 0;
+    static constexpr int NB = F32 ? (GEN ? (int)GEN_GROUP : DIM / 32) : 0; // full 32-float chunks (GEN: per group)
     static constexpr int TU = F32 ? (DIM % 32) / 4 : 0;  // 16-byte units of the tail
     // this lane's query pieces live in VGPRs for the short list; longer lists need the registers and read
     // the query from LDS (13 ds_read_b128 per expansion at 100-d, issued under the row loads)
-    static constexpr bool QREG = F32 && (NB * 16 + TU * 4 <= 64) && S == 1;
+#ifndef GRANNE_HIP_QUERY_IN_LDS
+#define GRANNE_HIP_QUERY_IN_LDS 0 // experiments: 1 = the short list reads the query from LDS too
+#endif
+    static constexpr bool QREG = F32 && !GEN && (NB * 16 + TU * 4 <= 64) && S == 1 && !GRANNE_HIP_QUERY_IN_LDS;
     static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u;
     static constexpr uint32_t CAP = 64u * S;
     // The next expansion's rows are issued before the merge where their registers (52 VGPRs for 100-d f32) fit
     // beside the merge's; with longer lists only the (one-register) adjacency fetch is hoisted.
     static constexpr bool EARLY_ROWS = !F32 || S == 1;
-    static_assert(!F32 || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
+    static_assert(!F32 || GEN || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
     const SearchParams& p;
     uint32_t lane, h, R;
@@ -187,6 +203,7 @@ struct FastWalker {
     float qt[(QREG && TU) ? TU * 4 : 1];
     uint4 qi8[F32 ? 1 : 4]; // i8: bytes 64h..64h+63 of the query
     float sy;               // i8: sqrt(sum of squares of the query) as f32
+    uint32_t g_nbk, g_ngroups, g_tu; // GEN: full chunks, groups of them, 16-byte units of the (zero padded) tail
     VisitedSet vis;
     WalkList<S> L;
     WalkStats st;
@@ -196,7 +213,10 @@ struct FastWalker {
         lane = threadIdx.x;
         h = lane & 1u;
         R = lane >> 1;
-        const uint32_t qb = lds_query_bytes(p.row_bytes);
+        const uint32_t qb = fast_query_bytes(GEN, p.dim, p.row_bytes);
+        g_nbk = p.dim / 32u;
+        g_ngroups = (g_nbk + GEN_GROUP - 1u) / GEN_GROUP;
+        g_tu = ((p.dim & 31u) + 3u) / 4u;
         lds_q = smem;
         mslot = reinterpret_cast<uint64_t*>(smem + qb);
         vis_tab = reinterpret_cast<uint32_t*>(smem + qb + CAP * 8u);
@@ -216,6 +236,12 @@ struct FastWalker {
                     for (int j = 0; j < 16; ++j) qh[b * 16 + j] = q[b * 32 + h * 16 + j];
 #pragma unroll
                 for (int j = 0; j < TU * 4; ++j) qt[j] = q[NB * 32 + j];
+            } else if constexpr (GEN) {
+                float* l = reinterpret_cast<float*>(lds_q);
+                const uint32_t full = g_nbk * 32u, padded = g_ngroups * GEN_GROUP * 32u;
+                for (uint32_t i = lane; i < padded; i += 64) l[i] = (i < full) ? q[i] : 0.0f;
+                if (lane < 32u) l[padded + lane] = (full + lane < p.dim) ? q[full + lane] : 0.0f;
+                __syncthreads();
             } else {
                 float* l = reinterpret_cast<float*>(lds_q);
                 for (uint32_t i = lane; i < (uint32_t)DIM; i += 64) l[i] = q[i];
@@ -243,11 +269,27 @@ struct FastWalker {
         float4 v[NB ? NB : 1][4];
         float4 vt[TU ? TU : 1];
         uint4 x[4];
+        const uint8_t* row; // GEN: the row, for the groups and the tail that finish_rows loads itself
     };
+
+    // GEN: the loads of chunks 3g..3g+2 of the row (chunks past the row's last re-read the last one; their
+    // query chunk in LDS is zero, so they add +-0 to accumulators whose zero sign never reaches the result)
+    __device__ __forceinline__ void load_group(RowRegs& rr, uint32_t g) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const uint32_t blk = min(g * GEN_GROUP + (uint32_t)b, g_nbk - 1u);
+            const uint8_t* e = rr.row + (size_t)blk * 128u + h * 64u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rr.v[b][k] = *reinterpret_cast<const float4*>(e + k * 16);
+        }
+    }
 
     // Issue every load of the rows idl (lanes of a pair pass the same idl). Nothing is waited for.
     __device__ __forceinline__ void issue_rows(uint32_t idl, RowRegs& rr) {
-        if constexpr (F32) {
+        if constexpr (GEN) {
+            rr.row = p.elements + (size_t)idl * p.row_bytes;
+            load_group(rr, 0u);
+        } else if constexpr (F32) {
             const uint8_t* row = p.elements + (size_t)idl * ROWB;
             const uint8_t* e = row + h * 64u;
 #pragma unroll
@@ -265,9 +307,51 @@ struct FastWalker {
     }
 
     // Distances of the rows in rr to the query: valid in ODD lanes.
-    __device__ __forceinline__ float finish_rows(const RowRegs& rr) {
+    __device__ __forceinline__ float finish_rows(RowRegs& rr) {
         float d;
-        if constexpr (F32) {
+        if constexpr (GEN) {
+            // the tail (dim % 32 floats, zero padded to 16-byte units) is read by every lane, used by the odd one
+            float4 vt[8];
+            const uint8_t* tailp = rr.row + (size_t)g_nbk * 128u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if ((uint32_t)u < g_tu) vt[u] = *reinterpret_cast<const float4*>(tailp + u * 16);
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+            for (uint32_t g = 0; g < g_ngroups; ++g) {
+                if (g > 0) load_group(rr, g); // group 0 was issued by issue_rows
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 qq = *reinterpret_cast<const float4*>(lds_q + (size_t)(g * GEN_GROUP + (uint32_t)b) * 128u + h * 64u + k * 16);
+                        acc[k * 4 + 0] = __builtin_fmaf(rr.v[b][k].x, qq.x, acc[k * 4 + 0]);
+                        acc[k * 4 + 1] = __builtin_fmaf(rr.v[b][k].y, qq.y, acc[k * 4 + 1]);
+                        acc[k * 4 + 2] = __builtin_fmaf(rr.v[b][k].z, qq.z, acc[k * 4 + 2]);
+                        acc[k * 4 + 3] = __builtin_fmaf(rr.v[b][k].w, qq.w, acc[k * 4 + 3]);
+                    }
+                }
+            }
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s = s + acc[j];
+            float r = from_lower_f(s);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) r = r + acc[j];
+            const uint8_t* qtail = lds_q + (size_t)g_ngroups * GEN_GROUP * 128u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if ((uint32_t)u < g_tu) {
+                    const float4 qq = *reinterpret_cast<const float4*>(qtail + u * 16);
+                    r = __builtin_fmaf(vt[u].x, qq.x, r);
+                    r = __builtin_fmaf(vt[u].y, qq.y, r);
+                    r = __builtin_fmaf(vt[u].z, qq.z, r);
+                    r = __builtin_fmaf(vt[u].w, qq.w, r);
+                }
+            }
+            d = angular_from_dot(r);
+        } else if constexpr (F32) {
             float acc[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -635,8 +719,9 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
 // allocation of each instantiation so that none spills (tools/isa_report.py prints both).
 constexpr int fast_waves_per_simd(int DT, int DIM, int S) {
     if (DT == DT_I8) return S == 1 ? 5 : S <= 4 ? 4 : S == 8 ? 3 : 2;
+    if (DIM == 0) return 2; // the streamed walker keeps a group of chunks, the tail and the accumulators: ~210 VGPRs
     if (DIM > 128) return S == 1 ? 3 : 2;
-    return S == 1 ? 3 : S == 2 ? 4 : S <= 8 ? 3 : 2;
+    return S == 1 ? (GRANNE_HIP_QUERY_IN_LDS ? 4 : 3) : S == 2 ? 4 : S <= 8 ? 3 : 2;
 }
 
 template <int DT, int DIM, int S, bool TRAIL = false>
@@ -645,8 +730,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S)) void fast_kern
     if (blockIdx.x < p.nq) fast_walk_one<DT, DIM, S, TRAIL>(p, blockIdx.x, smem);
 }
 
-__host__ __device__ inline uint32_t fast_lds_bytes(uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {
-    return lds_query_bytes(row_bytes) + 64u * S * 8u + visited_slots * 4u;
+__host__ __device__ inline uint32_t fast_lds_bytes(bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {
+    return fast_query_bytes(gen, dim, row_bytes) + 64u * S * 8u + visited_slots * 4u;
 }
 
 } // namespace granne_hip

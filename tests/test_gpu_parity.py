@@ -146,6 +146,15 @@ CASES = [
     (2000, 100, True, 30, 30),
     (500, 32, True, 20, 20),
     (700, 130, True, 12, 20),
+    # f32 dims that take the streamed run-time-dim walker (walk_fast.h, DIM = 0): one chunk exactly, chunks + tails
+    # of every length class, not a multiple of 4 (zero-padded tail unit), more than one group of three chunks
+    (900, 32, False, 30, 30),
+    (900, 50, False, 30, 30),
+    (900, 96, False, 30, 30),
+    (900, 97, False, 30, 30),
+    (700, 128, False, 20, 20),
+    (600, 300, False, 30, 30),
+    (400, 768, False, 30, 20),
 ]
 
 
