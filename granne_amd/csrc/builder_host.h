@@ -236,12 +236,14 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     const uint32_t lrow = ((b->row_bytes / 16) | 1u) * 16u;
     const BuildKernels K = pick_build_kernels(b->dtype, b->dim);
     const uint32_t lds = build_lds_bytes(lrow, cap);
+    if (lds > 160u * 1024u)
+        return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the GPU builder: select_neighbors stages %u candidate rows "
+                    "of %u bytes in LDS (%u bytes, a CU has 163840)", cap + 1, lrow, lds);
     if (lds > 64u * 1024u) {
         HIP_TRY(hipFuncSetAttribute((const void*)K.select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)K.apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)K.final_prune, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (lds > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the GPU builder");
 
     SearchTarget T;
     T.device = b->device;
