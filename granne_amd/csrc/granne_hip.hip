@@ -421,8 +421,11 @@ extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uin
     if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
     switch (option) {
     case GRANNE_HIP_OPT_VISITED_SLOTS:
-        if (value != 0 && (value < 256 || value > 32768 || (value & (value - 1))))
-            return fail(GRANNE_HIP_ERR_INVALID, "visited slots must be 0 or a power of two in [256, 32768]");
+        {
+            const uint64_t odd = value ? value >> __builtin_ctzll(value) : 1; // 2^k or 3 * 2^k
+            if (value != 0 && (value < 256 || value > 32768 || (odd != 1 && odd != 3)))
+                return fail(GRANNE_HIP_ERR_INVALID, "visited slots must be 0, 2^k or 3 * 2^k in [256, 32768]");
+        }
         ix->opt_visited_slots = value;
         return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_FORCE_SLOW:
@@ -558,7 +561,14 @@ struct LaunchPlan {
 // whatever fits in the CU's 160 KiB. GRANNE_HIP_MAXC overrides the stage rows (experiments).
 static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, uint32_t fastS /* 0: general walker */) {
     LaunchPlan P;
+    // The front table must hold the walk's visited ids (~40 x max_search on 10M uniform points) below its 7/8
+    // load limit. The walkers of walk_fast.h take tables of 2^k or 3 * 2^(k-1) slots: 3072 at max_search 50
+    // (12 KB instead of 16: twelve walkers per CU instead of nine -- LDS is what bounds residency).
     uint32_t want = ix->opt_visited_slots ? (uint32_t)ix->opt_visited_slots : next_pow2(ef * 64u);
+    if (!ix->opt_visited_slots && fastS) {
+        const uint32_t need = ef * 56u, p2 = next_pow2(need);
+        want = (p2 / 4u * 3u >= need) ? p2 / 4u * 3u : p2;
+    }
     if (!ix->opt_visited_slots) {
         if (want < 1024) want = 1024;
         // larger walks spill to the global overflow table. A launch with more walkers than the chip

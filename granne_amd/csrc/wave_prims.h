@@ -144,7 +144,8 @@ struct OverflowPool {
 
 struct VisitedSet {
     uint32_t* tab;   // LDS front table
-    uint32_t mask;   // slots - 1
+    uint32_t size;   // slots: 2^k or 3 * 2^k (3072 slots hold a max_search-50 walk in 12 KB instead of 16)
+    bool size_div3;  // wave-uniform
     uint32_t count;  // wave-uniform number of ids in the front table
     uint32_t limit;  // front table load limit
     // overflow state, kept to two wave-uniform words: the borrowed region (or NONE) and the number
@@ -160,7 +161,8 @@ struct VisitedSet {
     __device__ __forceinline__ bool frozen() const { return ocount != NONE; }
     __device__ __forceinline__ void reset(uint32_t* lds, uint32_t slots, uint32_t lane) {
         tab = lds;
-        mask = slots - 1;
+        size = slots;
+        size_div3 = (slots % 3u) == 0u;
         count = 0;
         // 87.5 % load, and never fewer than 72 free slots: one expansion adds up to 64 ids before
         // the limit is checked, so probing always terminates
@@ -172,41 +174,57 @@ struct VisitedSet {
     }
     __device__ __forceinline__ static uint32_t hash(uint32_t id) { return (id * 0x9E3779B1u) >> 7; }
     __device__ __forceinline__ static uint32_t step(uint32_t id) { return ((id * 0x85EBCA6Bu) >> 9) | 1u; }
+    // front table (any size): home slot = floor(hash32 * size / 2^32); the probe step is odd, below size and,
+    // when 3 divides size, not a multiple of 3 -- coprime with size, so a probe sequence visits every slot
+    __device__ __forceinline__ uint32_t home(uint32_t id) const { return __umulhi(id * 0x9E3779B1u, size); }
+    __device__ __forceinline__ uint32_t stride(uint32_t id) const {
+        uint32_t st = __umulhi(id * 0x85EBCA6Bu, size >> 1) * 2u + 1u; // odd, <= size - 1
+        if (size_div3) {
+            const uint32_t r = st - 3u * __umulhi(st, 0x55555556u); // st % 3
+            if (r == 0u) st = (st + 2u < size) ? st + 2u : st - 2u;
+        }
+        return st;
+    }
+    __device__ __forceinline__ uint32_t next(uint32_t slot, uint32_t st) const {
+        slot += st;
+        return slot >= size ? slot - size : slot;
+    }
 
     // HashSet::insert: true iff id was not present. Lanes with active==false do nothing.
     __device__ __forceinline__ bool insert(uint32_t id, bool active, const OverflowPool& pool) {
         bool fresh = false;
-        const uint32_t st = step(id); // odd: visits every slot of a power-of-two table
+        const uint32_t st = stride(id);
         if (!frozen()) {
             if (active) {
-                uint32_t slot = hash(id) & mask;
+                uint32_t slot = home(id);
                 for (;;) {
                     uint32_t old = atomicCAS(&tab[slot], ID_EMPTY, id);
                     if (old == ID_EMPTY) { fresh = true; break; }
                     if (old == id) break;
-                    slot = (slot + st) & mask;
+                    slot = next(slot, st);
                 }
             }
         } else {
             bool absent = false;
             if (active) { // the frozen front table: lookup only
-                uint32_t slot = hash(id) & mask;
+                uint32_t slot = home(id);
                 for (;;) {
                     uint32_t v = tab[slot];
                     if (v == ID_EMPTY) { absent = true; break; }
                     if (v == id) break;
-                    slot = (slot + st) & mask;
+                    slot = next(slot, st);
                 }
             }
             if (absent) {
                 uint32_t* otab = pool.tables + (size_t)region * pool.slots;
-                const uint32_t omask = pool.slots - 1;
+                const uint32_t omask = pool.slots - 1; // the overflow tables are powers of two
+                const uint32_t ost = step(id);         // odd
                 uint32_t slot = (hash(id) >> 3) & omask;
                 for (;;) {
                     uint32_t old = atomicCAS(&otab[slot], ID_EMPTY, id);
                     if (old == ID_EMPTY) { fresh = true; break; }
                     if (old == id) break;
-                    slot = (slot + st) & omask;
+                    slot = (slot + ost) & omask;
                 }
             }
         }

@@ -333,7 +333,7 @@ void granne_hip_builder_destroy(granne_hip_builder* builder);
 
 /* ---- options (per index) ---------------------------------------------------------------------- */
 enum {
-    GRANNE_HIP_OPT_VISITED_SLOTS = 1, /* LDS visited-table slots per query, power of two; 0 = auto */
+    GRANNE_HIP_OPT_VISITED_SLOTS = 1, /* LDS visited-table slots per query: 2^k or 3 * 2^k in [256, 32768]; 0 = auto */
     GRANNE_HIP_OPT_FORCE_SLOW = 2,    /* 1: route every query through the exact global-memory path */
     GRANNE_HIP_OPT_SLOW_SLOTS = 3,    /* global visited/queue slots per slow-path query (pow2)      */
     GRANNE_HIP_OPT_SLOW_BLOCKS = 4,   /* concurrent slow-path walkers                               */
