@@ -562,13 +562,10 @@ struct LaunchPlan {
 static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, uint32_t fastS /* 0: general walker */) {
     LaunchPlan P;
     // The front table must hold the walk's visited ids (~40 x max_search on 10M uniform points) below its 7/8
-    // load limit. The walkers of walk_fast.h take tables of 2^k or 3 * 2^(k-1) slots: 3072 at max_search 50
-    // (12 KB instead of 16: twelve walkers per CU instead of nine -- LDS is what bounds residency).
+    // load limit: 4096 slots at max_search 50. (Tables of 3 * 2^k slots are accepted as an option; 3072 slots --
+    // 12 KB, twelve walkers per CU instead of nine -- measured no faster: 0.5 % of the walks spill to the
+    // overflow table and a launch lasts as long as its slowest walk.)
     uint32_t want = ix->opt_visited_slots ? (uint32_t)ix->opt_visited_slots : next_pow2(ef * 64u);
-    if (!ix->opt_visited_slots && fastS) {
-        const uint32_t need = ef * 56u, p2 = next_pow2(need);
-        want = (p2 / 4u * 3u >= need) ? p2 / 4u * 3u : p2;
-    }
     if (!ix->opt_visited_slots) {
         if (want < 1024) want = 1024;
         // larger walks spill to the global overflow table. A launch with more walkers than the chip

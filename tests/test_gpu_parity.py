@@ -345,7 +345,7 @@ def test_visited_table_overflow_hands_over(ga, oracle):
 
 @pytest.mark.parametrize("int8", [False, True])
 @pytest.mark.parametrize("ef,lds_slots,ovf_slots", [(100, 256, 0), (100, 256, 4096), (250, 1024, 0), (40, 256, 2048),
-                                                    (200, 512, 512), (100, 384, 0), (60, 768, 0), (50, 3072, 0)])
+                                                    (200, 512, 512), (100, 384, 0), (60, 768, 0), (100, 1536, 0)])
 def test_visited_set_spills_to_global_overflow(ga, oracle, int8, ef, lds_slots, ovf_slots):
     """A full LDS visited table freezes and the walk continues with a global overflow table: same results,
     no hand-over -- unless the overflow table is too small as well (512 slots at ef=200), which hands over."""
@@ -360,7 +360,7 @@ def test_visited_set_spills_to_global_overflow(ga, oracle, int8, ef, lds_slots, 
     gix.set_option(_lib.OPT_OVERFLOW_SLOTS, ovf_slots)
     assert_same(oix, gix, q, ef, 10)
     slow = gix.last_slow_count()
-    assert (slow > 0) == (ef == 200 and ovf_slots == 512)  # (tables of 3 * 2^k slots: 384, 768, 3072)
+    assert (slow > 0) == (ef == 200 and ovf_slots == 512)  # (tables of 3 * 2^k slots: 384, 768, 1536)
     # the device-side status words: [1] slow-path queries, [2] walks that spilled
     tq = torch.from_numpy(q.view(np.uint8).reshape(96, -1)).cuda()
     ids = torch.empty((96, 10), dtype=torch.int64, device="cuda")
