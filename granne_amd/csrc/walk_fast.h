@@ -189,9 +189,6 @@ struct FastWalker {
     static constexpr bool QREG = F32 && !GEN && (NB * 16 + TU * 4 <= 64) && S == 1 && !GRANNE_HIP_QUERY_IN_LDS;
     static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u;
     static constexpr uint32_t CAP = 64u * S;
-    // The next expansion's rows are issued before the merge where their registers (52 VGPRs for 100-d f32) fit
-    // beside the merge's; with longer lists only the (one-register) adjacency fetch is hoisted.
-    static constexpr bool EARLY_ROWS = !F32 || S == 1;
     static_assert(!F32 || GEN || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
     const SearchParams& p;
@@ -510,48 +507,30 @@ struct FastWalker {
         }
     }
 
-    // pq.push of an expansion's candidates (mod.rs:1029-1031), then pq.pop() + res.push of the next node
-    // (mod.rs:1018-1023): after the merge it is the first unexpanded entry of the list
-    __device__ __forceinline__ void merge_and_pop(uint64_t pm, bool pass, uint64_t ck, uint32_t ef) {
-        insert(pm, pass, ck, ef);
-        if (bail) return;
-        uint32_t pos = 0;
-        L.first_unexpanded(pos);
-        const uint64_t x = L.at(pos);
-        L.mark_expanded(pos, x, lane);
-        st.n_expand += 1;
-    }
-
     // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
     //
-    // The loop is software-pipelined around the one thing that is known early: once the distances of an
-    // expansion are in, the NEXT node to expand is decided before the candidates are merged -- it is the
-    // smallest of (the list's first unexpanded entry y, the candidates that pass the filter), because
-    // merging changes nothing that sorts before that minimum. So the first memory operation of the next
-    // expansion is issued BEFORE the merge and runs under it: y's element rows when y's adjacency row was
-    // fetched ahead (the merge then follows the row loads), else the adjacency row of the winning
-    // candidate (the merge then precedes the row loads). Nothing is speculative: every load issued is a
-    // load the walk needs. The row loads have ONE site in the loop -- two sites would meet in a phi and the
-    // register copies at the join would wait for the data right after issuing it.
+    // One iteration = one expansion: pop, adjacency row, row loads, visited set under them, distances, filter,
+    // merge. Two things run ahead of their use:
+    //  * the adjacency row of the list's first unexpanded entry y is fetched during the expansion before it;
+    //  * once the distances are in, the node expanded next is known BEFORE the merge -- the smallest of y and
+    //    the candidates that pass the filter, since merging changes nothing that sorts before that minimum.
+    //    When a candidate wins (half of the expansions at max_search 50) its adjacency row is requested
+    //    right there and arrives under the merge instead of after it.
+    // (A fully software-pipelined variant that also issued y's ROW loads before the merge was measured and
+    // dropped: +40 % scalar instructions for the bookkeeping, launch time 3-5 % worse)
+    // The row loads have one site in the loop: two sites would meet in a phi, and the register copies at the
+    // join wait for the data right after issuing it.
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots) {
         vis.reset(vis_tab, slots, lane);
         L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;
-
-        // state handed from one expansion to the next
-        uint32_t next_id = entrypoint;   // the node popped next
-        uint32_t nb_next;                // its adjacency row, one id per pair (maybe still in flight)
-        bool adj_known = false;          // true: nb_next was fetched ahead, the rows go out before the merge
-        bool pass = false;               // candidates of the finished expansion that enter the list
-        uint64_t ck = 0;
-        uint64_t pm = 0;
-        uint32_t pre_id = ID_EMPTY, pre_nb = ID_EMPTY; // adjacency row fetched ahead for the first unexpanded entry
+        uint32_t pre_id = entrypoint, pre_nb; // adjacency row fetched ahead (one id per pair) and whose it is
 
         {   // distance to the entry point (mod.rs:1012-1016); the first pop of the loop takes it
             RowRegs r0;
             issue_rows(entrypoint, r0);
-            nb_next = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
+            pre_nb = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
             vis.insert(entrypoint, lane == 0, p.ovf);
             vis.count = 1;
             const float d0 = finish_rows(r0);
@@ -561,32 +540,35 @@ struct FastWalker {
 
         RowRegs rr;
         for (;;) {
-            // ---- A: the adjacency row of the next node is still in flight: merge and pop under it
-            if (!adj_known) {
-                merge_and_pop(pm, pass, ck, ef);
-                if (bail) return;
-            }
-            // ---- B: layer.get_neighbors (mod.rs:1025 / 540-552: prefix until UNUSED) and the row loads -- the one site
-            const uint32_t nb = nb_next;
+            uint32_t pos;
+            if (!L.first_unexpanded(pos)) break;          // pq.pop() on an empty queue, mod.rs:1018
+            const uint64_t x = L.at(pos);
+            // mod.rs:1019-1021. Every entry before x is expanded and at most as far; #{closer} = pos - #{ties
+            // before x}, so the count is only taken when pos alone does not already decide
+            if (pos >= ef && L.count_closer(wkey_hi(x)) >= ef) break;
+            L.mark_expanded(pos, x, lane);                 // res.push((d, idx)), mod.rs:1023
+            st.n_expand += 1;
+
+            // layer.get_neighbors(idx), mod.rs:1025 / 540-552: row prefix until UNUSED, one id per pair
+            const uint32_t xid = wkey_id(x);
+            uint32_t nb;
+            if (pre_id == xid) nb = pre_nb;
+            else nb = adjg[(size_t)xid * 32u + R];
             const uint64_t unused = wave_ballot(nb == ID_EMPTY);
             const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
+            st.n_adj += nvalid;
             {   // lanes beyond the row re-read its last neighbor (an empty row: the node itself)
-                const uint32_t last_id = nvalid ? readlane32(nb, 2u * (nvalid - 1u)) : next_id;
+                const uint32_t last_id = nvalid ? readlane32(nb, 2u * (nvalid - 1u)) : xid;
                 issue_rows((R < nvalid) ? nb : last_id, rr);
             }
-            // ---- C: the adjacency row was fetched ahead: merge and pop under the row loads
-            if (adj_known) {
-                merge_and_pop(pm, pass, ck, ef);
-                if (bail) return;
-            }
-            st.n_adj += nvalid;
-            {   // fetch ahead the adjacency row of the entry that is first in line now (it is expanded next unless
-                // a candidate of this expansion sorts before it); always one load: static wait counts
-                uint32_t p2;
-                pre_id = L.first_unexpanded(p2) ? wkey_id(L.at(p2)) : next_id;
-                pre_nb = adjg[(size_t)pre_id * 32u + R];
-            }
-            // ---- D: visited set under the loads, then the distances (mod.rs:1026-1027)
+            // fetch ahead the row of the node that is first in line now; always one load: static wait counts
+            uint32_t ypos = 0;
+            const bool has_y = L.first_unexpanded(ypos);
+            const uint64_t ykey = has_y ? L.at(ypos) : KEY_INF;
+            pre_id = has_y ? wkey_id(ykey) : xid;
+            pre_nb = adjg[(size_t)pre_id * 32u + R];
+
+            // visited set under the loads, then the distances (mod.rs:1026-1027)
             const bool fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
             const float d = finish_rows(rr);
             const uint64_t fm = wave_ballot(fresh);
@@ -594,42 +576,25 @@ struct FastWalker {
             vis.added(mf);
             st.n_dist += mf;
             const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
-            if (!vis.make_room(p.ovf, lane)) bail = true;
-            if (bail) return;
-            pass = filter(cand, d, ef);
-            ck = wkey(d, nb);
-            pm = wave_ballot(pass);
-
-            // ---- E: who is expanded next? Its first load is issued here, before the merge
-            uint32_t ypos = 0;
-            const bool has_y = L.first_unexpanded(ypos);
-            const uint64_t ykey = has_y ? L.at(ypos) : KEY_INF;
-            uint64_t beat = wave_ballot(pass && ck < ykey); // ykey = KEY_INF: every passing candidate
+            const bool pass = filter(cand, d, ef);
+            const uint64_t ck = wkey(d, nb);
+            const uint64_t pm = wave_ballot(pass);
+            // a candidate that sorts before y is expanded next (the smallest such): request its adjacency row now
+            // (not with 800-byte rows: the walk is bandwidth-bound there and the kernel sits at its 168-register limit)
+            uint64_t beat = (F32 && DIM > 128) ? 0ull : wave_ballot(pass && ck < ykey); // ykey = KEY_INF without y: every passing candidate
             if (beat) {
                 uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
-                for (;;) { // the smallest passing key (usually one or two rounds)
+                for (;;) { // usually one or two rounds
                     beat = wave_ballot(pass && ck < K);
                     if (!beat) break;
                     K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
                 }
-                next_id = wkey_id(K); // it passed `d <= theta`: fewer than max_search entries are closer, no break
-                adj_known = false;
-                nb_next = adjg[(size_t)next_id * 32u + R];
-            } else {
-                if (!has_y) break; // pq.pop() on an empty queue, mod.rs:1018
-                // mod.rs:1019-1021 for y. Every entry before y is expanded and at most as far; #{closer} =
-                // ypos - #{ties before y}, so the count is only taken when ypos alone does not decide. No
-                // candidate of this expansion sorts before y: the pending merge changes neither number.
-                if (ypos >= ef && L.count_closer(wkey_hi(ykey)) >= ef) break;
-                next_id = wkey_id(ykey);
-                if (EARLY_ROWS && pre_id == next_id) {
-                    adj_known = true;
-                    nb_next = pre_nb;
-                } else {
-                    adj_known = false;
-                    nb_next = (pre_id == next_id) ? pre_nb : adjg[(size_t)next_id * 32u + R];
-                }
+                pre_id = wkey_id(K);
+                pre_nb = adjg[(size_t)pre_id * 32u + R];
             }
+            insert(pm, pass, ck, ef);                      // pq.push, mod.rs:1029-1031
+            if (!vis.make_room(p.ovf, lane)) bail = true;
+            if (bail) return;
         }
     }
 };
