@@ -87,11 +87,11 @@ def parse():
 
 
 def csrc_sha():
-    """Hash of the kernel sources + build flags: PMC traffic figures in profiles/pmc_traffic.json are
-    only quoted for the kernels they were measured on."""
+    """Hash of the walker's sources + build flags: PMC traffic figures in profiles/pmc_traffic.json are
+    only quoted for the kernel they were measured on (the files that define its memory behaviour)."""
     from granne_amd import build as gbuild
     h = hashlib.sha256()
-    for f in sorted(os.listdir(gbuild.CSRC)):
+    for f in ("walk_fast.h", "wave_prims.h", "dist.h"):
         h.update(f.encode())
         h.update(open(os.path.join(gbuild.CSRC, f), "rb").read())
     h.update(" ".join(gbuild.FLAGS).encode())
