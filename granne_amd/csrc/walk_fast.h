@@ -520,21 +520,28 @@ struct FastWalker {
     // dropped: +40 % scalar instructions for the bookkeeping, launch time 3-5 % worse)
     // The row loads have one site in the loop: two sites would meet in a phi, and the register copies at the
     // join wait for the data right after issuing it.
-    __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots) {
+    __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
+                                                 bool d0_known = false, float d0_value = 0.0f) {
         vis.reset(vis_tab, slots, lane);
         L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;
         uint32_t pre_id = entrypoint, pre_nb; // adjacency row fetched ahead (one id per pair) and whose it is
 
-        {   // distance to the entry point (mod.rs:1012-1016); the first pop of the loop takes it
+        // distance to the entry point (mod.rs:1012-1016); the first pop of the loop takes it. On every layer
+        // but the first the entry point is the node the layer above returned as its closest, and its distance
+        // to the same query was evaluated there: the same operations on the same inputs give the same bits, so
+        // the value is reused (the evaluation still counts) and the layer starts one memory round trip earlier.
+        pre_nb = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
+        vis.insert(entrypoint, lane == 0, p.ovf);
+        vis.count = 1;
+        st.n_dist += 1;
+        if (d0_known) {
+            L.set_first(wkey(d0_value, entrypoint), lane);
+        } else {
             RowRegs r0;
             issue_rows(entrypoint, r0);
-            pre_nb = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
-            vis.insert(entrypoint, lane == 0, p.ovf);
-            vis.count = 1;
             const float d0 = finish_rows(r0);
-            st.n_dist += 1;
             L.set_first(readlane64(wkey(d0, entrypoint), 1), lane);
         }
 
@@ -627,12 +634,17 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
         return;
     } else {
         uint32_t entrypoint = 0; // mod.rs:989
+        float ep_dist = 0.0f;
         for (uint32_t l = 0; l < p.n_layers; ++l) {
             const LayerDev Ly = p.layers[l];
             const bool bottom = (l + 1 == p.n_layers);
-            w.search_layer(Ly, entrypoint, bottom ? p.ef : 1u, bottom ? p.visited_slots : p.upper_slots);
+            w.search_layer(Ly, entrypoint, bottom ? p.ef : 1u, bottom ? p.visited_slots : p.upper_slots, l > 0, ep_dist);
             if (w.bail) break;
-            if (!bottom) entrypoint = wkey_id(w.L.at(0)); // res[0].0, mod.rs:993: the smallest popped key
+            if (!bottom) { // res[0], mod.rs:993: the smallest popped key
+                const uint64_t best = w.L.at(0);
+                entrypoint = wkey_id(best);
+                ep_dist = wkey_dist(best);
+            }
         }
         w.vis.release(p.ovf, lane);
         if (w.bail) { // hand the untouched query to the exact global-memory walker
