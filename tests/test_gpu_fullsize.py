@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 N = int(os.environ.get("GRANNE_FULLSIZE_N", "10000000"))
 DIM = 100
 SEED = 0x6772616E6E65
-SELF_BAR = {"f32": 0.3, "i8": 0.3}  # set from the measured rates, see test_members_find_themselves
+SELF_BAR = {"f32": 0.5, "i8": 0.5}  # measured on the default graph: 0.566 (f32), 0.559 (i8); see test_members_find_themselves
 
 
 @pytest.fixture(scope="module", params=["f32", "i8"])
@@ -138,7 +138,7 @@ def test_members_find_themselves(built):
     ok = hit | (ds[:, 0] <= 1e-6)
     print("self-query hit rate at n=%d (%s): %.3f" % (N, kind, ok.mean()))
     # the reference's bar is 0.95 on 500-1500 points (src/index/tests.rs:50-62); on 10M i.i.d.-uniform 100-d points
-    # at max_search 50 the default graph finds %SELF% of its own members (the CPU oracle finds the same ones: the
+    # at max_search 50 the default graph finds 56 % of its own members (the CPU oracle finds the same ones: the
     # walk is bit-identical, test above) -- the bar sits a margin below what the graph achieves
     assert ok.mean() > SELF_BAR[kind], ok.mean()
 
