@@ -106,6 +106,8 @@ struct granne_hip_index {
         size_t d_cap = 0;
         uint8_t* h_pin = nullptr;
         size_t h_cap = 0;
+        uint8_t* d_scratch = nullptr; // search_launch's scratch block, kept across calls
+        size_t scratch_cap = 0;
     };
     std::mutex call_mu;
     std::vector<HostCall*> call_free;
@@ -166,6 +168,7 @@ static void destroy_index(granne_hip_index* ix) {
         if (c->stream) (void)hipStreamDestroy(c->stream);
         if (c->d_buf) (void)hipFree(c->d_buf);
         if (c->h_pin) (void)hipHostFree(c->h_pin);
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
         delete c;
     }
     delete ix;
@@ -632,7 +635,9 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
                          uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */,
                          uint32_t* d_trail = nullptr /* [nq][8]: trail mode, no search outputs */,
                          uint32_t trail_layers = 0, hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr,
-                         uint32_t* h_status_async = nullptr /* pinned u32[4]: the launch's header words, stream-ordered, no sync */) {
+                         uint32_t* h_status_async = nullptr /* pinned u32[4]: the launch's header words, stream-ordered, no sync */,
+                         uint8_t** scratch_cache = nullptr, size_t* scratch_cache_cap = nullptr /* a caller-kept scratch block */,
+                         uint32_t* host_status = nullptr /* u32[2], host-mapped: hand-over count and exhaustion flag, plain stores */) {
     if (ef == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
     if (nq == 0) return GRANNE_HIP_OK;
     DeviceGuard g(ix->device);
@@ -681,12 +686,25 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     size_t off_res = off_pq + (size_t)slow_blocks * slots * 8;
     size_t total = off_res + (size_t)slow_blocks * ef * 8;
     uint8_t* scratch = nullptr;
-    HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
+    if (scratch_cache) { // the caller keeps one block across calls (host-pointer searches): no allocator traffic per call
+        if (*scratch_cache_cap < total) {
+            if (*scratch_cache) (void)hipFree(*scratch_cache);
+            *scratch_cache = nullptr;
+            *scratch_cache_cap = 0;
+            HIP_TRY(hipMalloc((void**)scratch_cache, total));
+            *scratch_cache_cap = total;
+        }
+        scratch = *scratch_cache;
+    } else {
+        HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
+    }
     struct ScratchRelease { // stream-ordered free on every exit path
         void* ptr;
         hipStream_t stream;
-        ~ScratchRelease() { (void)hipFreeAsync(ptr, stream); }
-    } scratch_release{scratch, s};
+        ~ScratchRelease() {
+            if (ptr) (void)hipFreeAsync(ptr, stream);
+        }
+    } scratch_release{scratch_cache ? nullptr : scratch, s};
     HIP_TRY(hipMemsetAsync(scratch, 0, off_list, s)); // header + region states
 
     SearchParams p;
@@ -747,6 +765,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     sp.slots = slots;
     sp.status = ((uint32_t*)scratch) + 1;
     sp.status2 = d_status;
+    sp.host_status = host_status;
     uint32_t slow_lds = lds_query_bytes(ix->row_bytes) + 64 * 8;
     if (ix->dtype == GRANNE_HIP_F32)
         hipLaunchKernelGGL(slow_kernel<DT_F32>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
@@ -858,61 +877,68 @@ extern "C" int granne_hip_search_batch(const granne_hip_index* cix, const void* 
         granne_hip_index::HostCall* c;
         ~Release() { host_call_release(ix, c); }
     } release{ix, c};
-    if (c->d_cap < total) {
-        if (c->d_buf) (void)hipFree(c->d_buf);
-        c->d_buf = nullptr;
-        c->d_cap = 0;
-        const size_t want = total < (64u << 10) ? (64u << 10) : total;
-        HIP_TRY(hipMalloc((void**)&c->d_buf, want));
-        c->d_cap = want;
-    }
     if (staged && c->h_cap < total) {
         if (c->h_pin) (void)hipHostFree(c->h_pin);
         c->h_pin = nullptr;
         c->h_cap = 0;
-        HIP_TRY(hipHostMalloc((void**)&c->h_pin, (256u << 10) + 64, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&c->h_pin, (256u << 10) + 64, hipHostMallocMapped));
         c->h_cap = 256u << 10;
     }
     hipStream_t s = c->stream;
-    uint8_t* buf = c->d_buf;
-    if (staged) {
-        memcpy(c->h_pin, queries, qb);
-        HIP_TRY(hipMemcpyAsync(buf, c->h_pin, qb, hipMemcpyHostToDevice, s));
-    } else {
-        HIP_TRY(hipMemcpyAsync(buf, queries, qb, hipMemcpyHostToDevice, s));
-    }
-    uint32_t slow[2] = {0, 0};
     SearchTarget T = target_of(ix);
-    int r = search_launch(&T, buf, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
-                          (uint64_t*)(buf + o_ids), (float*)(buf + o_d), (uint32_t*)(buf + o_c), (uint64_t*)(buf + o_s),
-                          nullptr, s, staged ? nullptr : slow, nullptr, 0, nullptr, nullptr,
-                          staged ? (uint32_t*)(c->h_pin + total) : nullptr);
-    if (r) {
-        (void)hipStreamSynchronize(s);
-        return r;
-    }
+    uint32_t slow[2] = {0, 0};
     if (staged) {
-        // outputs and the launch's status words (written to h_pin + total by search_launch) in stream order
-        HIP_TRY(hipMemcpyAsync(c->h_pin + o_ids, buf + o_ids, total - o_ids, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        const uint32_t* hs = (const uint32_t*)(c->h_pin + total);
-        slow[0] = hs[0];
-        slow[1] = hs[1];
-    }
-    ix->last_slow_count.store(slow[0]);
-    if (slow[1]) return fail(GRANNE_HIP_ERR_OVERFLOW, "exact-search scratch exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)");
-    if (staged) {
+        // Small calls (one query per call is the reference's own shape, src/index/mod.rs:140-150): no copy
+        // engine at all. The pinned block is mapped into the device's address space: the walker reads the
+        // queries from it and writes results and status words into it over PCIe (a few hundred bytes), the
+        // scratch block is the caller context's own. What is left on the stream: one memset of the scratch
+        // header, the walker, the (normally empty) exact walker, one synchronisation.
+        void* dev_pin = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dev_pin, c->h_pin, 0));
+        uint8_t* dp = (uint8_t*)dev_pin;
+        uint32_t* hst = (uint32_t*)(c->h_pin + total);
+        memcpy(c->h_pin, queries, qb);
+        hst[0] = hst[1] = hst[2] = hst[3] = 0;
+        int r = search_launch(&T, dp, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
+                              (uint64_t*)(dp + o_ids), (float*)(dp + o_d), (uint32_t*)(dp + o_c), (uint64_t*)(dp + o_s),
+                              nullptr, s, nullptr, nullptr, 0, nullptr, nullptr, nullptr, &c->d_scratch, &c->scratch_cap,
+                              (uint32_t*)(dp + total));
+        hipError_t e = hipStreamSynchronize(s);
+        if (r) return r;
+        if (e != hipSuccess) return fail(GRANNE_HIP_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+        slow[0] = hst[1]; // queries served by the exact global-memory walker
+        slow[1] = hst[0]; // its scratch ran out
+        ix->last_slow_count.store(slow[0]);
+        if (slow[1]) return fail(GRANNE_HIP_ERR_OVERFLOW, "exact-search scratch exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)");
         memcpy(out_ids, c->h_pin + o_ids, (size_t)nq * k * 8);
         memcpy(out_dists, c->h_pin + o_d, (size_t)nq * k * 4);
         memcpy(out_counts, c->h_pin + o_c, (size_t)nq * 4);
         if (out_stats) memcpy(out_stats, c->h_pin + o_s, (size_t)nq * 24);
-    } else {
-        HIP_TRY(hipMemcpyAsync(out_ids, buf + o_ids, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out_dists, buf + o_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out_counts, buf + o_c, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        if (out_stats) HIP_TRY(hipMemcpyAsync(out_stats, buf + o_s, (size_t)nq * 24, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        return GRANNE_HIP_OK;
     }
+    if (c->d_cap < total) {
+        if (c->d_buf) (void)hipFree(c->d_buf);
+        c->d_buf = nullptr;
+        c->d_cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_buf, total));
+        c->d_cap = total;
+    }
+    uint8_t* buf = c->d_buf;
+    HIP_TRY(hipMemcpyAsync(buf, queries, qb, hipMemcpyHostToDevice, s));
+    int r = search_launch(&T, buf, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
+                          (uint64_t*)(buf + o_ids), (float*)(buf + o_d), (uint32_t*)(buf + o_c), (uint64_t*)(buf + o_s),
+                          nullptr, s, slow);
+    if (r) {
+        (void)hipStreamSynchronize(s);
+        return r;
+    }
+    ix->last_slow_count.store(slow[0]);
+    if (slow[1]) return fail(GRANNE_HIP_ERR_OVERFLOW, "exact-search scratch exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)");
+    HIP_TRY(hipMemcpyAsync(out_ids, buf + o_ids, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_dists, buf + o_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_counts, buf + o_c, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    if (out_stats) HIP_TRY(hipMemcpyAsync(out_stats, buf + o_s, (size_t)nq * 24, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return GRANNE_HIP_OK;
 }
 

@@ -22,6 +22,8 @@ struct SlowParams {
     uint32_t slots;  // power of two
     uint32_t* status;// set to 1 when a walk exhausts `slots`
     uint32_t* status2; // caller's u32[2] (optional): [0] same flag, [1] += queries that took this path
+    uint32_t* host_status; // optional u32[2] in host-mapped memory, written with PLAIN stores (no PCIe atomics):
+                           // [0] = 1 when a walk exhausts `slots`, [1] = queries that took this path
 };
 
 // binary heaps over u64 keys, run by one lane
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
     uint64_t* res = P.res + (size_t)blockIdx.x * p.ef;
     const uint32_t n_slow = *p.slow_count;
     if (blockIdx.x == 0 && threadIdx.x == 0 && P.status2 && n_slow) atomicAdd(P.status2 + 1, n_slow);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.host_status) P.host_status[1] = n_slow;
 
     for (uint32_t si = blockIdx.x; si < n_slow; si += gridDim.x) {
         const uint32_t qi = p.slow_list[si];
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
                 if (lane == 0) {
                     atomicExch(P.status, 1u);
                     if (P.status2) atomicExch(P.status2, 1u);
+                    if (P.host_status) P.host_status[0] = 1u;
                 }
             } else if (lane < TRAIL_WIDTH) {
                 p.trail_out[(size_t)qi * TRAIL_WIDTH + lane] = trail_mine;
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
             if (lane == 0) {
                 atomicExch(P.status, 1u);
                 if (P.status2) atomicExch(P.status2, 1u);
+                if (P.host_status) P.host_status[0] = 1u;
             }
         } else if (p.n_layers > 0) {
             if (lane == 0) {

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--fast-build", action="store_true", help="max_search 50, no reinsertion (7 s instead of 25 s at 10M)")
     ap.add_argument("--cfg", action="append", default=[])
+    ap.add_argument("--latency", action="store_true", help="also time one query per call through the host-pointer API")
     a = ap.parse_args()
     sys.argv = [sys.argv[0]]
     args = bench.parse()
@@ -36,6 +37,9 @@ def main():
     esize = 4 if a.dtype == "f32" else 1
     maxq = max(int(dict(kv.split("=") for kv in c.split(",")).get("nq", 1024)) for c in a.cfg) if a.cfg else 1024
     queries = B.rows(a.data, bench.SEED + 1, 0, (a.steps + a.warmup) * maxq, a.dim, a.dtype)
+    if a.latency:
+        for ef in (50, 200):
+            print("nq=1 ef=%d" % ef, B.latency_nq1(index, queries, a.dim, ef, 10), flush=True)
     for c in a.cfg:
         kv = dict(x.split("=") for x in c.split(","))
         ef, nq, infl, vs = int(kv.get("ef", 50)), int(kv.get("nq", 1024)), int(kv.get("inflight", 3)), int(kv.get("vs", 0))
