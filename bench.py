@@ -570,7 +570,8 @@ def run_partitioned(B, args):
     mine = list(range(rank * spg, (rank + 1) * spg))
 
     t0 = time.time()
-    elements = [B.rows(args.data, SEED + g, 0, bounds[g][1] - bounds[g][0], dim, args.dtype) for g in mine]  # per-shard seed
+    # per-shard seed, clear of the query stream's (SEED + 1): shard g is rows 0.. of stream SEED + 100 + g
+    elements = [B.rows(args.data, SEED + 100 + g, 0, bounds[g][1] - bounds[g][0], dim, args.dtype) for g in mine]
     queries = B.rows(args.data, SEED + 1, 0, n_batches * nq, dim, args.dtype)  # the SAME batches on every rank
     torch.cuda.synchronize()
     t_gen = time.time() - t0
