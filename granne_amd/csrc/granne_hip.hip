@@ -725,6 +725,15 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.out_stats = d_stats;
     p.visited_slots = plan.visited_slots;
     p.upper_slots = plan.upper_slots;
+    // A walk that will outgrow the front table anyway (it visits ~40 x max_search nodes) freezes it at 5/8 load
+    // instead of 7/8: every later lookup of a new id runs to an empty slot of the frozen table, 8 probes on average
+    // at 7/8 load with the wave waiting for its slowest lane, 2.7 at 5/8 (C5-like int8 walk at max_search 200:
+    // launch 2.70 -> 2.44 ms; f32 at 800: 7.75 -> 6.5 ms).
+    p.front_eighths = ((uint64_t)ef * 40u > (uint64_t)plan.visited_slots) ? 5u : 7u;
+    if (const char* e = getenv("GRANNE_HIP_FRONT_EIGHTHS")) { // experiments
+        const uint32_t v = (uint32_t)atoi(e);
+        if (v >= 1 && v <= 7) p.front_eighths = v;
+    }
     p.maxc = plan.maxc;
     p.lrow_bytes = plan.lrow_bytes;
     p.stage_bytes = plan.stage_bytes;

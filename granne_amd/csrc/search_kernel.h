@@ -55,6 +55,7 @@ struct SearchParams {
     uint64_t* out_stats;     // [nq][3] or null
     uint32_t visited_slots;  // bottom layer, power of two
     uint32_t upper_slots;    // upper layers, power of two <= visited_slots
+    uint32_t front_eighths;  // bottom layer: the front table freezes at this many eighths of its slots (7 = default)
     uint32_t maxc;           // f32: rows the LDS stage holds (<= 64)
     uint32_t lrow_bytes;     // f32: LDS stage row stride (odd multiple of 16)
     uint32_t stage_bytes;    // LDS bytes of the stage

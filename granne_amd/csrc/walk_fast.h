@@ -522,7 +522,7 @@ struct FastWalker {
     // join wait for the data right after issuing it.
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
                                                  bool d0_known = false, float d0_value = 0.0f) {
-        vis.reset(vis_tab, slots, lane);
+        vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
         L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;

@@ -159,14 +159,18 @@ struct VisitedSet {
         ocount = NONE;
     }
     __device__ __forceinline__ bool frozen() const { return ocount != NONE; }
-    __device__ __forceinline__ void reset(uint32_t* lds, uint32_t slots, uint32_t lane) {
+    // `eighths`: the front table freezes at eighths/8 load (7: a walk that is expected to fit; lower for walks
+    // that will spill anyway -- a lookup in a frozen table at 7/8 load probes 8 slots on average and the wave
+    // waits for its slowest lane)
+    __device__ __forceinline__ void reset(uint32_t* lds, uint32_t slots, uint32_t lane, uint32_t eighths = 7u) {
         tab = lds;
         size = slots;
         size_div3 = (slots % 3u) == 0u;
         count = 0;
         // 87.5 % load, and never fewer than 72 free slots: one expansion adds up to 64 ids before
         // the limit is checked, so probing always terminates
-        limit = slots - ((slots >> 3) > 72u ? (slots >> 3) : 72u);
+        limit = (slots >> 3) * eighths;
+        if (limit + 72u > slots) limit = slots - 72u;
         uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
         uint4* t4 = reinterpret_cast<uint4*>(lds);
         for (uint32_t i = lane; i < (slots >> 2); i += 64) t4[i] = e;
