@@ -814,6 +814,16 @@ extern "C" int granne_hip_search_batch_device_timed(const granne_hip_index* ix, 
                          nullptr, 0, (hipEvent_t)ev_before, (hipEvent_t)ev_after);
 }
 
+#if GRANNE_HIP_PHASE_TIMERS
+// diagnostics build only (tools/phase_probe.py): the per-walk phase clocks of the last launches
+extern "C" int granne_hip_debug_phases(uint64_t* out, uint32_t nq) {
+    if (!out || nq > PHASE_QUERIES) return fail(GRANNE_HIP_ERR_INVALID, "bad argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), (size_t)nq * PHASE_SLOTS * 8));
+    return GRANNE_HIP_OK;
+}
+#endif
+
 extern "C" int granne_hip_event_create(void** out_event) {
     if (!out_event) return fail(GRANNE_HIP_ERR_INVALID, "out_event is null");
     hipEvent_t e = nullptr;

@@ -38,6 +38,44 @@
 
 namespace granne_hip {
 
+// Diagnostics build (-DGRANNE_HIP_PHASE_TIMERS=1, tools/phase_probe.py): s_memtime stamps around the phases of
+// an expansion, summed per walk into a device array the host reads back. Never part of the shipped library.
+#ifndef GRANNE_HIP_PHASE_TIMERS
+#define GRANNE_HIP_PHASE_TIMERS 0
+#endif
+#if GRANNE_HIP_PHASE_TIMERS
+constexpr uint32_t PHASE_SLOTS = 32, PHASE_QUERIES = 4096;
+__device__ uint64_t g_phase[PHASE_QUERIES * PHASE_SLOTS];
+#define PT_MARK(i)                                                                   \
+    do {                                                                             \
+        asm volatile("" ::: "memory");                                               \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();                          \
+        const uint64_t dt_ = now_ - pt_last;                                         \
+        if (pt_bottom) pt_b[i] += dt_; else pt_u[i] += dt_;                          \
+        pt_last = now_;                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        asm volatile("" ::: "memory");                                               \
+    } while (0)
+#define PT_RESET()                                                                   \
+    do {                                                                             \
+        asm volatile("" ::: "memory");                                               \
+        pt_last = __builtin_amdgcn_s_memtime();                                      \
+        asm volatile("" ::: "memory");                                               \
+    } while (0)
+#define PT_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PT_COUNT() do { if (pt_bottom) pt_nb += 1; else pt_nu += 1; } while (0)
+#define PT_PIN(v) asm volatile("" ::"v"(v))
+#define PT_ADD(i, n) do { if (pt_bottom) pt_cnt[i] += (n); } while (0)
+#else
+#define PT_MARK(i) do {} while (0)
+#define PT_RESET() do {} while (0)
+#define PT_WAIT_VM() do {} while (0)
+#define PT_COUNT() do {} while (0)
+#define PT_PIN(v) do {} while (0)
+#define PT_ADD(i, n) do {} while (0)
+#endif
+
 // ---- list keys: dist bits (32) | id (31) | expanded (1) ----------------------------------------
 __device__ __forceinline__ uint64_t wkey(float d, uint32_t id) {
     return ((uint64_t)__float_as_uint(d) << 32) | ((uint64_t)id << 1);
@@ -60,10 +98,41 @@ __device__ __forceinline__ float from_lower_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
 }
 
+// lane i receives lane i-1's value, lane 0 receives 0
+__device__ __forceinline__ uint32_t from_prev_lane_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+
 template <int S>
 struct WalkList : SortedList<S> {
     using SortedList<S>::key;
     static constexpr uint32_t CAP = 64u * S;
+
+    // Insert K (wave-uniform, not in the list): the entries that sort after it move up one place, the last one
+    // falls off. No rank, no scalar round trip: entry e keeps its key when that is below K, else it takes
+    // max(key of entry e-1, K) -- which is K exactly at the insertion point. Returns the distance bits of what
+    // fell off the end (K itself when every entry is below it; 0xFFFFFFFF for an unused place).
+    __device__ __forceinline__ uint32_t insert_sorted(uint64_t K, uint32_t lane) {
+        const uint32_t last_hi = readlane32(wkey_hi(key[S - 1]), 63);
+        const uint32_t k_hi = wkey_hi(K);
+        const uint32_t lost = last_hi > k_hi ? last_hi : k_hi; // = high word of max(last entry, K)
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s) {
+            uint32_t up_lo = from_prev_lane_or_zero((uint32_t)key[s]);
+            uint32_t up_hi = from_prev_lane_or_zero((uint32_t)(key[s] >> 32));
+            if (s > 0) {
+                const uint64_t carry = readlane64(key[s - 1], 63);
+                if (lane == 0) {
+                    up_lo = (uint32_t)carry;
+                    up_hi = (uint32_t)(carry >> 32);
+                }
+            }
+            const uint64_t up = ((uint64_t)up_hi << 32) | up_lo;
+            const uint64_t t = (up < K) ? K : up;
+            key[s] = (key[s] < K) ? key[s] : t;
+        }
+        return lost;
+    }
 
     // position of the first entry whose expanded flag is clear (KEY_INF has it set)
     __device__ __forceinline__ bool first_unexpanded(uint32_t& pos) const {
@@ -205,6 +274,12 @@ struct FastWalker {
     WalkList<S> L;
     WalkStats st;
     bool bail;
+    uint32_t theta; // distance bits of list entry max_search-1 (0xFFFFFFFF while the list is shorter): kept by insert()
+#if GRANNE_HIP_PHASE_TIMERS
+    uint64_t pt_b[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_u[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last = 0, pt_t0 = 0;
+    uint32_t pt_nb = 0, pt_nu = 0, pt_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool pt_bottom = false;
+#endif
 
     __device__ __forceinline__ FastWalker(const SearchParams& p_, uint8_t* smem) : p(p_) {
         lane = threadIdx.x;
@@ -412,11 +487,6 @@ struct FastWalker {
         return d;
     }
 
-    // the entry that falls off the end of the list: dead unless it ties with entry ef-1
-    __device__ __forceinline__ void check_dropped(uint64_t dropped, uint32_t ef) {
-        if (wkey_hi(dropped) != 0xFFFFFFFFu && wkey_hi(dropped) == wkey_hi(L.at(ef - 1))) bail = true;
-    }
-
     // insert the candidates of the lanes in pm (bulk): every list entry counts the candidates
     // below it, every candidate its rank in the list plus its rank among the candidates; the keys
     // are scattered to their final places through LDS and the first CAP read back.
@@ -471,7 +541,6 @@ struct FastWalker {
         //   worst = res.peek().dist = dist of the max_search-th EXPANDED entry (mod.rs:1029), >= theta.
         // d <= theta < worst needs no second look; only a candidate that ties with theta can still fail
         // `d < worst`, and only then is the max_search-th expanded entry looked up.
-        const uint32_t theta = wkey_hi(L.at(ef - 1));
         bool pass = cand;
         if (theta != 0xFFFFFFFFu) {
             pass = pass && dbits <= theta;
@@ -483,28 +552,30 @@ struct FastWalker {
         return pass;
     }
 
-    // pq.push (mod.rs:1030) of the lanes in pm
+    // pq.push (mod.rs:1030) of the lanes in pm. Short lists take the candidates one at a time (insert_sorted:
+    // a dozen vector operations each, nothing scalar in the chain); lists that keep an LDS mirror are merged
+    // in bulk. An entry pushed off the end is dead unless its distance ties with the entry that is number
+    // max_search-1 once all candidates of the expansion are in (then max_search entries are not STRICTLY
+    // closer): the smallest lost distance is compared with that entry once, after the last insert.
+#ifndef GRANNE_HIP_BULK_MIN
+#define GRANNE_HIP_BULK_MIN 999 // experiments: short lists merge in bulk from this many candidates on
+#endif
     __device__ __forceinline__ void insert(uint64_t pm, bool pass, uint64_t ck, uint32_t ef) {
         const uint32_t m = (uint32_t)__popcll(pm);
         if (m == 0) return;
-        if (WalkList<S>::MIRROR || m >= (S == 1 ? 3u : 2u)) { // long lists: always the bulk merge (it keeps the LDS mirror)
+        if (WalkList<S>::MIRROR || m >= (uint32_t)GRANNE_HIP_BULK_MIN) {
             merge(pm, m, pass, ck, ef);
+            theta = wkey_hi(L.at(ef - 1));
             return;
         }
-        while (pm) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(pm);
-            pm &= pm - 1;
-            const uint64_t K = readlane64(ck, src);
-            const uint32_t r = L.rank(K);
-            uint64_t dropped;
-            if (r >= CAP) {
-                dropped = K;
-            } else {
-                dropped = L.at(CAP - 1);
-                L.insert_at(r, K, lane);
-            }
-            check_dropped(dropped, ef);
+        uint32_t lost = 0xFFFFFFFFu;
+        for (uint64_t it = pm; it; it &= it - 1) {
+            const uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(it));
+            const uint32_t l = L.insert_sorted(K, lane);
+            lost = l < lost ? l : lost;
         }
+        theta = wkey_hi(L.at(ef - 1));
+        if (lost == theta && theta != 0xFFFFFFFFu) bail = true;
     }
 
     // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
@@ -522,6 +593,7 @@ struct FastWalker {
     // join wait for the data right after issuing it.
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
                                                  bool d0_known = false, float d0_value = 0.0f) {
+        PT_RESET();
         vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
         L.init_list(mslot, lane);
         __syncthreads();
@@ -544,8 +616,11 @@ struct FastWalker {
             const float d0 = finish_rows(r0);
             L.set_first(readlane64(wkey(d0, entrypoint), 1), lane);
         }
+        theta = wkey_hi(L.at(ef - 1));
 
         RowRegs rr;
+        PT_WAIT_VM();
+        PT_MARK(7); // layer setup: tables, entry point distance
         for (;;) {
             uint32_t pos;
             if (!L.first_unexpanded(pos)) break;          // pq.pop() on an empty queue, mod.rs:1018
@@ -561,6 +636,10 @@ struct FastWalker {
             uint32_t nb;
             if (pre_id == xid) nb = pre_nb;
             else nb = adjg[(size_t)xid * 32u + R];
+            PT_MARK(0); // pop, break test, mark
+            PT_WAIT_VM();
+            PT_MARK(8); // wait for the adjacency row
+            PT_COUNT();
             const uint64_t unused = wave_ballot(nb == ID_EMPTY);
             const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
             st.n_adj += nvalid;
@@ -574,14 +653,20 @@ struct FastWalker {
             const uint64_t ykey = has_y ? L.at(ypos) : KEY_INF;
             pre_id = has_y ? wkey_id(ykey) : xid;
             pre_nb = adjg[(size_t)pre_id * 32u + R];
+            PT_MARK(1); // row loads and the fetch-ahead issued
 
             // visited set under the loads, then the distances (mod.rs:1026-1027)
             const bool fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
+            PT_MARK(2); // visited set (under the loads)
+            PT_WAIT_VM();
+            PT_MARK(3); // what is left of the wait for the rows
             const float d = finish_rows(rr);
             const uint64_t fm = wave_ballot(fresh);
             const uint32_t mf = (uint32_t)__popcll(fm);
             vis.added(mf);
             st.n_dist += mf;
+            PT_PIN(d);
+            PT_MARK(4); // distances
             const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
             const bool pass = filter(cand, d, ef);
             const uint64_t ck = wkey(d, nb);
@@ -589,6 +674,7 @@ struct FastWalker {
             // a candidate that sorts before y is expanded next (the smallest such): request its adjacency row now
             // (not with 800-byte rows: the walk is bandwidth-bound there and the kernel sits at its 168-register limit)
             uint64_t beat = (F32 && DIM > 128) ? 0ull : wave_ballot(pass && ck < ykey); // ykey = KEY_INF without y: every passing candidate
+            [[maybe_unused]] const bool beat0 = beat != 0;
             if (beat) {
                 uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
                 for (;;) { // usually one or two rounds
@@ -599,8 +685,20 @@ struct FastWalker {
                 pre_id = wkey_id(K);
                 pre_nb = adjg[(size_t)pre_id * 32u + R];
             }
+            PT_MARK(5); // filter, next-node decision, its adjacency request
+            {
+                [[maybe_unused]] const uint32_t m_ = (uint32_t)__popcll(pm);
+                PT_ADD(0, m_);
+                PT_ADD(1, m_ == 0u ? 1u : 0u);
+                PT_ADD(2, (m_ == 1u || m_ == 2u) ? 1u : 0u);
+                PT_ADD(3, (m_ >= 3u && m_ <= 6u) ? 1u : 0u);
+                PT_ADD(4, m_ > 6u ? 1u : 0u);
+                PT_ADD(5, beat0 ? 1u : 0u);
+            }
             insert(pm, pass, ck, ef);                      // pq.push, mod.rs:1029-1031
+            PT_MARK(6); // insert / merge
             if (!vis.make_room(p.ovf, lane)) bail = true;
+            PT_MARK(9); // visited-set housekeeping
             if (bail) return;
         }
     }
@@ -638,6 +736,10 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
         for (uint32_t l = 0; l < p.n_layers; ++l) {
             const LayerDev Ly = p.layers[l];
             const bool bottom = (l + 1 == p.n_layers);
+#if GRANNE_HIP_PHASE_TIMERS
+            w.pt_bottom = bottom;
+            if (l == 0) w.pt_t0 = __builtin_amdgcn_s_memtime();
+#endif
             w.search_layer(Ly, entrypoint, bottom ? p.ef : 1u, bottom ? p.visited_slots : p.upper_slots, l > 0, ep_dist);
             if (w.bail) break;
             if (!bottom) { // res[0], mod.rs:993: the smallest popped key
@@ -679,6 +781,16 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
             p.out_ids[(size_t)qi * p.k + e] = ~0ull;
             p.out_dists[(size_t)qi * p.k + e] = __builtin_inff();
         }
+#if GRANNE_HIP_PHASE_TIMERS
+        if (lane == 0 && qi < PHASE_QUERIES) {
+            uint64_t* o = g_phase + (size_t)qi * PHASE_SLOTS;
+            for (int i = 0; i < 10; ++i) { o[i] = w.pt_b[i]; o[10 + i] = w.pt_u[i]; }
+            o[20] = w.pt_nb; o[21] = w.pt_nu;
+            o[22] = __builtin_amdgcn_s_memtime() - w.pt_t0;
+            for (int i = 0; i < 8; ++i) o[24 + i] = w.pt_cnt[i];
+            o[30] = w.vis.pt_rounds;
+        }
+#endif
         if (lane == 0) {
             p.out_counts[qi] = count;
             if (p.out_stats) {
@@ -695,6 +807,9 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
 // per SIMD on AMD; 5 waves = 96 VGPRs, 4 = 128, 3 = 168, 2 = 256). Chosen from the unconstrained
 // allocation of each instantiation so that none spills (tools/isa_report.py prints both).
 constexpr int fast_waves_per_simd(int DT, int DIM, int S) {
+#if GRANNE_HIP_PHASE_TIMERS
+    return 1; // the phase clocks live in registers too: no cap, the diagnostics run is one wave per SIMD anyway
+#endif
     if (DT == DT_I8) return S == 1 ? 5 : S <= 4 ? 4 : S == 8 ? 3 : 2;
     if (DIM == 0) return 2; // the streamed walker keeps a group of chunks, the tail and the accumulators: ~210 VGPRs
     if (DIM > 128) return S == 1 ? 3 : 2;

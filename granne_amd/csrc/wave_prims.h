@@ -14,6 +14,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef GRANNE_HIP_PHASE_TIMERS
+#define GRANNE_HIP_PHASE_TIMERS 0 // diagnostics build, see walk_fast.h
+#endif
+
 namespace granne_hip {
 
 // Pointers that were themselves loaded from memory (e.g. LayerDev::adj) reach the compiler as
@@ -153,6 +157,9 @@ struct VisitedSet {
     static constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t region;
     uint32_t ocount;
+#if GRANNE_HIP_PHASE_TIMERS
+    uint32_t pt_rounds = 0; // probe rounds of the wave (the slowest lane's) in the front table
+#endif
 
     __device__ __forceinline__ void init_walker() {
         region = NONE;
@@ -198,16 +205,26 @@ struct VisitedSet {
     __device__ __forceinline__ bool insert(uint32_t id, bool active, const OverflowPool& pool) {
         bool fresh = false;
         const uint32_t st = stride(id);
+#if GRANNE_HIP_PHASE_TIMERS
+        uint32_t r_ = 0;
+#endif
         if (!frozen()) {
             if (active) {
                 uint32_t slot = home(id);
                 for (;;) {
+#if GRANNE_HIP_PHASE_TIMERS
+                    r_ += 1;
+#endif
                     uint32_t old = atomicCAS(&tab[slot], ID_EMPTY, id);
                     if (old == ID_EMPTY) { fresh = true; break; }
                     if (old == id) break;
                     slot = next(slot, st);
                 }
             }
+#if GRANNE_HIP_PHASE_TIMERS
+            for (int o_ = 32; o_ > 0; o_ >>= 1) r_ = max(r_, (uint32_t)__shfl_xor((int)r_, o_, 64));
+            pt_rounds += r_;
+#endif
         } else {
             bool absent = false;
             if (active) { // the frozen front table: lookup only
