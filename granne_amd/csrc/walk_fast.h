@@ -257,6 +257,13 @@ struct FastWalker {
 #endif
     static constexpr bool QREG = F32 && !GEN && (NB * 16 + TU * 4 <= 64) && S == 1 && !GRANNE_HIP_QUERY_IN_LDS;
     static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u;
+#ifndef GRANNE_HIP_SPEC_ROWS
+#define GRANNE_HIP_SPEC_ROWS 1 // 0: no speculative request of the next node's element rows (A/B runs)
+#endif
+    // int8 walks are latency-bound (a quarter of the f32 bytes): the rows of the node that is first in line are
+    // requested one expansion early. f32 walks saturate HBM while a batch is young; there the extra lines cost more
+    // than the shorter tail gives back.
+    static constexpr bool SPEC_ROWS = GRANNE_HIP_SPEC_ROWS && !F32;
     static constexpr uint32_t CAP = 64u * S;
     static_assert(!F32 || GEN || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
@@ -579,7 +586,7 @@ struct FastWalker {
     }
 
 #ifndef GRANNE_HIP_PIPELINE
-#define GRANNE_HIP_PIPELINE 1 // 0: the one-expansion-per-iteration loop (kept for A/B runs)
+#define GRANNE_HIP_PIPELINE 0 // 1: the rotated loop (measured no faster, kept for A/B runs)
 #endif
 #if GRANNE_HIP_PIPELINE
     // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
@@ -764,6 +771,7 @@ struct FastWalker {
         theta = wkey_hi(L.at(ef - 1));
 
         RowRegs rr;
+        [[maybe_unused]] uint32_t touched = 0; // SPEC_ROWS: the last speculative request (kept until it has landed)
         PT_WAIT_VM();
         PT_MARK(7); // layer setup: tables, entry point distance
         for (;;) {
@@ -812,6 +820,16 @@ struct FastWalker {
             st.n_dist += mf;
             PT_PIN(d);
             PT_MARK(4); // distances
+            if constexpr (SPEC_ROWS) {
+                // y's adjacency row arrived with the element rows. Unless a candidate of this expansion beats it, y is
+                // expanded next -- a thousand cycles of filter, merge and pop from now. Requesting its neighbors'
+                // rows here (one line per row, the data is dropped) turns that expansion's gather into L2 hits; a y
+                // that is beaten stays first in line among the old entries and is expanded soon after. No decision
+                // reads these loads: results and counters cannot change.
+                asm volatile("" ::"v"(touched)); // the request of the expansion before has landed (loads return in order)
+                const uint32_t sid = (pre_nb == ID_EMPTY) ? pre_id : pre_nb;
+                touched = *reinterpret_cast<const uint32_t*>(p.elements + (size_t)sid * ROWB + h * 64u);
+            }
             const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
             const bool pass = filter(cand, d, ef);
             const uint64_t ck = wkey(d, nb);
