@@ -218,8 +218,9 @@ struct BuildScratch {
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     LayerDev* d_layers = nullptr;
+    uint8_t* selected = nullptr; // per row of the layer being built: BuildParams::selected
     void free_all() {
-        void* ps[] = {s_ids, op_keys, op_vals, sorted_keys, sorted_vals, s_dists, s_counts, seg_start, counters, sort_tmp, d_layers};
+        void* ps[] = {s_ids, op_keys, op_vals, sorted_keys, sorted_vals, s_dists, s_counts, seg_start, counters, sort_tmp, d_layers, selected};
         for (void* p : ps)
             if (p) (void)hipFree(p);
     }
@@ -281,6 +282,8 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     P.sorted_vals = S.sorted_vals;
     P.seg_start = S.seg_start;
     P.n_seg = S.counters;
+    P.selected = S.selected;
+    HIP_TRY(hipMemsetAsync(S.selected, 0, layer_len ? layer_len : 1, s)); // nothing is known about the rows of a pass
 
     const bool debug = getenv("GRANNE_HIP_DEBUG") != nullptr;
     auto dbg = [&](const char* what, uint64_t pos_, uint64_t B_) {
@@ -388,6 +391,7 @@ static int index_elements_in_last_layer(granne_hip_builder* b, uint64_t max_num_
         HIP_TRY(hipMalloc((void**)&S.sorted_vals, n_ops_max * 8));
         HIP_TRY(hipMalloc((void**)&S.seg_start, n_ops_max * 4));
         HIP_TRY(hipMalloc((void**)&S.counters, 32));
+        HIP_TRY(hipMalloc((void**)&S.selected, num_in_layer ? num_in_layer : 1));
         HIP_TRY(hipMemsetAsync(S.counters, 0, 32, s));
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, S.sort_tmp_bytes, S.op_keys, S.sorted_keys, S.op_vals,
                                                    S.sorted_vals, (int)n_ops_max, 0, OP_KEY_BITS, s));

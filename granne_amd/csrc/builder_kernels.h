@@ -57,6 +57,7 @@ struct BuildParams {
     uint32_t n_ops;
     uint32_t* seg_start;
     uint32_t* n_seg;
+    uint8_t* selected;             // [layer_len]: 1 = the row is the untouched output of select_neighbors (see apply_kernel)
 };
 
 // LDS carve-up shared by the three kernels
@@ -300,6 +301,55 @@ struct RowWork {
         __syncthreads();
         return ns;
     }
+
+    // add_and_limit_neighbors (mod.rs:923-959) with one extra candidate x for a FULL row (c == num_neighbors)
+    // that is itself the untouched output of select_neighbors for this node. Such a row is sorted by (distance
+    // to the node, id) and every entry is at most as far from the node as from each entry before it, so
+    // re-running select_neighbors on row + x decides nothing new about the old entries among themselves:
+    //   * entries that sort before x are selected again (same predecessors as when they were selected);
+    //   * x is selected iff it is at most as far from the node as from every entry before it (and fewer than
+    //     num_neighbors entries sort before it) -- otherwise the result is the old row;
+    //   * with x selected, an entry after x survives iff it is at most as far from the node as from x; the list
+    //     is cut at num_neighbors (mod.rs:866: the loop breaks before it evaluates anything further).
+    // Only the distances node<->entries (the reference's elements.dists, :938) and x<->entries are evaluated:
+    // 2c row products instead of c + (c+1)c/2, the same values the full pass would compare. Returns the new
+    // count, or 0xFFFFFFFF when the row is not sorted after all (the caller takes the full pass).
+    __device__ __forceinline__ uint32_t add_one_to_selected(uint32_t c, uint32_t ex_id, float ex_d, uint32_t num_neighbors) {
+        uint32_t id = ID_EMPTY;
+        if (lane < c) id = L.cur[lane];
+        if (lane == c) id = ex_id;
+        __syncthreads();
+        if (lane <= c) L.cid[lane] = id;
+        __syncthreads();
+        gather_chunk(L.cid, c + 1u);
+        __syncthreads();
+        float d = 0.0f, e = 0.0f;
+        if (lane < c) {
+            const uint8_t* rj = L.chunk + (size_t)lane * P.lrow;
+            d = dist_lds(L.qrow, rj);                              // element(node).dist(element(j)), :938
+            e = dist_lds(rj, L.chunk + (size_t)c * P.lrow);        // dist_to_element(j, &element_x) = dist(x, j)
+        }
+        const uint64_t key = (lane < c) ? make_key(d, id) : KEY_INF;
+        const uint64_t next = shift_down1(key); // lane i: key of lane i+1
+        if (wave_ballot(lane + 1u < c && key > next)) return 0xFFFFFFFFu;
+        const uint64_t kx = make_key(ex_d, ex_id);
+        const uint32_t p = (uint32_t)__popcll(wave_ballot(lane < c && key < kx));
+        if (p >= num_neighbors) return c;                              // :866: the loop breaks before it reaches x
+        if (wave_ballot(lane < p && !(ex_d <= e))) return c;           // x is closer to an earlier neighbor: not selected
+        const bool keep = lane < c && (lane < p || d <= e);           // :873-876 with x among the selected
+        const uint64_t km = wave_ballot(keep);
+        const uint64_t after = km & ~((1ull << p) - 1ull) & ((1ull << lane) - 1ull); // survivors in [p, lane)
+        const uint32_t pos = lane < p ? lane : p + 1u + (uint32_t)__popcll(after);
+        uint32_t total = (uint32_t)__popcll(km) + 1u;
+        if (total > num_neighbors) total = num_neighbors;
+        __syncthreads();
+        L.cur[lane] = ID_EMPTY;
+        __syncthreads();
+        if (keep && pos < total) L.cur[pos] = id;
+        if (lane == 0) L.cur[p] = ex_id;
+        __syncthreads();
+        return total;
+    }
 };
 
 // ---- phase A tail: filter, select_neighbors, dead-node rule, emit ops (mod.rs:813-845) ------------
@@ -393,6 +443,8 @@ __global__ __launch_bounds__(64) void apply_kernel(const BuildParams P) {
         uint32_t c = un ? (uint32_t)__builtin_ctzll(un) : 64u;
         w.L.cur[lane] = (lane < c) ? nb : ID_EMPTY;
         bool qloaded = false;
+        // the row is the untouched output of select_neighbors (set by add_and_limit, cleared by any plain write)
+        bool selected = P.selected[t] != 0;
         __syncthreads();
 
         while (i < P.n_ops) {
@@ -413,6 +465,7 @@ __global__ __launch_bounds__(64) void apply_kernel(const BuildParams P) {
                     }
                     i += 1;
                 }
+                selected = false;
                 __syncthreads();
                 continue;
             }
@@ -425,6 +478,7 @@ __global__ __launch_bounds__(64) void apply_kernel(const BuildParams P) {
                     if (pos == c) {
                         if (lane == 0) w.L.cur[c] = other;
                         c += 1;
+                        selected = false;
                         __syncthreads();
                     }
                 } else {
@@ -433,13 +487,20 @@ __global__ __launch_bounds__(64) void apply_kernel(const BuildParams P) {
                         qloaded = true;
                         __syncthreads();
                     }
-                    c = w.add_and_limit(c, true, other, d, P.cap); // num_neighbors = node.len(), :916-917
+                    // num_neighbors = node.len(), :916-917. A full row that select_neighbors produced takes the
+                    // one-candidate form of the same computation
+                    uint32_t nc = 0xFFFFFFFFu;
+                    if (selected && c == P.cap && c + 1u <= BUILD_CHUNK) nc = w.add_one_to_selected(c, other, d, P.cap);
+                    if (nc == 0xFFFFFFFFu) nc = w.add_and_limit(c, true, other, d, P.cap);
+                    c = nc;
+                    selected = true;
                 }
             }
             i += 1;
         }
         __syncthreads();
         if (lane < P.W) row[lane] = (lane < c) ? w.L.cur[lane] : ID_EMPTY;
+        if (lane == 0) P.selected[t] = selected ? 1 : 0;
     }
 }
 

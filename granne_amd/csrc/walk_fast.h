@@ -257,13 +257,6 @@ struct FastWalker {
 #endif
     static constexpr bool QREG = F32 && !GEN && (NB * 16 + TU * 4 <= 64) && S == 1 && !GRANNE_HIP_QUERY_IN_LDS;
     static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u;
-#ifndef GRANNE_HIP_SPEC_ROWS
-#define GRANNE_HIP_SPEC_ROWS 1 // 0: no speculative request of the next node's element rows (A/B runs)
-#endif
-    // int8 walks are latency-bound (a quarter of the f32 bytes): the rows of the node that is first in line are
-    // requested one expansion early. f32 walks saturate HBM while a batch is young; there the extra lines cost more
-    // than the shorter tail gives back.
-    static constexpr bool SPEC_ROWS = GRANNE_HIP_SPEC_ROWS && !F32;
     static constexpr uint32_t CAP = 64u * S;
     static_assert(!F32 || GEN || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
@@ -585,151 +578,6 @@ struct FastWalker {
         if (lost == theta && theta != 0xFFFFFFFFu) bail = true;
     }
 
-#ifndef GRANNE_HIP_PIPELINE
-#define GRANNE_HIP_PIPELINE 0 // 1: the rotated loop (measured no faster, kept for A/B runs)
-#endif
-#if GRANNE_HIP_PIPELINE
-    // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
-    //
-    // The reference's loop is pop -> expand -> push. Here the loop is rotated so that the element rows of the
-    // node expanded next are in flight while the candidates of the expansion before are merged into the list:
-    //   E  once the distances of an expansion are in, the node expanded next is known BEFORE its candidates are
-    //      merged: the smaller of y (the list's first unexpanded entry) and the smallest passing candidate K --
-    //      merging changes nothing that sorts before that minimum. y: its flag is set in the list; K: its flag is
-    //      set in the candidate key, it enters the list as an expanded entry (= pop right after push).
-    //      K passed `d <= theta`, so fewer than max_search entries are strictly closer: only y needs mod.rs:1019.
-    //   A  K won: its adjacency row is requested and the merge runs under that load (inside E's branch);
-    //   B  the row loads of the node's neighbors: the ONE load site of the loop (two sites would meet in a phi
-    //      and the register copies at the join wait for data right after requesting it);
-    //   C  y won: its adjacency row was fetched ahead during the expansion before, the row loads went out at
-    //      once -- the merge runs under them;
-    //   F  the adjacency row of the entry that is first in line now is fetched ahead;
-    //   D  visited set (under the loads), distances, filter.
-    // Candidates that are still pending when the walk ends are never merged: they are unexpanded entries, the
-    // result is the expanded ones.
-    __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
-                                                 bool d0_known = false, float d0_value = 0.0f) {
-        PT_RESET();
-        vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
-        L.init_list(mslot, lane);
-        __syncthreads();
-        const gptr_u32 adjg = (gptr_u32)Ly.adj;
-
-        // The entry point is the first pop (a list of one entry never meets mod.rs:1019): it enters the list
-        // expanded. Its distance (mod.rs:1012-1016): on every layer but the first the entry point is the node the
-        // layer above returned as its closest, and its distance to the same query was evaluated there -- the
-        // same operations on the same inputs give the same bits, so the value is reused (the evaluation still
-        // counts) and the layer starts one memory round trip earlier.
-        uint32_t nb_next = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint), one id per pair
-        vis.insert(entrypoint, lane == 0, p.ovf);
-        vis.count = 1;
-        st.n_dist += 1;
-        if (d0_known) {
-            L.set_first(wkey(d0_value, entrypoint) | 1ull, lane);
-        } else {
-            RowRegs r0;
-            issue_rows(entrypoint, r0);
-            const float d0 = finish_rows(r0);
-            L.set_first(readlane64(wkey(d0, entrypoint), 1) | 1ull, lane);
-        }
-        st.n_expand += 1;
-        theta = wkey_hi(L.at(ef - 1));
-
-        uint32_t xid = entrypoint; // the node being expanded
-        bool pass = false;         // candidates of the expansion before, not merged yet
-        uint64_t ck = 0, pm = 0;
-        RowRegs rr;
-        PT_WAIT_VM();
-        PT_MARK(7); // layer setup: tables, entry point distance
-        for (;;) {
-            // B: layer.get_neighbors(idx), mod.rs:1025 / 540-552: row prefix until UNUSED, one id per pair
-            const uint32_t nb = nb_next;
-            PT_WAIT_VM();
-            PT_MARK(8); // wait for the adjacency row
-            PT_COUNT();
-            const uint64_t unused = wave_ballot(nb == ID_EMPTY);
-            const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
-            st.n_adj += nvalid;
-            {   // lanes beyond the row re-read its last neighbor (an empty row: the node itself)
-                const uint32_t last_id = nvalid ? readlane32(nb, 2u * (nvalid - 1u)) : xid;
-                issue_rows((R < nvalid) ? nb : last_id, rr);
-            }
-            PT_MARK(1); // row loads issued
-            // C: y won (or this is the first expansion): the pending candidates are merged under the row loads
-            insert(pm, pass, ck, ef);
-            PT_MARK(6);
-            if (bail) return;
-            // F: fetch ahead the adjacency row of the entry that is first in line now; always one load
-            uint32_t ypos = 0;
-            const bool has_y = L.first_unexpanded(ypos);
-            const uint64_t ykey = has_y ? L.at(ypos) : KEY_INF;
-            nb_next = adjg[(size_t)(has_y ? wkey_id(ykey) : xid) * 32u + R];
-            PT_MARK(0); // first in line, fetch-ahead
-
-            // D: visited set under the loads, then the distances (mod.rs:1026-1027)
-            const bool fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
-            PT_MARK(2); // visited set (under the loads)
-            PT_WAIT_VM();
-            PT_MARK(3); // what is left of the wait for the rows
-            const float d = finish_rows(rr);
-            const uint64_t fm = wave_ballot(fresh);
-            const uint32_t mf = (uint32_t)__popcll(fm);
-            vis.added(mf);
-            st.n_dist += mf;
-            PT_PIN(d);
-            PT_MARK(4); // distances
-            if (!vis.make_room(p.ovf, lane)) bail = true;
-            if (bail) return;
-            const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
-            pass = filter(cand, d, ef);
-            ck = wkey(d, nb);
-            pm = wave_ballot(pass);
-            PT_MARK(5); // filter
-            {
-                [[maybe_unused]] const uint32_t m_ = (uint32_t)__popcll(pm);
-                PT_ADD(0, m_);
-                PT_ADD(1, m_ == 0u ? 1u : 0u);
-                PT_ADD(2, (m_ == 1u || m_ == 2u) ? 1u : 0u);
-                PT_ADD(3, (m_ >= 3u && m_ <= 6u) ? 1u : 0u);
-                PT_ADD(4, m_ > 6u ? 1u : 0u);
-            }
-
-            // E: who is expanded next?
-            uint64_t beat = wave_ballot(pass && ck < ykey); // ykey = KEY_INF without y: every passing candidate
-            if (beat) {
-                uint32_t src = (uint32_t)__builtin_ctzll(beat);
-                uint64_t K = readlane64(ck, src);
-                for (;;) { // the smallest passing key: usually one or two rounds
-                    beat = wave_ballot(pass && ck < K);
-                    if (!beat) break;
-                    src = (uint32_t)__builtin_ctzll(beat);
-                    K = readlane64(ck, src);
-                }
-                if (lane == src) ck |= 1ull;                 // res.push((d, idx)), mod.rs:1023: it enters expanded
-                xid = wkey_id(K);
-                nb_next = adjg[(size_t)xid * 32u + R];
-                // A: merge under that load, HERE: the two definitions of nb_next (this one and F's) meet in a phi
-                // after this branch, and the compiler's register copy at the join waits for the data -- placed
-                // after the merge that wait is the one stage B needs anyway
-                insert(pm, pass, ck, ef);
-                pm = 0;
-                PT_MARK(6);
-                if (bail) return;
-                PT_ADD(5, 1u);
-            } else {
-                if (!has_y) break;                           // pq.pop() on an empty queue, mod.rs:1018
-                // mod.rs:1019-1021 for y. Every entry before y is expanded and at most as far; #{closer} = ypos -
-                // #{ties before y}, so the count is only taken when ypos alone does not decide. No candidate of
-                // this expansion sorts before y: the pending merge changes neither number.
-                if (ypos >= ef && L.count_closer(wkey_hi(ykey)) >= ef) break;
-                L.mark_expanded(ypos, ykey, lane);           // res.push((d, idx)), mod.rs:1023
-                xid = wkey_id(ykey);                          // nb_next holds its row since F
-            }
-            st.n_expand += 1;
-            PT_MARK(9); // next-node decision
-        }
-    }
-#else
     // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
     //
     // One iteration = one expansion: pop, adjacency row, row loads, visited set under them, distances, filter,
@@ -771,7 +619,6 @@ struct FastWalker {
         theta = wkey_hi(L.at(ef - 1));
 
         RowRegs rr;
-        [[maybe_unused]] uint32_t touched = 0; // SPEC_ROWS: the last speculative request (kept until it has landed)
         PT_WAIT_VM();
         PT_MARK(7); // layer setup: tables, entry point distance
         for (;;) {
@@ -820,16 +667,6 @@ struct FastWalker {
             st.n_dist += mf;
             PT_PIN(d);
             PT_MARK(4); // distances
-            if constexpr (SPEC_ROWS) {
-                // y's adjacency row arrived with the element rows. Unless a candidate of this expansion beats it, y is
-                // expanded next -- a thousand cycles of filter, merge and pop from now. Requesting its neighbors'
-                // rows here (one line per row, the data is dropped) turns that expansion's gather into L2 hits; a y
-                // that is beaten stays first in line among the old entries and is expanded soon after. No decision
-                // reads these loads: results and counters cannot change.
-                asm volatile("" ::"v"(touched)); // the request of the expansion before has landed (loads return in order)
-                const uint32_t sid = (pre_nb == ID_EMPTY) ? pre_id : pre_nb;
-                touched = *reinterpret_cast<const uint32_t*>(p.elements + (size_t)sid * ROWB + h * 64u);
-            }
             const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
             const bool pass = filter(cand, d, ef);
             const uint64_t ck = wkey(d, nb);
@@ -865,7 +702,6 @@ struct FastWalker {
             if (bail) return;
         }
     }
-#endif
 };
 
 template <int DT, int DIM, int S, bool TRAIL>
