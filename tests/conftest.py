@@ -4,6 +4,13 @@ import sys
 import numpy as np
 import pytest
 
+# The oracle (oracle/granne_oracle.c) opens one OpenMP region per build batch. The tests build thousands of tiny
+# batches: on a 256-thread host an all-cores team that spin-waits between regions turns seconds into minutes
+# (measured on the GPU box: 16 s vs 285 s for the same tests). A small, sleeping team is plenty here; bench.py's
+# CPU baseline runs in its own process and is not affected.
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, os.cpu_count() or 1))))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

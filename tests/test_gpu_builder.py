@@ -28,6 +28,11 @@ CASES = [
     (3000, 100, True, 30, 40, False, 512),
     (700, 3, False, 10, 20, True, 32),
     (40, 16, False, 30, 200, True, 65536),
+    # rows of num_neighbors + 1 = 32 candidates still take the one-candidate form of add_and_limit_neighbors,
+    # 33 do not (builder_kernels.h, add_one_to_selected); low dimensions prune hard, rows fill and empty again
+    (2000, 6, False, 31, 40, True, 128),
+    (1500, 6, False, 32, 40, True, 128),
+    (2500, 8, True, 30, 40, True, 256),
 ]
 
 
@@ -53,6 +58,24 @@ def test_gpu_build_equals_oracle_batched_build(ga, oracle, n, dim, int8, nn, ms,
     ids, ds, cnt = gix.search_batch(q, 30, 10)
     oi, od, oc, _ = oix.search_batch(q, 30, 10)
     assert (ids == oi).all() and ds.tobytes() == od.tobytes() and (cnt == oc).all()
+
+
+@pytest.mark.parametrize("int8", [False, True])
+def test_clustered_points_prune_and_refill_rows(ga, oracle, int8):
+    """Tight clusters: select_neighbors (src/index/mod.rs:849-883) drops most of a full row, the row refills by
+    plain appends (connect_nodes, :898-921) and is limited again -- every mix of the full and the one-candidate
+    pass of add_and_limit_neighbors, graph for graph against the oracle."""
+    rng = np.random.default_rng(77)
+    centers = random_floats(rng, 25, 24)
+    raw = centers[rng.integers(0, 25, 4000)] + 0.05 * random_floats(rng, 4000, 24)
+    el = prep(oracle, raw.astype(np.float32), int8)
+    b = ga.GranneBuilder("angular_int" if int8 else "angular", el, num_neighbors=30, max_search=60, batch_max=512)
+    b.build()
+    oix = oracle.build_index(el, num_neighbors=30, max_search=60, batch_max=512, batch_div=8, n_threads=0)
+    for l, want in enumerate(oix.layers):
+        got = b.get_layer(l)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (l, bad[:5])
 
 
 def test_duplicates_and_zero_vectors(ga, oracle):
