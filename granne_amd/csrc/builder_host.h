@@ -237,6 +237,7 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     const uint32_t lrow = ((b->row_bytes / 16) | 1u) * 16u;
     const BuildKernels K = pick_build_kernels(b->dtype, b->dim);
     const uint32_t lds = build_lds_bytes(lrow, cap);
+    const uint32_t lds_rows = build_lds_bytes_rows(lrow, cap); // apply / final_prune (<= lds)
     if (lds > 160u * 1024u)
         return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the GPU builder: select_neighbors stages %u candidate rows "
                     "of %u bytes in LDS (%u bytes, a CU has 163840)", cap + 1, lrow, lds);
@@ -327,14 +328,14 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
                            S.seg_start, S.counters);
         HIP_TRY(hipGetLastError());
         uint32_t grid = P.n_ops < 4096 ? P.n_ops : 4096;
-        hipLaunchKernelGGL(K.apply, dim3(grid), dim3(64), lds, s, P);
+        hipLaunchKernelGGL(K.apply, dim3(grid), dim3(64), lds_rows, s, P);
         HIP_TRY(hipGetLastError());
         dbg("apply", pos, B);
         pos += B;
     }
     // limit number of neighbors, src/index/mod.rs:795-797
     uint32_t grid = layer_len < 8192 ? (uint32_t)layer_len : 8192u;
-    hipLaunchKernelGGL(K.final_prune, dim3(grid ? grid : 1), dim3(64), lds, s, P);
+    hipLaunchKernelGGL(K.final_prune, dim3(grid ? grid : 1), dim3(64), lds_rows, s, P);
     HIP_TRY(hipGetLastError());
     dbg("final_prune", total, 0);
     return GRANNE_HIP_OK;

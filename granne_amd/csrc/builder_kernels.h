@@ -78,6 +78,14 @@ __host__ __device__ inline uint32_t build_lds_bytes(uint32_t lrow, uint32_t cap)
     // the pairwise matrix shares the selected-rows stage when that is large enough
     return lrow * (1 + BUILD_CHUNK + cap) + (lrow * cap < PAIR_BYTES ? PAIR_BYTES : 0u) + BUILD_MAX_CAND * 8 + 64 * 4 * 4;
 }
+// apply_kernel / final_prune_kernel only ever limit a row of at most cap + 1 candidates: while that is one chunk
+// (select_neighbors_pairs) the selected-rows stage is never touched and is left out -- 21 KB instead of 29 KB per
+// wave at 100-d f32, seven waves per CU instead of five
+__host__ __device__ inline bool build_lds_compact(uint32_t cap) { return cap + 1u <= BUILD_CHUNK; }
+__host__ __device__ inline uint32_t build_lds_bytes_rows(uint32_t lrow, uint32_t cap) {
+    if (!build_lds_compact(cap)) return build_lds_bytes(lrow, cap);
+    return lrow * (1 + BUILD_CHUNK) + PAIR_BYTES + BUILD_MAX_CAND * 8 + 64 * 4 * 4;
+}
 
 template <int DT, int DIM>
 struct RowWork {
@@ -85,14 +93,17 @@ struct RowWork {
     BuildLds L;
     uint32_t lane;
 
-    __device__ __forceinline__ RowWork(const BuildParams& p, uint8_t* smem) : P(p) {
+    // rows_only: the layout of build_lds_bytes_rows (no selected-rows stage)
+    __device__ __forceinline__ RowWork(const BuildParams& p, uint8_t* smem, bool rows_only = false) : P(p) {
         lane = threadIdx.x;
         L.qrow = smem;
         L.chunk = smem + p.lrow;
         L.selrows = L.chunk + (size_t)BUILD_CHUNK * p.lrow;
         uint8_t* a = L.selrows + (size_t)p.cap * p.lrow;
         L.pair = reinterpret_cast<float*>(L.selrows);
-        if (p.lrow * p.cap < PAIR_BYTES) {
+        if (rows_only && build_lds_compact(p.cap)) {
+            a = L.selrows + PAIR_BYTES;
+        } else if (p.lrow * p.cap < PAIR_BYTES) {
             L.pair = reinterpret_cast<float*>(a);
             a += PAIR_BYTES;
         }
@@ -430,7 +441,7 @@ __global__ void mark_heads_kernel(const uint64_t* __restrict__ keys, uint32_t n_
 template <int DT, int DIM>
 __global__ __launch_bounds__(64) void apply_kernel(const BuildParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
-    RowWork<DT, DIM> w(P, smem);
+    RowWork<DT, DIM> w(P, smem, true);
     const uint32_t lane = threadIdx.x;
     const uint32_t n_seg = *P.n_seg;
     for (uint32_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(64) void apply_kernel(const BuildParams P) {
 template <int DT, int DIM>
 __global__ __launch_bounds__(64) void final_prune_kernel(const BuildParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
-    RowWork<DT, DIM> w(P, smem);
+    RowWork<DT, DIM> w(P, smem, true);
     const uint32_t lane = threadIdx.x;
     for (uint64_t t = blockIdx.x; t < P.layer_len; t += gridDim.x) {
         uint32_t* row = P.adj + (size_t)t * P.W;
