@@ -587,8 +587,10 @@ struct FastWalker {
     //    the candidates that pass the filter, since merging changes nothing that sorts before that minimum.
     //    When a candidate wins (half of the expansions at max_search 50) its adjacency row is requested
     //    right there and arrives under the merge instead of after it.
-    // (A fully software-pipelined variant that also issued y's ROW loads before the merge was measured and
-    // dropped: +40 % scalar instructions for the bookkeeping, launch time 3-5 % worse)
+    // Measured and dropped (the phase clocks of tools/phase_probe.py say why): a rotated loop that
+    // puts the next node's ROW loads in flight under the merge (twice, rounds 2a and 2b: the bookkeeping costs
+    // what the overlap gives), and a speculative request of y's neighbor rows one expansion early (int8: 6 %
+    // slower per launch -- the lines arrive no sooner than the compute that follows them needs).
     // The row loads have one site in the loop: two sites would meet in a phi, and the register copies at the
     // join wait for the data right after issuing it.
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
