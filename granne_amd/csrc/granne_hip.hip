@@ -586,12 +586,12 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
     }
     P.visited_slots = want;
     P.upper_slots = want < 1024 ? want : 1024;
-    if (fastS) { // walk_fast.h: [query][64*S keys][visited front table]
+    if (fastS) { // walk_fast.h: [query][S >= 8: 64*S keys][visited front table]
         P.maxc = 0;
         P.lrow_bytes = 16;
         P.stage_bytes = 0;
         P.adjspec_bytes = 0;
-        P.lds_bytes = fast_lds_bytes(fast_generic(ix), ix->dim, ix->row_bytes, fastS, P.visited_slots);
+        P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, P.visited_slots);
         return P;
     }
     const bool reg_spec = false; // (the compile-time-dim f32 kernels moved to walk_fast.h)

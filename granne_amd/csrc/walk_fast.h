@@ -232,10 +232,24 @@ struct WalkList : SortedList<S> {
     }
 };
 
-// LDS bytes of the query. Compile-time dims and i8: the row itself. Run-time f32 dims (DIM == 0): full
+#ifndef GRANNE_HIP_QUERY_IN_LDS
+#define GRANNE_HIP_QUERY_IN_LDS 0 // experiments: 1 = the short list reads an f32 query from LDS too
+#endif
+// A query that lives in registers needs no LDS of its own: int8 rows (64 bytes per lane; staged once through the
+// start of the visited table, before that table's first reset) and, for the short list, f32 rows of the unrolled
+// dims (this lane's pieces in VGPRs; longer lists need the registers and read the query from LDS, 13 ds_read_b128
+// per expansion at 100-d, issued under the row loads). At 4096 visited slots the walker's LDS is then the table
+// alone, 16 KB: ten walkers per CU.
+__host__ __device__ constexpr bool fast_query_in_regs(bool i8, bool gen, uint32_t dim, uint32_t S) {
+    if (i8) return true;
+    if (gen || S != 1u || GRANNE_HIP_QUERY_IN_LDS) return false;
+    return (dim / 32u) * 16u + ((dim % 32u) / 4u) * 4u <= 64u;
+}
+// LDS bytes of the query. f32 rows of a compile-time dim: the row itself. Run-time f32 dims (DIM == 0): full
 // 32-float chunks padded with zero chunks to a whole number of groups of three, then one 128-byte tail block.
 constexpr uint32_t GEN_GROUP = 3; // chunks whose loads are in flight together (12 x 16 bytes per lane)
-__host__ __device__ inline uint32_t fast_query_bytes(bool gen, uint32_t dim, uint32_t row_bytes) {
+__host__ __device__ inline uint32_t fast_query_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S) {
+    if (fast_query_in_regs(i8, gen, dim, S)) return 0u;
     if (!gen) return lds_query_bytes(row_bytes);
     const uint32_t nbk = dim / 32u;
     const uint32_t ngroups = (nbk + GEN_GROUP - 1u) / GEN_GROUP;
@@ -250,20 +264,15 @@ struct FastWalker {
     static constexpr bool GEN = F32 && DIM == 0;
     static constexpr int NB = F32 ? (GEN ? (int)GEN_GROUP : DIM / 32) : 0; // full 32-float chunks (GEN: per group)
     static constexpr int TU = F32 ? (DIM % 32) / 4 : 0;  // 16-byte units of the tail
-    // this lane's query pieces live in VGPRs for the short list; longer lists need the registers and read
-    // the query from LDS (13 ds_read_b128 per expansion at 100-d, issued under the row loads)
-#ifndef GRANNE_HIP_QUERY_IN_LDS
-#define GRANNE_HIP_QUERY_IN_LDS 0 // experiments: 1 = the short list reads the query from LDS too
-#endif
-    static constexpr bool QREG = F32 && !GEN && (NB * 16 + TU * 4 <= 64) && S == 1 && !GRANNE_HIP_QUERY_IN_LDS;
+    static constexpr bool QREG = F32 && fast_query_in_regs(false, GEN, (uint32_t)DIM, (uint32_t)S);
     static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u;
     static constexpr uint32_t CAP = 64u * S;
     static_assert(!F32 || GEN || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
     const SearchParams& p;
     uint32_t lane, h, R;
-    uint8_t* lds_q;       // the query (f32 without QREG: read per expansion; i8: staging)
-    uint64_t* mslot;      // CAP keys: scatter space of the bulk merge
+    uint8_t* lds_q;       // the query (f32 without QREG: read per expansion; i8: staging, shared with the visited table)
+    uint64_t* mslot;      // lists with an LDS mirror (S >= 8): CAP keys, the mirror = the scatter space of the bulk merge
     uint32_t* vis_tab;
     float qh[QREG ? NB * 16 : 1];
     float qt[(QREG && TU) ? TU * 4 : 1];
@@ -285,13 +294,13 @@ struct FastWalker {
         lane = threadIdx.x;
         h = lane & 1u;
         R = lane >> 1;
-        const uint32_t qb = fast_query_bytes(GEN, p.dim, p.row_bytes);
+        const uint32_t qb = fast_query_bytes(!F32, GEN, p.dim, p.row_bytes, (uint32_t)S);
         g_nbk = p.dim / 32u;
         g_ngroups = (g_nbk + GEN_GROUP - 1u) / GEN_GROUP;
         g_tu = ((p.dim & 31u) + 3u) / 4u;
         lds_q = smem;
         mslot = reinterpret_cast<uint64_t*>(smem + qb);
-        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + CAP * 8u);
+        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + (WalkList<S>::MIRROR ? CAP * 8u : 0u));
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
         sy = 0.0f;
@@ -557,13 +566,10 @@ struct FastWalker {
     // in bulk. An entry pushed off the end is dead unless its distance ties with the entry that is number
     // max_search-1 once all candidates of the expansion are in (then max_search entries are not STRICTLY
     // closer): the smallest lost distance is compared with that entry once, after the last insert.
-#ifndef GRANNE_HIP_BULK_MIN
-#define GRANNE_HIP_BULK_MIN 999 // experiments: short lists merge in bulk from this many candidates on
-#endif
     __device__ __forceinline__ void insert(uint64_t pm, bool pass, uint64_t ck, uint32_t ef) {
         const uint32_t m = (uint32_t)__popcll(pm);
         if (m == 0) return;
-        if (WalkList<S>::MIRROR || m >= (uint32_t)GRANNE_HIP_BULK_MIN) {
+        if constexpr (WalkList<S>::MIRROR) {
             merge(pm, m, pass, ck, ef);
             theta = wkey_hi(L.at(ef - 1));
             return;
@@ -804,7 +810,7 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
     }
 }
 
-// Block b walks query b (one wavefront). LDS: [query][CAP keys of merge space][visited front table].
+// Block b walks query b (one wavefront). LDS: [query][S >= 8: the list's mirror, CAP keys][visited front table].
 // waves per SIMD the register allocator is asked to keep possible (__launch_bounds__'s second argument is
 // per SIMD on AMD; 5 waves = 96 VGPRs, 4 = 128, 3 = 168, 2 = 256). Chosen from the unconstrained
 // allocation of each instantiation so that none spills (tools/isa_report.py prints both).
@@ -824,8 +830,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S)) void fast_kern
     if (blockIdx.x < p.nq) fast_walk_one<DT, DIM, S, TRAIL>(p, blockIdx.x, smem);
 }
 
-__host__ __device__ inline uint32_t fast_lds_bytes(bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {
-    return fast_query_bytes(gen, dim, row_bytes) + 64u * S * 8u + visited_slots * 4u;
+__host__ __device__ inline uint32_t fast_lds_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {
+    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (S >= 8u ? 64u * S * 8u : 0u) + visited_slots * 4u;
 }
 
 } // namespace granne_hip
