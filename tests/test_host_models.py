@@ -1,0 +1,135 @@
+"""CPU models of two device-side arguments, replayed against the reference's plain algorithms.
+
+* tools/model_unified.py: the walker's ONE sorted list with expanded flags and its once-per-expansion tie test
+  (walk_fast.h, insert_sorted) against the reference's two heaps (src/index/mod.rs:999-1037) on tie-heavy graphs.
+* the builder's one-candidate form of add_and_limit_neighbors (builder_kernels.h, add_one_to_selected) against the
+  full sort + select_neighbors pass (src/index/mod.rs:849-883, 923-959) over rows that fill, get limited, refill.
+"""
+import importlib.util
+import os
+import random
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sorted_list_with_deferred_tie_test_equals_two_heaps():
+    spec = importlib.util.spec_from_file_location("model_unified", os.path.join(ROOT, "tools", "model_unified.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rnd = random.Random(11)
+    equal = bailed = 0
+    for it in range(700):
+        n = rnd.choice([5, 20, 80, 300])
+        deg = rnd.choice([2, 4, 8, 15, 30])
+        ef = rnd.choice([1, 2, 5, 10, 50, 60, 64])
+        adj = [rnd.sample(range(n), min(deg, n)) for _ in range(n)]
+        mode = rnd.choice(["float", "int_small", "int_tiny"])
+        dv = [rnd.random() if mode == "float" else rnd.randrange(50 if mode == "int_small" else 4) / 50.0 for _ in range(n)]
+        ep = rnd.randrange(n)
+        r0, c0 = m.reference(adj, dv.__getitem__, ep, ef)
+        r1, c1 = m.unified(adj, dv.__getitem__, ep, ef, 64, deferred=bool(it & 1))
+        if r1 is None:
+            bailed += 1
+            continue
+        assert r0 == r1 and c0 == c1, (it, mode, n, deg, ef)
+        equal += 1
+    assert equal > 500 and bailed > 0  # both outcomes are exercised
+
+
+def _dist(a, b):
+    r = np.float32(1.0) - np.float32(np.dot(a, b))
+    return float(r) if r > 0 else 0.0
+
+
+def _select(el, cands, m):
+    """select_neighbors, src/index/mod.rs:849-883: cands = [(id, d)] sorted ascending."""
+    if len(cands) <= m:
+        return list(cands)
+    out = []
+    for j, d in cands:
+        if len(out) >= m:
+            break
+        if all(d <= _dist(el[n], el[j]) for n, _ in out):
+            out.append((j, d))
+    return out
+
+
+def _full(el, node, row, x, cap):
+    """add_and_limit_neighbors with one extra candidate, src/index/mod.rs:923-959 (ties by id)."""
+    cands = [(j, _dist(el[node], el[j])) for j in row] + [(x, _dist(el[node], el[x]))]
+    cands.sort(key=lambda c: (c[1], c[0]))
+    return [j for j, _ in _select(el, cands, cap)]
+
+
+def _one_candidate(el, node, row, x, cap):
+    """builder_kernels.h, add_one_to_selected: `row` is full and the untouched output of select_neighbors."""
+    c = len(row)
+    d = [_dist(el[node], el[j]) for j in row]
+    e = [_dist(el[j], el[x]) for j in row]
+    keys = [(d[i], row[i]) for i in range(c)]
+    assert keys == sorted(keys)
+    dx = _dist(el[node], el[x])
+    p = sum(1 for k in keys if k < (dx, x))
+    if p >= cap or any(not (dx <= e[i]) for i in range(p)):
+        return list(row)
+    keep = [row[i] for i in range(c) if i < p or d[i] <= e[i]]
+    return (keep[:p] + [x] + keep[p:])[:cap]
+
+
+def _replay(el, nodes, cap, rng, pool=150, cands=None):
+    """connect_nodes (src/index/mod.rs:898-921) for a stream of near neighbors per node; every time the row is full and
+    is the untouched output of the pass before, the one-candidate form must give what the full pass gives."""
+    took_short = changed = 0
+    for node in nodes:
+        # link candidates are near neighbors, as in a build
+        near = np.asarray(cands[node]) if cands is not None else np.argsort(-(el @ el[node]))[:pool]
+        row, selected = [], False
+        for x in rng.permutation(near).tolist():
+            if x == node or x in row:
+                continue
+            if len(row) < cap:  # a free place, :912-914
+                row.append(x)
+                selected = False
+                continue
+            want = _full(el, node, row, x, cap)
+            if selected:
+                got = _one_candidate(el, node, row, x, cap)
+                assert got == want, (node, x, cap)
+                took_short += 1
+                changed += got != row
+            row, selected = want, True
+    return took_short, changed
+
+
+def test_one_candidate_add_and_limit_equals_the_full_pass():
+    rng = np.random.default_rng(5)
+    short = changed = 0
+    # random points: select_neighbors prunes hard, small rows stay full now and then
+    for dim, cap in [(100, 4), (48, 6), (16, 5), (6, 3)]:
+        raw = rng.random((500, dim), dtype=np.float32) - np.float32(0.5)
+        el = (raw / np.linalg.norm(raw, axis=1, keepdims=True)).astype(np.float32)
+        a, b = _replay(el, range(30), cap, rng)
+        short, changed = short + a, changed + b
+    # shells: the neighbors of a center sit at center + eps * (its own direction), so each is closer to the center than
+    # to the others (rows of 30 stay full and the newcomer mostly just takes its sorted place) -- except for pairs
+    # that share a direction, where the closer one displaces the other
+    for dim in (64, 100):
+        rows, cands = [], {}
+        for c in range(12):
+            center = rng.standard_normal(dim).astype(np.float32)
+            center /= np.linalg.norm(center)
+            g = rng.standard_normal((100, dim)).astype(np.float32)
+            g[60:] = g[rng.integers(0, 60, 40)] + np.float32(0.15) * rng.standard_normal((40, dim)).astype(np.float32)
+            g /= np.linalg.norm(g, axis=1, keepdims=True)
+            pts = center + rng.uniform(0.2, 0.7, (100, 1)).astype(np.float32) * g
+            cands[len(rows)] = list(range(len(rows) + 1, len(rows) + 101))
+            rows.append(center)
+            rows.extend(pts)
+        raw = np.asarray(rows, np.float32)
+        el = (raw / np.linalg.norm(raw, axis=1, keepdims=True)).astype(np.float32)
+        a, b = _replay(el, list(cands), 30, rng, cands=cands)
+        assert a > 200, a  # full rows of 30 did take the short form
+        short, changed = short + a, changed + b
+    assert short > 1000 and changed > 50, (short, changed)

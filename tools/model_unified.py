@@ -11,7 +11,11 @@ keys (dist, id) with an `expanded` flag per entry:
                            entries are in the list, `worst` is the max_search-th of them;
   * dead candidates      (>= max_search entries strictly closer) are not inserted;
   * an entry that falls off the end is provably dead unless it ties with entry max_search-1:
-    then the walk is abandoned (handed to the exact global-memory walker).
+    then the walk is abandoned (handed to the exact global-memory walker). The kernel takes that
+    test once per expansion (insert_sorted: the smallest lost distance against entry max_search-1
+    AFTER the expansion's last insert -- that entry only moves closer while candidates go in, so a
+    lost entry that does not tie with it then has max_search entries strictly closer); the model
+    runs both forms (`deferred`).
 This script replays both on random graphs -- including integer distances full of ties -- and
 asserts equal results and counters whenever the model does not bail.  Not product code.
 """
@@ -44,7 +48,7 @@ def reference(adj, dist, ep, ef):
     return sorted((-a, -b) for a, b in res), (n_dist, n_expand, n_adj)
 
 
-def unified(adj, dist, ep, ef, cap):
+def unified(adj, dist, ep, ef, cap, deferred=True):
     """The list walker with walk_fast.h's control flow: the next node is decided (and its break test
     taken) BEFORE the candidates of the current expansion are merged."""
     L = [[dist(ep), ep, True]]  # ascending by (dist, id); third field = expanded. The entry point is popped at once
@@ -79,13 +83,17 @@ def unified(adj, dist, ep, ef, cap):
             if ypos >= ef and sum(1 for e in L if e[0] < ykey[0]) >= ef:
                 break
             nxt = ykey[1]
+        lost = None
         for dn, n in cands:
             keys = [(e[0], e[1]) for e in L]
             L.insert(bisect.bisect_left(keys, (dn, n)), [dn, n, False])
             while len(L) > cap:
                 y = L.pop()
-                if y[0] == L[ef - 1][0]:
+                if not deferred and y[0] == L[ef - 1][0]:
                     return None, None  # bail: not provably dead
+                lost = y[0] if lost is None else min(lost, y[0])
+        if deferred and lost is not None and lost == L[ef - 1][0]:
+            return None, None  # bail: the closest lost entry ties with entry max_search-1
         p = next(i for i, e in enumerate(L) if not e[2])
         assert L[p][1] == nxt, "the decision taken before the merge must name the first unexpanded entry after it"
         L[p][2] = True
@@ -118,13 +126,14 @@ def main():
         dist = dv.__getitem__
         ep = rnd.randrange(n)
         r0, c0 = reference(adj, dist, ep, ef)
-        r1, c1 = unified(adj, dist, ep, ef, cap)
+        deferred = bool(it & 1)
+        r1, c1 = unified(adj, dist, ep, ef, cap, deferred)
         trials += 1
         if r1 is None:
             bails += 1
             continue
-        assert r0 == r1, (it, mode, n, deg, ef, r0[:5], r1[:5])
-        assert c0 == c1, (it, mode, n, deg, ef, c0, c1)
+        assert r0 == r1, (it, mode, deferred, n, deg, ef, r0[:5], r1[:5])
+        assert c0 == c1, (it, mode, deferred, n, deg, ef, c0, c1)
     print("ok: %d walks equal, %d bailed (ties at the boundary)" % (trials - bails, bails))
 
 
