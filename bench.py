@@ -318,6 +318,24 @@ class Bench:
         got = got.cpu().numpy()
         return float(np.mean([len(set(gt[i]) & set(got[i])) / k for i in range(gt.shape[0])]))
 
+    def launch_scaling(self, index, data, dim, dtype, ef, k, batches=(4096, 16384)):
+        """The same kernel with more walks per launch, one launch at a time: finished walks' SIMDs are refilled from
+        the same grid, so the per-launch roofline fraction shows what the batch of 1024 leaves idle.
+        Not the headline: BASELINE.json fixes the batch."""
+        esize = 4 if dtype == "f32" else 1
+        out = []
+        for nq in batches:
+            steps, warmup = 4, 1
+            q = self.rows(data, SEED + 3, 0, (steps + warmup) * nq, dim, dtype)
+            m = self.measure(index, q, dim, esize, nq, ef, k, steps, warmup, 1)
+            out.append({"batch": nq, "launch_ms_mean": round(m["launch_ms_mean"], 4),
+                        "frac": round(m["achieved"] / HBM_PEAK_GBPS, 4),
+                        "qps_one_launch_at_a_time": round(steps * nq / m["seq_elapsed"], 1),
+                        "slow_path_queries": m["slow"]})
+            del m, q
+            self.torch.cuda.empty_cache()
+        return out
+
     def ef_sweep(self, index, queries, gt, nq, k, efs, steps, warmup, stop_at=None):
         """recall@10 (first timed batch) and queries/sec (K batches, one at a time and three in flight)."""
         torch = self.torch
@@ -501,6 +519,8 @@ def run_replica(B, args):
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
         if world == 1 and not args.no_extras:
             out["latency_nq1"] = B.latency_nq1(index, queries, dim, ef, k)
+            if order is None:
+                out["launch_scaling"] = B.launch_scaling(index, args.data, dim, args.dtype, ef, k)
         del m
         if world == 1 and not args.no_extras and args.dtype == "f32" and args.data == "uniform" and order is None:
             del index, builder, elements, queries
@@ -541,6 +561,8 @@ def sub_record(B, args, dtype, data):
         "recall_at_10": round(B.recall(gt, m["ids"][warmup], k), 4),
         "roofline": B.roofline(m, wl_key, m["value_local"], nq),
     })
+    if data == "uniform":
+        rec["launch_scaling"] = B.launch_scaling(index, data, dim, dtype, ef, k)
     if args.cpu_batches > 0:
         nb = min(4, steps)
         h_q = queries[warmup * nq:(warmup + nb) * nq].cpu().numpy()

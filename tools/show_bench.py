@@ -25,6 +25,10 @@ for k in ("ef_sweep",):
         print("ef_sweep:", " ".join("%d:%.3f/%.0fk/%.0fk" % (s["ef"], s["recall_at_10"], s["qps"] / 1e3, s["qps_one_batch_at_a_time"] / 1e3) for s in d[k]))
 if "secondary" in d and "ef_sweep" in d["secondary"]:
     print("secondary sweep:", " ".join("%d:%.3f/%.0fk" % (s["ef"], s["recall_at_10"], s["qps"] / 1e3) for s in d["secondary"]["ef_sweep"]))
+for tag, r in (("f32", d), ("int8", d.get("int8", {}))):
+    if "launch_scaling" in r:
+        print("launch_scaling %s:" % tag, " ".join("%d:%.4fms/frac %.3f/%.0fk" % (x["batch"], x["launch_ms_mean"], x["frac"], x["qps_one_launch_at_a_time"] / 1e3)
+                                                    for x in r["launch_scaling"]))
 for k in ("latency_nq1", "phases_ms", "exchange"):
     if k in d:
         print(k, d[k])
