@@ -594,33 +594,27 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, P.visited_slots);
         return P;
     }
-    const bool reg_spec = false; // (the compile-time-dim f32 kernels moved to walk_fast.h)
-    P.adjspec_bytes = (reg_spec || ix->dtype == GRANNE_HIP_I8) ? 0u : LDS_ADJSPEC_BYTES; // Walker::REGSPEC
+    // the general walker (search_kernel.h): int8 keeps its speculative adjacency rows in registers (Walker::REGSPEC),
+    // run-time-dim f32 parks them in LDS
+    P.adjspec_bytes = ix->dtype == GRANNE_HIP_I8 ? 0u : LDS_ADJSPEC_BYTES;
     uint32_t fixed = lds_query_bytes(ix->row_bytes) + LDS_FIXED_BYTES + P.adjspec_bytes;
     if (ix->dtype == GRANNE_HIP_F32) {
         uint32_t row16 = ix->row_bytes / 16;
         P.lrow_bytes = (row16 | 1u) * 16u; // odd number of 16-byte units: conflict-free ds_read_b128
-        if (reg_spec) {
-            // the fast expansion (search_kernel.h, fast_rows) keeps rows in registers; an LDS stage
-            // is only needed by the whole-row path that serves layers wider than 32 ids
-            P.stage_bytes = ix->max_dev_width > 32 ? 8u * P.lrow_bytes : 0u;
-            P.maxc = P.stage_bytes / P.lrow_bytes;
-        } else {
-            uint32_t wmax = ix->max_dev_width < 64 ? ix->max_dev_width : 64;
-            uint32_t used = fixed + P.visited_slots * 4u;
-            auto rows_in = [&](uint32_t budget) { return budget > used ? (budget - used) / P.lrow_bytes : 0u; };
-            uint32_t maxc = rows_in(40u * 1024u);
-            if (maxc < 16) maxc = rows_in(64u * 1024u) < 32u ? rows_in(64u * 1024u) : 32u;
-            if (maxc < 16) maxc = rows_in(160u * 1024u) < 32u ? rows_in(160u * 1024u) : 32u;
-            if (maxc > wmax) maxc = wmax;
-            if (const char* e = getenv("GRANNE_HIP_MAXC")) {
-                uint32_t v = (uint32_t)atoi(e);
-                if (v >= 1 && v <= 64) maxc = v;
-            }
-            if (maxc < 1) maxc = 1;
-            P.maxc = maxc;
-            P.stage_bytes = P.maxc * P.lrow_bytes;
+        uint32_t wmax = ix->max_dev_width < 64 ? ix->max_dev_width : 64;
+        uint32_t used = fixed + P.visited_slots * 4u;
+        auto rows_in = [&](uint32_t budget) { return budget > used ? (budget - used) / P.lrow_bytes : 0u; };
+        uint32_t maxc = rows_in(40u * 1024u);
+        if (maxc < 16) maxc = rows_in(64u * 1024u) < 32u ? rows_in(64u * 1024u) : 32u;
+        if (maxc < 16) maxc = rows_in(160u * 1024u) < 32u ? rows_in(160u * 1024u) : 32u;
+        if (maxc > wmax) maxc = wmax;
+        if (const char* e = getenv("GRANNE_HIP_MAXC")) {
+            uint32_t v = (uint32_t)atoi(e);
+            if (v >= 1 && v <= 64) maxc = v;
         }
+        if (maxc < 1) maxc = 1;
+        P.maxc = maxc;
+        P.stage_bytes = P.maxc * P.lrow_bytes;
     } else {
         P.maxc = 0;
         P.lrow_bytes = 16;
@@ -742,11 +736,6 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.slow_list = (uint32_t*)(scratch + off_list);
     p.force_slow = all_slow ? 1 : 0;
     p.spec = 1;
-    // The candidates' adjacency rows can ride along with the row gather (SearchParams::spec_ticks).
-    // Measured on MI355X at C2: no gain with one batch in flight (2.54M vs 2.54M queries/s), 10-25 % lost
-    // with three (the rows are 20 % of the traffic) at every threshold tried -> off unless asked for.
-    p.spec_ticks = 0;
-    if (const char* e = getenv("GRANNE_HIP_SPEC_TICKS")) p.spec_ticks = (uint32_t)strtoul(e, nullptr, 10); // experiments
     p.ovf.tables = (uint32_t*)(scratch + off_ovf);
     p.ovf.state = (uint32_t*)(scratch + off_state);
     p.ovf.slots = ovf_slots;

@@ -64,9 +64,6 @@ struct SearchParams {
     uint32_t* slow_list;     // [nq]
     uint32_t force_slow;
     uint32_t spec;           // 1: speculative adjacency prefetch (narrow layers)
-    uint32_t spec_ticks;     // fast expansion: the candidates' adjacency rows ride along with the row gather
-                             // while the gather of the previous expansion came back within this many
-                             // s_memrealtime ticks (100 MHz); 0 = never, ~0u = always
     OverflowPool ovf;        // global overflow tables of the visited sets (wave_prims.h)
     // trail mode (Granne::reorder, src/index/reorder.rs:180-208): instead of a search, walk layers
     // 0..trail_layers-1 with max_search 1, each from node 0, and record the ids found
