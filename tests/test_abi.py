@@ -37,6 +37,22 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(raw, name), name
 
 
+def test_rust_binding_in_integration_md_declares_the_whole_header():
+    """INTEGRATION.md's src/gpu.rs: every entry point of include/granne_hip.h is declared, with exactly the
+    types the header has (tools/gen_rust_sys.py derives the Rust declaration from the C prototype)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_sys", os.path.join(ROOT, "tools", "gen_rust_sys.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    doc = re.sub(r"\s+", "", open(os.path.join(ROOT, "INTEGRATION.md")).read())
+    names = []
+    for name, ret, params in g.protos():
+        names.append(name)
+        assert re.sub(r"\s+", "", g.decl(name, ret, params)) in doc, name
+    assert sorted(names) == _declared()
+    assert not set(re.findall(r"fn(granne_hip_[a-z0-9_]+)\(", doc)) - set(names)  # nothing bound that the header lacks
+
+
 def test_abi_version(lib):
     assert lib.granne_hip_abi_version() == 2
 
