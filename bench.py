@@ -564,7 +564,8 @@ def sub_record(B, args, dtype, data):
     if data == "uniform":
         rec["launch_scaling"] = B.launch_scaling(index, data, dim, dtype, ef, k)
     if args.cpu_batches > 0:
-        nb = min(4, steps)
+        nb = min(args.cpu_batches, steps)  # the same bounded sample as the main record (a few thousand queries finish
+        # in hundredths of a second on 128 threads: thread wake-up, not search, is what such a sample times)
         h_q = queries[warmup * nq:(warmup + nb) * nq].cpu().numpy()
         g_ids = m["ids"][warmup:warmup + nb].reshape(-1, k).cpu().numpy().astype(np.uint64)
         g_d = m["dists"][warmup:warmup + nb].reshape(-1, k).cpu().numpy()
