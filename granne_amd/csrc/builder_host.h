@@ -27,6 +27,7 @@ struct granne_hip_builder {
     uint32_t W = 32; // device row width
     std::vector<BuilderLayer> layers;
     uint64_t hbm_bytes = 0;
+    ScratchCache scratch; // the build's searches (search_launch)
 };
 
 extern "C" void granne_hip_build_config_default(granne_hip_build_config* c) {
@@ -60,6 +61,7 @@ static void destroy_builder(granne_hip_builder* b) {
     if (b->d_elements) (void)hipFree(b->d_elements);
     for (auto& L : b->layers)
         if (L.d_adj) (void)hipFree(L.d_adj);
+    b->scratch.free_all();
     delete b;
 }
 
@@ -262,6 +264,7 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     T.opt_slow_slots = 1u << 18;
     T.opt_slow_blocks = 16;
     T.opt_overflow_slots = 0;
+    T.scratch = &b->scratch;
 
     BuildParams P;
     P.elements = b->d_elements;

@@ -72,6 +72,22 @@ extern "C" int granne_hip_device_count(int* out_count) {
 // ------------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------------
+// search_launch's scratch blocks, one per stream that has searched (see scratch_for)
+struct ScratchCache {
+    struct Block {
+        hipStream_t stream;
+        uint8_t* p;
+        size_t cap;
+    };
+    std::mutex mu;
+    std::vector<Block> blocks;
+    void free_all() {
+        for (auto& b : blocks)
+            if (b.p) (void)hipFree(b.p);
+        blocks.clear();
+    }
+};
+
 struct LayerHost {
     uint64_t len = 0;
     uint32_t width = 0;     // caller's row width
@@ -106,11 +122,10 @@ struct granne_hip_index {
         size_t d_cap = 0;
         uint8_t* h_pin = nullptr;
         size_t h_cap = 0;
-        uint8_t* d_scratch = nullptr; // search_launch's scratch block, kept across calls
-        size_t scratch_cap = 0;
     };
     std::mutex call_mu;
     std::vector<HostCall*> call_free;
+    ScratchCache scratch;
 };
 
 static inline uint32_t elem_size(int dtype) { return dtype == GRANNE_HIP_F32 ? 4u : 1u; }
@@ -168,9 +183,9 @@ static void destroy_index(granne_hip_index* ix) {
         if (c->stream) (void)hipStreamDestroy(c->stream);
         if (c->d_buf) (void)hipFree(c->d_buf);
         if (c->h_pin) (void)hipHostFree(c->h_pin);
-        if (c->d_scratch) (void)hipFree(c->d_scratch);
         delete c;
     }
+    ix->scratch.free_all();
     delete ix;
 }
 
@@ -484,6 +499,7 @@ struct SearchTarget {
     uint32_t n_layers;
     uint32_t max_dev_width;
     uint64_t opt_visited_slots, opt_force_slow, opt_slow_slots, opt_slow_blocks, opt_overflow_slots;
+    ScratchCache* scratch; // search_launch's per-stream scratch blocks
 };
 
 static SearchTarget target_of(const granne_hip_index* ix) {
@@ -502,10 +518,32 @@ static SearchTarget target_of(const granne_hip_index* ix) {
     T.opt_slow_slots = ix->opt_slow_slots;
     T.opt_slow_blocks = ix->opt_slow_blocks;
     T.opt_overflow_slots = ix->opt_overflow_slots;
+    T.scratch = &const_cast<granne_hip_index*>(ix)->scratch;
     return T;
 }
 
-typedef void (*search_fn)(const SearchParams);
+typedef void (*search_fn)(const SlowParams);
+
+// experiment knobs, read once per process
+struct EnvKnobs {
+    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, v16 = 1, v16_lg = 0, tail_blocks = -1;
+    EnvKnobs() {
+        auto geti = [](const char* name, int dflt) {
+            const char* e = getenv(name);
+            return e ? atoi(e) : dflt;
+        };
+        visited_cap = geti("GRANNE_HIP_VISITED_CAP", 0);
+        front_eighths = geti("GRANNE_HIP_FRONT_EIGHTHS", 0);
+        maxc = geti("GRANNE_HIP_MAXC", 0);
+        lds_pad = geti("GRANNE_HIP_LDS_PAD", 0);
+        v16 = geti("GRANNE_HIP_V16", 1);       // 0: always the 32-bit visited table
+        v16_lg = geti("GRANNE_HIP_V16_LG", 0); // log2(buckets) of the 16-bit table
+    }
+};
+static const EnvKnobs& knobs() {
+    static const EnvKnobs k;
+    return k;
+}
 
 template <int DT, int DIM>
 static search_fn pick_s(uint32_t ef) {
@@ -530,12 +568,12 @@ static search_fn pick_kernel(int dtype, uint32_t ef) {
 constexpr uint32_t FAST_MAX_SEARCH = 1024;
 static uint32_t fast_list_slots(uint32_t ef) { return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : 17u; }
 template <int DT, int DIM>
-static search_fn pick_fast_s(uint32_t S, bool trail) {
+static search_fn pick_fast_s(uint32_t S, bool trail, bool v16) {
     if (trail) return fast_kernel<DT, DIM, 1, true>;
     switch (S) {
-    case 1: return fast_kernel<DT, DIM, 1>;
-    case 2: return fast_kernel<DT, DIM, 2>;
-    case 4: return fast_kernel<DT, DIM, 4>;
+    case 1: return v16 ? fast_kernel<DT, DIM, 1, false, true> : fast_kernel<DT, DIM, 1>;
+    case 2: return v16 ? fast_kernel<DT, DIM, 2, false, true> : fast_kernel<DT, DIM, 2>;
+    case 4: return v16 ? fast_kernel<DT, DIM, 4, false, true> : fast_kernel<DT, DIM, 4>;
     case 8: return fast_kernel<DT, DIM, 8>;
     default:
         if constexpr (DT == DT_F32 && DIM == 0) return fast_kernel<DT, DIM, 8>; // not reached: max_search <= 508 there
@@ -548,22 +586,51 @@ static bool fast_shape(const SearchTarget* ix) {
     return ix->dim >= 32; // 100 and 200 fully unrolled, any other dim with at least one 32-float chunk streamed
 }
 static bool fast_generic(const SearchTarget* ix) { return ix->dtype == GRANNE_HIP_F32 && ix->dim != 100 && ix->dim != 200; }
-static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail) {
-    if (ix->dtype == GRANNE_HIP_I8) return pick_fast_s<DT_I8, 0>(S, trail);
-    if (ix->dim == 100) return pick_fast_s<DT_F32, 100>(S, trail);
-    if (ix->dim == 200) return pick_fast_s<DT_F32, 200>(S, trail);
-    return pick_fast_s<DT_F32, 0>(S, trail);
+static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail, bool v16) {
+    if (ix->dtype == GRANNE_HIP_I8) return pick_fast_s<DT_I8, 0>(S, trail, v16);
+    if (ix->dim == 100) return pick_fast_s<DT_F32, 100>(S, trail, v16);
+    if (ix->dim == 200) return pick_fast_s<DT_F32, 200>(S, trail, v16);
+    return pick_fast_s<DT_F32, 0>(S, trail, v16);
 }
 
 struct LaunchPlan {
     uint32_t visited_slots, upper_slots, maxc, lrow_bytes, stage_bytes, adjspec_bytes, lds_bytes;
+    bool v16;
 };
 
 // LDS plan. The visited table dominates; the f32 stage gets what keeps four walkers per CU
 // (160 KiB / 4) when that leaves it at least 16 rows, else up to 32 rows within 64 KiB, else
 // whatever fits in the CU's 160 KiB. GRANNE_HIP_MAXC overrides the stage rows (experiments).
-static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, uint32_t fastS /* 0: general walker */) {
+static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, uint32_t fastS /* 0: general walker */,
+                              bool trail) {
     LaunchPlan P;
+    P.v16 = false;
+    // The register walkers with short lists keep the visited set in 16-bit two-choice buckets (VisitedSet16,
+    // wave_prims.h) whenever the ids fit its tags: nb buckets of 16 bytes hold up to 32767 * nb ids' worth of id space
+    // and ~5.8 * nb ids before the first one spills (two-choice, 8 entries per bucket). A walk visits ~40 x
+    // max_search nodes on 10M uniform points: nb = 8 * max_search rounded up to a power of two -- 512 buckets =
+    // 8 KB at max_search 50 (the 32-bit table: 16 KB), so twice the walkers fit a CU's LDS.
+    if (fastS >= 1 && fastS <= 4 && !trail && knobs().v16 && !ix->opt_visited_slots) {
+        const uint32_t lg_ids = v16_lg_for_ids(ix->n_elements);
+        uint32_t lg = V16_MIN_LG;
+        while ((1u << lg) < ef * 8u) ++lg;
+        // big launches keep more walkers resident with a smaller table and let the largest walks spill
+        const uint32_t lg_cap = nq >= 2048 ? 10u : 11u;
+        if (lg > lg_cap) lg = lg_cap;
+        if (knobs().v16_lg) lg = (uint32_t)knobs().v16_lg;
+        if (lg < lg_ids) lg = lg_ids;
+        if (lg <= 11) {
+            P.v16 = true;
+            P.visited_slots = lg;
+            P.upper_slots = lg_ids < lg ? lg_ids : lg; // upper layers: the smallest table whose tags hold the ids
+            P.maxc = 0;
+            P.lrow_bytes = 16;
+            P.stage_bytes = 0;
+            P.adjspec_bytes = 0;
+            P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, 4u << lg);
+            return P;
+        }
+    }
     // The front table must hold the walk's visited ids (~40 x max_search on 10M uniform points) below its 7/8
     // load limit: 4096 slots at max_search 50. (Tables of 3 * 2^k slots are accepted as an option; 3072 slots --
     // 12 KB, twelve walkers per CU instead of nine -- measured no faster: 0.5 % of the walks spill to the
@@ -579,7 +646,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         // whatever the front table's size, and a 32 KB front table beside the list's LDS mirror leaves room
         // for only three walkers per CU (768 of a batch of 1024 resident: the batch runs in two rounds)
         if (fastS >= 8) cap = 4096u;
-        if (const char* e = getenv("GRANNE_HIP_VISITED_CAP")) cap = next_pow2((uint32_t)atoi(e)); // experiments
+        if (knobs().visited_cap) cap = next_pow2((uint32_t)knobs().visited_cap); // experiments
         if (cap < 1024) cap = 1024;
         if (cap > 32768) cap = 32768;
         if (want > cap) want = cap;
@@ -608,10 +675,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         if (maxc < 16) maxc = rows_in(64u * 1024u) < 32u ? rows_in(64u * 1024u) : 32u;
         if (maxc < 16) maxc = rows_in(160u * 1024u) < 32u ? rows_in(160u * 1024u) : 32u;
         if (maxc > wmax) maxc = wmax;
-        if (const char* e = getenv("GRANNE_HIP_MAXC")) {
-            uint32_t v = (uint32_t)atoi(e);
-            if (v >= 1 && v <= 64) maxc = v;
-        }
+        if (knobs().maxc >= 1 && knobs().maxc <= 64) maxc = (uint32_t)knobs().maxc;
         if (maxc < 1) maxc = 1;
         P.maxc = maxc;
         P.stage_bytes = P.maxc * P.lrow_bytes;
@@ -624,13 +688,48 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
     return P;
 }
 
+// A search's scratch block (control words, overflow-region states, hand-over list, overflow tables, the exact
+// walker's containers) is kept per (index, stream) for the life of the index: launches on one stream run in
+// order, so they can share a block, and the kernels leave its control words and region states zeroed -- no
+// allocator call and no memset per search.
+constexpr uint32_t SCRATCH_MAX_REGIONS = 16384;                       // 256 CUs x 32 waves x 2
+constexpr size_t SCRATCH_STATE_OFF = CTL_WORDS * 4;                   // region states follow the control words
+constexpr size_t SCRATCH_FIXED = SCRATCH_STATE_OFF + (size_t)SCRATCH_MAX_REGIONS * 4; // zero between launches
+
+static int scratch_for(ScratchCache* cache, hipStream_t s, size_t total, uint8_t** out) {
+    // (the caller holds cache->mu for the whole enqueue)
+    ScratchCache::Block* b = nullptr;
+    for (auto& x : cache->blocks)
+        if (x.stream == s) b = &x;
+    if (!b) {
+        if (cache->blocks.size() >= 64) { // a caller that keeps inventing streams: start over
+            HIP_TRY(hipDeviceSynchronize());
+            cache->free_all();
+        }
+        cache->blocks.push_back({s, nullptr, 0});
+        b = &cache->blocks.back();
+    }
+    if (b->cap < total) {
+        if (b->p) {
+            HIP_TRY(hipStreamSynchronize(s)); // earlier launches on this stream still use the old block
+            (void)hipFree(b->p);
+            b->p = nullptr;
+            b->cap = 0;
+        }
+        size_t want = total + (total >> 2); // some headroom: batch sizes vary
+        HIP_TRY(hipMalloc((void**)&b->p, want));
+        b->cap = want;
+        HIP_TRY(hipMemsetAsync(b->p, 0, SCRATCH_FIXED, s));
+    }
+    *out = b->p;
+    return GRANNE_HIP_OK;
+}
+
 static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t q_stride, uint32_t nq, uint32_t ef,
                          uint32_t k, uint64_t* d_ids, float* d_dists, uint32_t* d_counts, uint64_t* d_stats,
                          uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */,
                          uint32_t* d_trail = nullptr /* [nq][8]: trail mode, no search outputs */,
                          uint32_t trail_layers = 0, hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr,
-                         uint32_t* h_status_async = nullptr /* pinned u32[4]: the launch's header words, stream-ordered, no sync */,
-                         uint8_t** scratch_cache = nullptr, size_t* scratch_cache_cap = nullptr /* a caller-kept scratch block */,
                          uint32_t* host_status = nullptr /* u32[2], host-mapped: hand-over count and exhaustion flag, plain stores */) {
     if (ef == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
     if (nq == 0) return GRANNE_HIP_OK;
@@ -648,7 +747,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     const uint32_t fastS = fast ? fast_list_slots(ef) : 0u;
     const uint32_t ef_walk = fast ? ef : (ef > 256 ? 256 : ef); // what the register/LDS walker is sized for
     const bool all_slow = ix->opt_force_slow || (!fast && ef > 256);
-    LaunchPlan plan = plan_launch(ix, ef_walk, nq, fastS);
+    LaunchPlan plan = plan_launch(ix, ef_walk, nq, fastS, d_trail != nullptr);
     if (plan.lds_bytes > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
 
     // visited-set overflow pool: one table per walker that can be resident at once (bounded by
@@ -664,44 +763,30 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
         if (per_cu < 1) per_cu = 1;
         ovf_regions = 256u * per_cu * 2u; // 2x the residency bound keeps the region probe short
         if (ovf_regions > nq) ovf_regions = nq;
+        if (ovf_regions > SCRATCH_MAX_REGIONS) ovf_regions = SCRATCH_MAX_REGIONS;
     }
 
-    // stream-ordered scratch: hand-over list, overflow pool, slow-path containers.
-    // header words: [0] hand-over count, [1] slow-path exhaustion flag, [2] walks that spilled
+    // scratch: [control words][region states] (zero between launches) [hand-over list][overflow tables][exact walker]
     const uint32_t slow_blocks = (uint32_t)ix->opt_slow_blocks;
+    const uint32_t n_tail = all_slow ? 0u : (slow_blocks < nq ? slow_blocks : nq);
     const uint32_t slots = (uint32_t)ix->opt_slow_slots;
     const size_t list_bytes = ((size_t)nq * 4 + 15) & ~(size_t)15;
-    const size_t state_bytes = ((size_t)ovf_regions * 4 + 15) & ~(size_t)15;
-    size_t off_state = 16;
-    size_t off_list = off_state + state_bytes;
+    size_t off_list = SCRATCH_FIXED;
     size_t off_ovf = off_list + list_bytes;
     size_t off_vis = off_ovf + (size_t)ovf_regions * ovf_slots * 4;
     size_t off_pq = off_vis + (size_t)slow_blocks * slots * 4;
     size_t off_res = off_pq + (size_t)slow_blocks * slots * 8;
     size_t total = off_res + (size_t)slow_blocks * ef * 8;
+    std::lock_guard<std::mutex> cache_lock(ix->scratch->mu);
     uint8_t* scratch = nullptr;
-    if (scratch_cache) { // the caller keeps one block across calls (host-pointer searches): no allocator traffic per call
-        if (*scratch_cache_cap < total) {
-            if (*scratch_cache) (void)hipFree(*scratch_cache);
-            *scratch_cache = nullptr;
-            *scratch_cache_cap = 0;
-            HIP_TRY(hipMalloc((void**)scratch_cache, total));
-            *scratch_cache_cap = total;
-        }
-        scratch = *scratch_cache;
-    } else {
-        HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
+    {
+        int r = scratch_for(ix->scratch, s, total, &scratch);
+        if (r) return r;
     }
-    struct ScratchRelease { // stream-ordered free on every exit path
-        void* ptr;
-        hipStream_t stream;
-        ~ScratchRelease() {
-            if (ptr) (void)hipFreeAsync(ptr, stream);
-        }
-    } scratch_release{scratch_cache ? nullptr : scratch, s};
-    HIP_TRY(hipMemsetAsync(scratch, 0, off_list, s)); // header + region states
+    uint32_t* ctl = (uint32_t*)scratch;
 
-    SearchParams p;
+    SlowParams sp;
+    SearchParams& p = sp.sp;
     p.elements = ix->d_elements;
     p.n_elements = ix->n_elements;
     p.dim = ix->dim;
@@ -723,61 +808,61 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     // instead of 7/8: every later lookup of a new id runs to an empty slot of the frozen table, 8 probes on average
     // at 7/8 load with the wave waiting for its slowest lane, 2.7 at 5/8 (C5-like int8 walk at max_search 200:
     // launch 2.70 -> 2.44 ms; f32 at 800: 7.75 -> 6.5 ms).
-    p.front_eighths = ((uint64_t)ef * 40u > (uint64_t)plan.visited_slots) ? 5u : 7u;
-    if (const char* e = getenv("GRANNE_HIP_FRONT_EIGHTHS")) { // experiments
-        const uint32_t v = (uint32_t)atoi(e);
-        if (v >= 1 && v <= 7) p.front_eighths = v;
-    }
+    p.front_eighths = (!plan.v16 && (uint64_t)ef * 40u > (uint64_t)plan.visited_slots) ? 5u : 7u;
+    if (knobs().front_eighths >= 1 && knobs().front_eighths <= 7) p.front_eighths = (uint32_t)knobs().front_eighths;
     p.maxc = plan.maxc;
     p.lrow_bytes = plan.lrow_bytes;
     p.stage_bytes = plan.stage_bytes;
     p.adjspec_bytes = plan.adjspec_bytes;
-    p.slow_count = (uint32_t*)scratch;
+    p.slow_count = ctl + CTL_SLOW_COUNT;
     p.slow_list = (uint32_t*)(scratch + off_list);
-    p.force_slow = all_slow ? 1 : 0;
+    p.force_slow = 0;
     p.spec = 1;
     p.ovf.tables = (uint32_t*)(scratch + off_ovf);
-    p.ovf.state = (uint32_t*)(scratch + off_state);
+    p.ovf.state = (uint32_t*)(scratch + SCRATCH_STATE_OFF);
     p.ovf.slots = ovf_slots;
     p.ovf.regions = ovf_regions;
-    p.ovf.spilled = d_status ? d_status + 2 : ((uint32_t*)scratch) + 2;
+    p.ovf.spilled = d_status ? d_status + 2 : ctl + CTL_SPILLED;
     p.trail_out = d_trail;
     p.trail_layers = trail_layers;
-
-    search_fn fn = fast ? pick_fast_kernel(ix, fastS, d_trail != nullptr)
-                        : (d_trail ? pick_trail_kernel(ix->dtype) : pick_kernel(ix->dtype, ef_walk));
-    if (const char* e = getenv("GRANNE_HIP_LDS_PAD")) plan.lds_bytes += (uint32_t)atoi(e); // occupancy experiments
-    if (plan.lds_bytes > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
-    if (plan.lds_bytes > 32u * 1024u)
-        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes));
-    if (ev_before) HIP_TRY(hipEventRecord(ev_before, s));
-    hipLaunchKernelGGL(fn, dim3(nq), dim3(64), plan.lds_bytes, s, p);
-    HIP_TRY(hipGetLastError());
-    if (ev_after) HIP_TRY(hipEventRecord(ev_after, s));
-
-    SlowParams sp;
-    sp.sp = p;
+    sp.ctl = ctl;
     sp.vis = (uint32_t*)(scratch + off_vis);
     sp.pq = (uint64_t*)(scratch + off_pq);
     sp.res = (uint64_t*)(scratch + off_res);
     sp.slots = slots;
-    sp.status = ((uint32_t*)scratch) + 1;
+    sp.all = all_slow ? 1u : 0u;
     sp.status2 = d_status;
     sp.host_status = host_status;
-    uint32_t slow_lds = lds_query_bytes(ix->row_bytes) + 64 * 8;
-    if (ix->dtype == GRANNE_HIP_F32)
-        hipLaunchKernelGGL(slow_kernel<DT_F32>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
-    else
-        hipLaunchKernelGGL(slow_kernel<DT_I8>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
-    HIP_TRY(hipGetLastError());
 
-    if (h_status_async) HIP_TRY(hipMemcpyAsync(h_status_async, scratch, 16, hipMemcpyDeviceToHost, s));
+    const uint32_t slow_lds = lds_query_bytes(ix->row_bytes) + 64 * 8;
+    if (all_slow) { // every query on the exact walker: its kernel alone
+        if (ev_before) HIP_TRY(hipEventRecord(ev_before, s));
+        if (ix->dtype == GRANNE_HIP_F32)
+            hipLaunchKernelGGL(slow_kernel<DT_F32>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
+        else
+            hipLaunchKernelGGL(slow_kernel<DT_I8>, dim3(slow_blocks), dim3(64), slow_lds, s, sp);
+        HIP_TRY(hipGetLastError());
+        if (ev_after) HIP_TRY(hipEventRecord(ev_after, s));
+    } else {
+        search_fn fn = fast ? pick_fast_kernel(ix, fastS, d_trail != nullptr, plan.v16)
+                            : (d_trail ? pick_trail_kernel(ix->dtype) : pick_kernel(ix->dtype, ef_walk));
+        uint32_t lds = plan.lds_bytes > slow_lds ? plan.lds_bytes : slow_lds; // the tail blocks stage a query too
+        lds += (uint32_t)knobs().lds_pad; // occupancy experiments
+        if (lds > 160u * 1024u) return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the LDS stage");
+        if (lds > 32u * 1024u)
+            HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (ev_before) HIP_TRY(hipEventRecord(ev_before, s));
+        hipLaunchKernelGGL(fn, dim3(nq + n_tail), dim3(64), lds, s, sp);
+        HIP_TRY(hipGetLastError());
+        if (ev_after) HIP_TRY(hipEventRecord(ev_after, s));
+    }
+
     if (h_slow_count) {
-        uint32_t hs[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(hs, scratch, 16, hipMemcpyDeviceToHost, s));
+        uint32_t hs[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(hs, ctl + CTL_LAST_SLOW, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         h_slow_count[0] = hs[0]; // queries served by the global-memory walker
-        h_slow_count[1] = hs[1];
+        h_slow_count[1] = hs[1]; // its containers ran out
     }
     return GRANNE_HIP_OK;
 }
@@ -909,8 +994,7 @@ extern "C" int granne_hip_search_batch(const granne_hip_index* cix, const void* 
         hst[0] = hst[1] = hst[2] = hst[3] = 0;
         int r = search_launch(&T, dp, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
                               (uint64_t*)(dp + o_ids), (float*)(dp + o_d), (uint32_t*)(dp + o_c), (uint64_t*)(dp + o_s),
-                              nullptr, s, nullptr, nullptr, 0, nullptr, nullptr, nullptr, &c->d_scratch, &c->scratch_cap,
-                              (uint32_t*)(dp + total));
+                              nullptr, s, nullptr, nullptr, 0, nullptr, nullptr, (uint32_t*)(dp + total));
         hipError_t e = hipStreamSynchronize(s);
         if (r) return r;
         if (e != hipSuccess) return fail(GRANNE_HIP_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));

@@ -84,6 +84,17 @@ constexpr uint32_t LDS_ADJSPEC_BYTES = 4096 + 16;        // 32x32 u32 + a 16-byt
 constexpr uint32_t COLSTAGE_ROW_BYTES = 144;             // column-streamed stage: 32 floats + pad = 9 x 16 B (odd)
 constexpr uint32_t COLSTAGE_BYTES = 32 * COLSTAGE_ROW_BYTES;
 
+// Hand query qi, untouched, to the exact global-memory walker. The list is read by other CUs (possibly of
+// another XCD) inside the same launch: the entry is written with a device-scope atomic and fenced before the
+// block reports itself done (slow_kernel.h).
+__device__ __forceinline__ void hand_over(const SearchParams& p, uint32_t qi) {
+    if (threadIdx.x == 0) {
+        const uint32_t at = atomicAdd(p.slow_count, 1u);
+        atomicExch(p.slow_list + at, qi);
+        __threadfence();
+    }
+}
+
 template <int DT, int DIM, int S>
 struct Walker {
     // ---- immutable per-launch state
@@ -448,7 +459,7 @@ template <int DT, int DIM, int S, bool TRAIL>
 __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t qi, uint8_t* smem) {
     const uint32_t lane = threadIdx.x;
     if (p.force_slow) {
-        if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+        hand_over(p, qi);
         return;
     }
 
@@ -466,7 +477,7 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
         }
         w.vis.release(p.ovf, lane);
         if (w.bail) {
-            if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+            hand_over(p, qi);
         } else if (lane < TRAIL_WIDTH) {
             p.trail_out[(size_t)qi * TRAIL_WIDTH + lane] = mine;
         }
@@ -484,7 +495,7 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
 
     w.vis.release(p.ovf, lane);
     if (w.bail) { // hand the untouched query to the exact global-memory walker
-        if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+        hand_over(p, qi);
         return;
     }
 
@@ -520,15 +531,7 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
 }
 
 
-// Block b walks query b. A walk whose LDS visited table fills continues with an overflow table
-// borrowed from p.ovf; only a walk that cannot continue exactly (unsafe queue drop, no overflow
-// region left) is handed, untouched, to the global-memory walker of slow_kernel.h.
-// TRAIL = true is the variant Granne::reorder launches (SearchParams::trail_out): a kernel of its own,
-// so that the search kernel carries one copy of the walker and nothing else.
-template <int DT, int DIM, int S, bool TRAIL = false>
-__global__ __launch_bounds__(64) void search_kernel(const SearchParams p) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    if (blockIdx.x < p.nq) walk_one<DT, DIM, S, TRAIL>(p, blockIdx.x, smem);
-}
+// The __global__ entry point (search_kernel) lives in slow_kernel.h, beside the tail blocks that serve the
+// hand-over list inside the same launch.
 
 } // namespace granne_hip

@@ -2,26 +2,46 @@
 // (/root/reference/src/index/mod.rs:963-1037), but `res`, `pq` and `visited` are the reference's
 // literal containers (binary heaps and an open-addressing set) in GLOBAL memory, sized by the
 // host, so no walk can outgrow them short of GRANNE_HIP_ERR_OVERFLOW. It serves
-//   - queries the register/LDS walker hands over (a queue drop that ties with the max_search-th
+//   - queries the register/LDS walkers hand over (a queue drop that ties with the max_search-th
 //     distance -- search_kernel.h explains why only those are unsafe -- or no visited-set
 //     overflow table left),
-//   - max_search > 256, and GRANNE_HIP_OPT_FORCE_SLOW (tests).
+//   - max_search beyond the register walkers' lists, and GRANNE_HIP_OPT_FORCE_SLOW (tests).
 // It is slow on purpose of simplicity: lane 0 runs the heaps; the 64 lanes split the neighbor
 // row (visited insert + one exact distance each, rows read straight from HBM).
+//
+// One launch per search. The hand-over list is served INSIDE the walker's launch: the grid is nq walker
+// blocks plus a few tail blocks; a tail block sleeps until the launch's `done` counter says every walker
+// block has finished, reads the list (device-scope atomics on both sides: the list crosses XCDs) and walks
+// its share; the last tail block out re-arms the control words, so the scratch block needs no memset
+// between launches and a search is ONE kernel on the stream (round 2: memset + walker + slow_kernel +
+// stream-ordered malloc/free per call, 20-37 us per step). Tail blocks never hold a walker up: walkers do
+// not wait for anything, so the order in which the dispatcher places blocks does not matter. Searches that
+// are known to go to the exact walker wholesale launch `slow_kernel` alone.
 #pragma once
 
 #include "search_kernel.h"
 
 namespace granne_hip {
 
+// control words at the start of a search's scratch block (all zero between launches)
+constexpr uint32_t CTL_SLOW_COUNT = 0; // hand-over list length (SearchParams::slow_count)
+constexpr uint32_t CTL_DONE = 1;       // walker blocks finished
+constexpr uint32_t CTL_TAIL_DONE = 2;  // tail blocks finished
+constexpr uint32_t CTL_EXHAUSTED = 3;  // a walk outgrew the exact walker's containers in THIS launch
+constexpr uint32_t CTL_LAST_SLOW = 4;  // previous launch: queries the exact walker served
+constexpr uint32_t CTL_LAST_EXHAUSTED = 5; // previous launch: CTL_EXHAUSTED
+constexpr uint32_t CTL_SPILLED = 6;    // walks that borrowed an overflow table (statistics, monotonic)
+constexpr uint32_t CTL_WORDS = 16;
+
 struct SlowParams {
     SearchParams sp;
+    uint32_t* ctl;   // the control words above
     uint32_t* vis;   // [blocks][slots]
     uint64_t* pq;    // [blocks][slots]   min-heap of keys
     uint64_t* res;   // [blocks][ef]      max-heap of keys
     uint32_t slots;  // power of two
-    uint32_t* status;// set to 1 when a walk exhausts `slots`
-    uint32_t* status2; // caller's u32[2] (optional): [0] same flag, [1] += queries that took this path
+    uint32_t all;    // 1: no list, every query of the launch is walked here (slow_kernel launched alone)
+    uint32_t* status2; // caller's u32[2] (optional): [0] = 1 when a walk exhausts `slots`, [1] += queries that took this path
     uint32_t* host_status; // optional u32[2] in host-mapped memory, written with PLAIN stores (no PCIe atomics):
                            // [0] = 1 when a walk exhausts `slots`, [1] = queries that took this path
 };
@@ -94,23 +114,23 @@ __device__ inline float slow_dist(const SearchParams& p, const uint8_t* lds_q, u
     }
 }
 
+// Block `me` of `n_blocks` walks entries me, me + n_blocks, ... of the hand-over list (or of 0..nq-1 when P.all).
 template <int DT>
-__global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
-    extern __shared__ __align__(16) uint8_t smem[];
+__device__ inline void slow_walk_list(const SlowParams& P, const uint32_t me, const uint32_t n_blocks,
+                                      const uint32_t n_slow, uint8_t* smem) {
     const SearchParams& p = P.sp;
     const uint32_t lane = threadIdx.x;
     uint8_t* lds_q = smem;
     uint64_t* ckey = reinterpret_cast<uint64_t*>(smem + lds_query_bytes(p.row_bytes)); // [64]
 
-    uint32_t* vis = P.vis + (size_t)blockIdx.x * P.slots;
-    uint64_t* pq = P.pq + (size_t)blockIdx.x * P.slots;
-    uint64_t* res = P.res + (size_t)blockIdx.x * p.ef;
-    const uint32_t n_slow = *p.slow_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && P.status2 && n_slow) atomicAdd(P.status2 + 1, n_slow);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && P.host_status) P.host_status[1] = n_slow;
+    uint32_t* vis = P.vis + (size_t)me * P.slots;
+    uint64_t* pq = P.pq + (size_t)me * P.slots;
+    uint64_t* res = P.res + (size_t)me * p.ef;
+    if (me == 0 && threadIdx.x == 0 && P.status2 && n_slow) atomicAdd(P.status2 + 1, n_slow);
+    if (me == 0 && threadIdx.x == 0 && P.host_status) P.host_status[1] = n_slow;
 
-    for (uint32_t si = blockIdx.x; si < n_slow; si += gridDim.x) {
-        const uint32_t qi = p.slow_list[si];
+    for (uint32_t si = me; si < n_slow; si += n_blocks) {
+        const uint32_t qi = P.all ? si : __hip_atomic_load(p.slow_list + si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         // query to LDS
         int dy = 0;
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
         if (trail) {
             if (overflow) {
                 if (lane == 0) {
-                    atomicExch(P.status, 1u);
+                    atomicExch(P.ctl + CTL_EXHAUSTED, 1u);
                     if (P.status2) atomicExch(P.status2, 1u);
                     if (P.host_status) P.host_status[0] = 1u;
                 }
@@ -256,7 +276,7 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
         uint32_t count = 0;
         if (overflow) {
             if (lane == 0) {
-                atomicExch(P.status, 1u);
+                atomicExch(P.ctl + CTL_EXHAUSTED, 1u);
                 if (P.status2) atomicExch(P.status2, 1u);
                 if (P.host_status) P.host_status[0] = 1u;
             }
@@ -301,6 +321,65 @@ __global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
             }
         }
         __syncthreads();
+    }
+}
+
+// The last block out publishes the launch's status words and re-arms the control words.
+__device__ inline void slow_epilogue(const SlowParams& P, const uint32_t n_blocks, const uint32_t n_slow) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(P.ctl + CTL_TAIL_DONE, 1u) == n_blocks - 1u) {
+            const uint32_t ex = atomicExch(P.ctl + CTL_EXHAUSTED, 0u);
+            atomicExch(P.ctl + CTL_LAST_SLOW, n_slow);
+            atomicExch(P.ctl + CTL_LAST_EXHAUSTED, ex);
+            atomicExch(P.ctl + CTL_SLOW_COUNT, 0u);
+            atomicExch(P.ctl + CTL_DONE, 0u);
+            atomicExch(P.ctl + CTL_TAIL_DONE, 0u);
+        }
+    }
+}
+
+// a walker block has finished (its hand-over, if any, is already on the list: hand_over() fences)
+__device__ __forceinline__ void walker_done(const SlowParams& P) {
+    if (threadIdx.x == 0) atomicAdd(P.ctl + CTL_DONE, 1u);
+}
+
+// blocks nq.. of a walker launch
+template <int DT>
+__device__ inline void tail_block(const SlowParams& P, uint8_t* smem) {
+    const uint32_t nq = P.sp.nq;
+    const uint32_t me = blockIdx.x - nq, n_blocks = gridDim.x - nq;
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(P.ctl + CTL_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nq)
+            __builtin_amdgcn_s_sleep(24);
+    }
+    __syncthreads();
+    const uint32_t n_slow = __hip_atomic_load(P.ctl + CTL_SLOW_COUNT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_slow) slow_walk_list<DT>(P, me, n_blocks, n_slow, smem);
+    else if (me == 0 && threadIdx.x == 0 && P.host_status) P.host_status[1] = 0u;
+    slow_epilogue(P, n_blocks, n_slow);
+}
+
+// every query of the launch on the exact walker (max_search beyond the register walkers, GRANNE_HIP_OPT_FORCE_SLOW)
+template <int DT>
+__global__ __launch_bounds__(64) void slow_kernel(const SlowParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    slow_walk_list<DT>(P, blockIdx.x, gridDim.x, P.sp.nq, smem);
+    slow_epilogue(P, gridDim.x, P.sp.nq);
+}
+
+// The general walker's launch (search_kernel.h): block b < nq walks query b; the blocks after them are the tail.
+// TRAIL = true is the variant Granne::reorder launches (SearchParams::trail_out): a kernel of its own,
+// so that the search kernel carries one copy of the walker and nothing else.
+template <int DT, int DIM, int S, bool TRAIL = false>
+__global__ __launch_bounds__(64) void search_kernel(const SlowParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    if (blockIdx.x < P.sp.nq) {
+        walk_one<DT, DIM, S, TRAIL>(P.sp, blockIdx.x, smem);
+        walker_done(P);
+    } else {
+        tail_block<DT>(P, smem);
     }
 }
 

@@ -34,7 +34,9 @@
 // tools/model_unified.py replays this list against the two heaps on tie-heavy random graphs.
 #pragma once
 
-#include "search_kernel.h"
+#include <type_traits>
+
+#include "slow_kernel.h"
 
 namespace granne_hip {
 
@@ -256,7 +258,9 @@ __host__ __device__ inline uint32_t fast_query_bytes(bool i8, bool gen, uint32_t
     return ngroups * GEN_GROUP * 128u + 128u;
 }
 
-template <int DT, int DIM, int S>
+// V16: the visited set's front table holds 16-bit entries in two-choice buckets (VisitedSet16, wave_prims.h) --
+// half the LDS of the 32-bit table for id spaces of up to 32767 ids per bucket; the host picks it when the ids fit.
+template <int DT, int DIM, int S, bool V16 = false>
 struct FastWalker {
     static constexpr bool F32 = (DT == DT_F32);
     // DIM == 0: any f32 dim >= 32, known at run time. The chunks stream through the registers in groups of
@@ -279,7 +283,7 @@ struct FastWalker {
     uint4 qi8[F32 ? 1 : 4]; // i8: bytes 64h..64h+63 of the query
     float sy;               // i8: sqrt(sum of squares of the query) as f32
     uint32_t g_nbk, g_ngroups, g_tu; // GEN: full chunks, groups of them, 16-byte units of the (zero padded) tail
-    VisitedSet vis;
+    typename std::conditional<V16, VisitedSet16, VisitedSet>::type vis;
     WalkList<S> L;
     WalkStats st;
     bool bail;
@@ -602,7 +606,11 @@ struct FastWalker {
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
                                                  bool d0_known = false, float d0_value = 0.0f) {
         PT_RESET();
-        vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
+        if constexpr (V16) { // `slots` is log2(buckets) here (the host sizes it for the ids' tags: SearchParams)
+            vis.reset(vis_tab, slots, lane);
+        } else {
+            vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
+        }
         L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;
@@ -613,7 +621,8 @@ struct FastWalker {
         // to the same query was evaluated there: the same operations on the same inputs give the same bits, so
         // the value is reused (the evaluation still counts) and the layer starts one memory round trip earlier.
         pre_nb = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
-        vis.insert(entrypoint, lane == 0, p.ovf);
+        if constexpr (V16) vis.insert(entrypoint, R == 0u, h, p.ovf, lane, bail);
+        else vis.insert(entrypoint, lane == 0, p.ovf);
         vis.count = 1;
         st.n_dist += 1;
         if (d0_known) {
@@ -664,7 +673,9 @@ struct FastWalker {
             PT_MARK(1); // row loads and the fetch-ahead issued
 
             // visited set under the loads, then the distances (mod.rs:1026-1027)
-            const bool fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
+            bool fresh;
+            if constexpr (V16) fresh = vis.insert(nb, R < nvalid, h, p.ovf, lane, bail) && h == 0u;
+            else fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
             PT_MARK(2); // visited set (under the loads)
             PT_WAIT_VM();
             PT_MARK(3); // what is left of the wait for the rows
@@ -712,14 +723,14 @@ struct FastWalker {
     }
 };
 
-template <int DT, int DIM, int S, bool TRAIL>
+template <int DT, int DIM, int S, bool TRAIL, bool V16>
 __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint32_t qi, uint8_t* smem) {
     const uint32_t lane = threadIdx.x;
     if (p.force_slow) {
-        if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+        hand_over(p, qi);
         return;
     }
-    FastWalker<DT, DIM, S> w(p, smem);
+    FastWalker<DT, DIM, S, V16> w(p, smem);
     w.load_query(qi);
 
     if constexpr (TRAIL) { // find_entrypoint_trail (reorder.rs:180-208): every walk starts at node 0
@@ -733,7 +744,7 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
         }
         w.vis.release(p.ovf, lane);
         if (w.bail) {
-            if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+            hand_over(p, qi);
         } else if (lane < TRAIL_WIDTH) {
             p.trail_out[(size_t)qi * TRAIL_WIDTH + lane] = mine;
         }
@@ -758,7 +769,7 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
         }
         w.vis.release(p.ovf, lane);
         if (w.bail) { // hand the untouched query to the exact global-memory walker
-            if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = qi;
+            hand_over(p, qi);
             return;
         }
         // res = the first max_search expanded entries; .take(num_neighbors), mod.rs:974-977
@@ -824,10 +835,16 @@ constexpr int fast_waves_per_simd(int DT, int DIM, int S) {
     return S == 1 ? (GRANNE_HIP_QUERY_IN_LDS ? 4 : 3) : S == 2 ? 4 : S <= 8 ? 3 : 2;
 }
 
-template <int DT, int DIM, int S, bool TRAIL = false>
-__global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S)) void fast_kernel(const SearchParams p) {
+// Blocks nq.. are the tail (slow_kernel.h): they serve the hand-over list inside the same launch.
+template <int DT, int DIM, int S, bool TRAIL = false, bool V16 = false>
+__global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S)) void fast_kernel(const SlowParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
-    if (blockIdx.x < p.nq) fast_walk_one<DT, DIM, S, TRAIL>(p, blockIdx.x, smem);
+    if (blockIdx.x < P.sp.nq) {
+        fast_walk_one<DT, DIM, S, TRAIL, V16>(P.sp, blockIdx.x, smem);
+        walker_done(P);
+    } else {
+        tail_block<DT>(P, smem);
+    }
 }
 
 __host__ __device__ inline uint32_t fast_lds_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {

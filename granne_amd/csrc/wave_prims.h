@@ -292,4 +292,186 @@ struct VisitedSet {
     }
 };
 
+// ---- the same exact set in HALF the LDS: 16-bit entries, two-choice buckets ----------------------------------
+// For id spaces of at most 32767 * nb ids (nb = number of buckets, a power of two): 10M ids fit nb = 512, i.e. an
+// 8 KB table instead of 16 KB -- LDS is what bounds the walkers per CU.
+//   id = q * nb + r.   tag = q + 1 (1..32767, so 0 can mean "empty").   Home bucket b1 = r ^ scramble(q), second
+//   bucket b2 = b1 ^ g(q) with g odd (never b1).   (bucket, choice bit, tag) names the id exactly: q from the tag, r
+//   from the bucket and q -- nothing is hashed away, the set is exact.
+//   A bucket is 8 entries = 16 bytes = one ds_read_b128; entry = choice << 15 | tag; buckets fill front to back.
+// The two lanes of a pair (walk_fast.h: both hold the same neighbor id) take one bucket each: one read, a packed
+// 16-bit compare of the eight entries, the fill count; one DPP exchange decides present / which bucket is emptier
+// (ties: b1); the lane that owns the chosen bucket claims the first free entry with ONE ds_cmpst on its 32-bit word.
+// A claim fails only when another lane of the same expansion took that word in the same round (two ids sharing a
+// bucket: ~0.4 pairs per expansion); those pairs go round again. Two-choice placement keeps every bucket below 8
+// entries up to ~0.72 load (2,930 ids in 512 buckets, simulated: tools/model_visited16.py); an id that finds both
+// of its buckets full goes to the walk's overflow table in global memory, exactly as with the 32-bit table, and is
+// looked up there by every later pair that finds both of its buckets full. Buckets never lose entries, so an id is
+// in the set iff it is in b1, in b2, or (both full) in the overflow table.
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_min1_u16(uint32_t a) { // min(each half, 1): 1 where the half is non-zero
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t dpp_pair_swap(uint32_t v) { // the other lane of the pair (lane ^ 1)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
+}
+
+constexpr uint32_t V16_TAG_MAX = 32767u;   // tags 1..32767
+constexpr uint32_t V16_MIN_LG = 6;         // smallest table: 64 buckets = 1 KB (upper layers)
+__host__ __device__ inline uint32_t v16_lg_for_ids(uint64_t n_ids) { // smallest log2(nb) whose tags hold n_ids ids
+    uint32_t lg = V16_MIN_LG;
+    while (((uint64_t)V16_TAG_MAX << lg) < n_ids && lg < 31) ++lg;
+    return lg;
+}
+
+struct VisitedSet16 {
+    uint32_t* tab;     // LDS: nb buckets of 4 words
+    uint32_t lg;       // log2(nb)
+    static constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t region;   // overflow region borrowed from the pool, or NONE
+    uint32_t ocount;   // ids in the overflow table
+    uint32_t count;    // statistics only
+#if GRANNE_HIP_PHASE_TIMERS
+    uint32_t pt_rounds = 0;
+#endif
+
+    __device__ __forceinline__ void init_walker() {
+        region = NONE;
+        ocount = 0;
+    }
+    __device__ __forceinline__ void reset(uint32_t* lds, uint32_t lg_, uint32_t lane) {
+        tab = lds;
+        lg = lg_;
+        count = 0;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        uint4* t4 = reinterpret_cast<uint4*>(lds);
+        for (uint32_t i = lane; i < (1u << lg_); i += 64) t4[i] = z;
+        if (region != NONE && ocount != 0) ocount = NONE; // a borrowed region is wiped before it is used again
+    }
+    __device__ __forceinline__ void added(uint32_t) {}
+
+    // HashSet::insert for the id both lanes of a pair hold (h = lane & 1). `active` is the same in both lanes.
+    // Returns true in BOTH lanes iff the id was not present.
+    __device__ __forceinline__ bool insert(uint32_t id, bool active, uint32_t h, const OverflowPool& pool, uint32_t lane,
+                                           bool& bail) {
+        const uint32_t mask = (1u << lg) - 1u;
+        const uint32_t q = id >> lg;
+        const uint32_t sh = 32u - lg;
+        const uint32_t b1 = (id ^ ((q * 0x9E3779B1u) >> sh)) & mask;
+        const uint32_t g = ((q * 0x85EBCA6Bu) >> sh) | 1u;
+        const uint32_t mine = h ? (b1 ^ g) : b1;
+        const uint32_t entry = (q + 1u) | (h << 15);
+        const uint32_t pat = entry | (entry << 16);
+        uint4* slot4 = reinterpret_cast<uint4*>(tab) + mine;
+        bool pending = active, fresh = false, both_full = false;
+#if GRANNE_HIP_PHASE_TIMERS
+        uint32_t r_ = 0;
+#endif
+        while (wave_ballot(pending)) {
+#if GRANNE_HIP_PHASE_TIMERS
+            r_ += 1;
+#endif
+            if (pending) {
+                const uint4 w = *slot4;
+                const uint32_t m = pk_min_u16(pk_min_u16(w.x ^ pat, w.y ^ pat), pk_min_u16(w.z ^ pat, w.w ^ pat));
+                const uint32_t found_mine = (((m & 0xFFFFu) == 0u) || (m < 0x10000u)) ? 1u : 0u;
+                const uint32_t c2 = pk_add_u16(pk_add_u16(pk_min1_u16(w.x), pk_min1_u16(w.y)),
+                                               pk_add_u16(pk_min1_u16(w.z), pk_min1_u16(w.w)));
+                const uint32_t cnt = (c2 & 0xFFFFu) + (c2 >> 16);
+                // one exchange: fill count in the low bits, "present here" above them
+                const uint32_t other = dpp_pair_swap(cnt | (found_mine << 8));
+                const uint32_t cnt_o = other & 0xFFu;
+                if (found_mine | (other >> 8)) {
+                    pending = false; // already in the set
+                } else if (cnt >= 8u && cnt_o >= 8u) {
+                    pending = false; // both buckets full: the overflow table decides
+                    both_full = true;
+                } else {
+                    const bool claim = h ? (cnt < cnt_o) : (cnt <= cnt_o); // the emptier bucket, ties to b1
+                    uint32_t ok = 0u;
+                    if (claim) {
+                        const uint32_t wi = cnt >> 1;
+                        const uint32_t old = wi == 0u ? w.x : wi == 1u ? w.y : wi == 2u ? w.z : w.w;
+                        const uint32_t neww = old | (entry << ((cnt & 1u) * 16u));
+                        const uint32_t got = atomicCAS(reinterpret_cast<uint32_t*>(slot4) + wi, old, neww);
+                        ok = got == old ? 1u : 0u;
+                    }
+                    if (ok | dpp_pair_swap(ok)) {
+                        pending = false;
+                        fresh = true;
+                    }
+                }
+            }
+        }
+#if GRANNE_HIP_PHASE_TIMERS
+        pt_rounds += r_;
+#endif
+        if (wave_ballot(both_full)) { // rare: the walk outgrew its table's two-choice capacity
+            if (region == NONE) {
+                uint32_t got = NONE;
+                if (pool.slots != 0 && lane == 0) {
+                    uint32_t r = (blockIdx.x * 0x9E3779B1u) % pool.regions;
+                    for (uint32_t tries = 0; tries < pool.regions; ++tries) {
+                        if (atomicCAS(&pool.state[r], 0u, 1u) == 0u) { got = r; break; }
+                        r = (r + 1 == pool.regions) ? 0u : r + 1;
+                    }
+                    if (got != NONE && pool.spilled) atomicAdd(pool.spilled, 1u);
+                }
+                region = (uint32_t)__shfl((int)got, 0, 64);
+                ocount = NONE;
+            }
+            if (region == NONE) {
+                bail = true; // no overflow configured or none left: the exact global-memory walker takes the query
+                return false;
+            }
+            uint32_t* otab = pool.tables + (size_t)region * pool.slots;
+            if (ocount == NONE) { // first use (in this layer): wipe
+                const uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
+                uint4* t4 = reinterpret_cast<uint4*>(otab);
+                for (uint32_t i = lane; i < (pool.slots >> 2); i += 64) t4[i] = e;
+                __threadfence();
+                ocount = 0;
+            }
+            bool ofresh = false;
+            if (both_full && h == 0u) {
+                const uint32_t omask = pool.slots - 1;
+                const uint32_t ost = VisitedSet::step(id);
+                uint32_t slot = (VisitedSet::hash(id) >> 3) & omask;
+                for (;;) {
+                    const uint32_t old = atomicCAS(&otab[slot], ID_EMPTY, id);
+                    if (old == ID_EMPTY) { ofresh = true; break; }
+                    if (old == id) break;
+                    slot = (slot + ost) & omask;
+                }
+            }
+            const uint64_t om = wave_ballot(ofresh);
+            ocount += (uint32_t)__popcll(om);
+            if (((om | (om << 1)) >> lane) & 1ull) fresh = true; // both lanes of the pair
+        }
+        return fresh;
+    }
+    // after an expansion: false when the overflow table itself is full (75 % load)
+    __device__ __forceinline__ bool make_room(const OverflowPool& pool, uint32_t) {
+        return region == NONE || ocount == NONE || ocount <= pool.slots - (pool.slots >> 2) - 72u;
+    }
+    __device__ __forceinline__ void release(const OverflowPool& pool, uint32_t lane) {
+        if (region != NONE) {
+            __threadfence();
+            if (lane == 0) atomicExch(&pool.state[region], 0u);
+            region = NONE;
+        }
+    }
+};
+
 } // namespace granne_hip
