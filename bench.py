@@ -28,15 +28,30 @@ Rank 0 prints ONE JSON line. Besides the contract fields it carries
   int8          the same workload on angular_int (BASELINE.json configs[2]) as a sub-record
   secondary     a second synthetic workload on which recall@10 >= 0.95 is reachable (the headline
                 data is i.i.d. uniform in 100-d, where it is not): QPS at the smallest such ef
+  c4_shard      one shard of BASELINE.json configs[3] (12.5M x 200-d f32, batch 4096, ef 50) and
+  c5_shard      one shard of configs[4] (125M x 100-d int8, batch 4096, ef 200), measured the same way
+  partitioned   (WORLD_SIZE > 1 only) C2's 10M points split into WORLD_SIZE id ranges, one per rank: every rank
+                searches the SAME batches, ONE all_gather_into_tensor of the packed per-shard top-k (RCCL) per
+                batch, merge kernel; pipelined two batches deep
   latency_nq1   one query per call through the host-pointer API (the reference's own call shape)
+  steady        the same K steps repeated back to back for >= 0.5 s (the contract's K-step window is a few ms)
 """
 import argparse
 import ctypes as C
 import hashlib
 import json
+import math
 import os
 import sys
 import time
+
+# Batches in flight run on HIP streams of their own; HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware
+# queues (default 4, one of them the null stream's), and two streams that share a queue run one after the other
+# (tools/inflight_probe.py: four streams on the default setting run like two). Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the CPU baseline's OpenMP team: one thread per core, spread over both sockets (read when libgomp loads)
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np
 
@@ -72,9 +87,15 @@ def parse():
     ap.add_argument("--build-reinsert", type=int, default=1)
     ap.add_argument("--num-neighbors", type=int, default=30)
     ap.add_argument("--batch-max", type=int, default=65536)
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="batches in flight: step i is enqueued on HIP stream i %% inflight (1 = strictly sequential)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="batches in flight: step i is enqueued on HIP stream i %% inflight (1 = strictly sequential; "
+                         "0 = per element type: f32 4, int8 6 -- int8 walks move a quarter of the bytes)")
     ap.add_argument("--cpu-batches", type=int, default=16, help="batches of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=2.0, help="wall seconds the CPU baseline is timed over (repeats its sample)")
+    ap.add_argument("--c5-elements", type=int, default=125_000_000, help="elements of the c5_shard sub-record (0 = skip)")
+    ap.add_argument("--c4-elements", type=int, default=12_500_000, help="elements of the c4_shard sub-record (0 = skip)")
+    ap.add_argument("--no-partitioned", action="store_true", help="WORLD_SIZE > 1: skip the partitioned sub-record")
+    ap.add_argument("--force-partitioned", action="store_true", help="take the partitioned sub-record with one rank too (tests)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--sweep-ef", default="50,100,200,400,800", help="ef values of ef_sweep ('' = skip)")
     ap.add_argument("--no-recall", action="store_true")
@@ -96,6 +117,24 @@ def csrc_sha():
         h.update(open(os.path.join(gbuild.CSRC, f), "rb").read())
     h.update(" ".join(gbuild.FLAGS).encode())
     return h.hexdigest()[:16]
+
+
+def auto_inflight(args, dtype):
+    return max(1, args.inflight) if args.inflight else (4 if dtype == "f32" else 6)
+
+
+def workload_label(n, dim, dtype, data, nq, ef, k):
+    """Names what actually ran. BASELINE.json's configs get their tag only for their exact shape."""
+    comp = "i.i.d. uniform components" if data == "uniform" else "16-d latent cube through a fixed random linear map"
+    tag = "custom"
+    if data == "uniform" and dim == 100 and n == 10_000_000 and nq == 1024 and ef == 50:
+        tag = "C2 (BASELINE.json configs[1])" if dtype == "f32" else "C3 (BASELINE.json configs[2])"
+    elif data == "uniform" and dtype == "f32" and dim == 200 and n == 12_500_000 and nq == 4096:
+        tag = "C4 shard (one of the 8 shards of BASELINE.json configs[3]: 100M x 200-d f32)"
+    elif data == "uniform" and dtype == "i8" and dim == 100 and nq == 4096 and ef == 200:
+        tag = ("C5 shard (one of the 8 shards of BASELINE.json configs[4]: 1B x 100-d int8)" if n == 125_000_000
+               else "C5-shaped shard at reduced size (BASELINE.json configs[4] has 125M per shard)")
+    return "%s: %d x %d-d %s angular, %s, batch=%d, ef_search=%d, k=%d" % (tag, n, dim, dtype, comp, nq, ef, k)
 
 
 class Bench:
@@ -126,6 +165,9 @@ class Bench:
         self.ga, self._lib, self.lib = granne_amd, _lib, _lib.lib()
         self.stream = torch.cuda.current_stream().cuda_stream
         self.sp = C.c_void_p(self.stream)
+        # the in-flight streams, created ONCE: HIP assigns hardware queues at stream creation, so every measurement of
+        # a run sees the same stream-to-queue mapping
+        self.streams = [torch.cuda.Stream() for _ in range(8)]
 
     # ---- synthetic rows, generated and prepared on the device ---------------------------------------
     def synth_raw(self, seed, row0, rows, dim):
@@ -149,6 +191,13 @@ class Bench:
         uniform cube pushed through a fixed random LATENT x dim linear map (low intrinsic dimension:
         a graph index can reach recall 0.95 on it), then the same Vector::from."""
         if data == "uniform":
+            if dtype == "i8" and rows > 20_000_000:  # the f32 staging of 125M rows is 50 GB: in pieces
+                out = self.torch.empty((rows, dim), dtype=self.torch.int8, device="cuda")
+                step = 12_500_000
+                for r0 in range(0, rows, step):
+                    r1 = min(rows, r0 + step)
+                    out[r0:r1] = self.prepare(self.synth_raw(seed, row0 + r0, r1 - r0, dim), dtype)
+                return out
             return self.prepare(self.synth_raw(seed, row0, rows, dim), dtype)
         LATENT = 16
         proj = self.synth_raw(SEED + 7, 0, LATENT, dim)
@@ -180,7 +229,7 @@ class Bench:
         self.torch.cuda.synchronize()
 
     # ---- one workload on one index: the timed K steps + per-launch events + counters ----------------
-    def measure(self, index, queries, dim, esize, nq, ef, k, steps, warmup, inflight, contract=False):
+    def measure(self, index, queries, dim, esize, nq, ef, k, steps, warmup, inflight, contract=False, steady_s=0.0):
         torch = self.torch
         n_batches = warmup + steps
         ids = torch.empty((n_batches, nq, k), dtype=torch.int64, device="cuda")
@@ -197,9 +246,10 @@ class Bench:
         # Step i is enqueued on stream i % inflight: a batch starts while the previous ones drain (one
         # batch of 1024 one-wave walkers fills one wave slot per SIMD). Every step is still one batch
         # of `nq` queries through one kernel launch; nothing is skipped or cached.
-        streams = [torch.cuda.Stream() for _ in range(inflight)] if inflight > 1 else [torch.cuda.current_stream()]
-        for b in range(warmup):
-            step(b, streams[b % inflight].cuda_stream)
+        inflight = min(inflight, len(self.streams))
+        streams = self.streams[:inflight] if inflight > 1 else [torch.cuda.current_stream()]
+        for b in range(max(warmup, inflight)):  # (every stream has searched once: its scratch block exists)
+            step(b % n_batches, streams[b % inflight].cuda_stream)
         torch.cuda.synchronize()
         status.zero_()
         if contract:
@@ -221,9 +271,26 @@ class Bench:
         if int(status[0].item()) != 0:
             raise RuntimeError("exact-search scratch exhausted during the timed steps")
 
-        # the same K steps strictly one after the other on ONE stream. Two pairs of HIP events per step, all
-        # on the launch stream: around the whole call (scratch memset + walker + the exact walker's launch)
-        # and, inside the library, immediately around the walker's dispatch = what rocprofv3 reports per kernel
+        # the same K steps again and again, back to back, until `steady_s` seconds have passed: the K-step window above
+        # is a few milliseconds, this one is long enough to trust (same batches, same streams, one synchronisation)
+        steady = None
+        if steady_s > 0:
+            rounds = max(2, int(math.ceil(steady_s / max(elapsed, 1e-6))))
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for r in range(rounds):
+                for i in range(steps):
+                    step(warmup + i, streams[(r * steps + i) % inflight].cuda_stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t2
+            steady = {"value": round(rounds * steps * nq / dt, 1), "unit": "queries/s", "steps": rounds * steps,
+                      "seconds": round(dt, 3), "note": "the same K steps repeated back to back (rank-local)"}
+
+        # the same K steps strictly one after the other on ONE stream, twice: first bare (the wall clock of K back-to-back
+        # launches: what one batch at a time costs, launch gaps included), then with one pair of HIP events per step
+        # recorded inside the library immediately around the walker's dispatch = what rocprofv3 reports per kernel
+        # (a search is one kernel: walk_fast.h / slow_kernel.h). The events themselves are work on the stream, which is
+        # why the two loops are separate.
         glib, _glib = self.lib, self._lib
 
         def hip_event():
@@ -231,10 +298,15 @@ class Bench:
             _glib.check(glib.granne_hip_event_create(C.byref(e)))
             return e
 
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        kev = [(hip_event(), hip_event()) for _ in range(steps)]
+        step(0, self.stream)  # (the launch stream's scratch block exists)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i, self.stream)
+        torch.cuda.synchronize()
+        seq_elapsed = time.perf_counter() - t1
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        kev = [(hip_event(), hip_event()) for _ in range(steps)]
         for i in range(steps):
             b = warmup + i
             ev[i][0].record()
@@ -243,7 +315,6 @@ class Bench:
                                             status.data_ptr(), self.stream, kev[i][0].value, kev[i][1].value)
             ev[i][1].record()
         torch.cuda.synchronize()
-        seq_elapsed = time.perf_counter() - t1
         call_ms = [a.elapsed_time(b) for a, b in ev]
         step_ms = []
         for a, b in kev:
@@ -259,8 +330,8 @@ class Bench:
         mean_ms = float(np.mean(step_ms))
         achieved = alg_per_launch / (mean_ms * 1e-3) / 1e9
         return {
-            "elapsed": elapsed, "value_local": steps * nq / elapsed, "seq_elapsed": seq_elapsed,
-            "ids": ids, "dists": dists, "counts": counts, "status": status,
+            "elapsed": elapsed, "value_local": steps * nq / elapsed, "seq_elapsed": seq_elapsed, "steady": steady,
+            "ids": ids, "dists": dists, "counts": counts, "status": status, "inflight": inflight,
             "slow": int(status[1].item()), "spill": int(status[2].item()),
             "alg_per_launch": alg_per_launch, "achieved": achieved, "launch_ms_mean": mean_ms,
             "launch_ms_min": float(np.min(step_ms)), "call_ms_mean": float(np.mean(call_ms)),
@@ -284,6 +355,7 @@ class Bench:
             "bound": "hbm", "kernel": "fast_kernel (walk_fast.h)", "achieved": round(m["achieved"], 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(m["achieved"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "aggregate_achieved_with_inflight": round(m["alg_per_launch"] * (value_per_gpu / nq) / 1e9, 1),
+            "aggregate_frac_with_inflight": round(m["alg_per_launch"] * (value_per_gpu / nq) / 1e9 / HBM_PEAK_GBPS, 4),
             "alg_bytes_per_launch": int(m["alg_per_launch"]), "launch_ms_mean": round(m["launch_ms_mean"], 4),
             "launch_ms_min": round(m["launch_ms_min"], 4), "call_ms_mean": round(m["call_ms_mean"], 4),
             "per_query": m["per_query"],
@@ -325,10 +397,10 @@ class Bench:
         esize = 4 if dtype == "f32" else 1
         out = []
         for nq in batches:
-            steps, warmup = 4, 1
+            steps, warmup = 20, 1
             q = self.rows(data, SEED + 3, 0, (steps + warmup) * nq, dim, dtype)
             m = self.measure(index, q, dim, esize, nq, ef, k, steps, warmup, 1)
-            out.append({"batch": nq, "launch_ms_mean": round(m["launch_ms_mean"], 4),
+            out.append({"batch": nq, "steps": steps, "launch_ms_mean": round(m["launch_ms_mean"], 4),
                         "frac": round(m["achieved"] / HBM_PEAK_GBPS, 4),
                         "qps_one_launch_at_a_time": round(steps * nq / m["seq_elapsed"], 1),
                         "slow_path_queries": m["slow"]})
@@ -336,14 +408,30 @@ class Bench:
             self.torch.cuda.empty_cache()
         return out
 
-    def ef_sweep(self, index, queries, gt, nq, k, efs, steps, warmup, stop_at=None):
-        """recall@10 (first timed batch) and queries/sec (K batches, one at a time and three in flight)."""
+    def timed_window(self, run, n_distinct, min_s=0.05):
+        """calls/s of run(j) over a window of at least min_s seconds (sized from a short probe)."""
+        torch = self.torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(4):
+            run(j % n_distinct)
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / 4
+        reps = max(8, int(math.ceil(min_s / max(per, 1e-7))))
+        t0 = time.perf_counter()
+        for j in range(reps):
+            run(j % n_distinct)
+        torch.cuda.synchronize()
+        return reps / (time.perf_counter() - t0), reps
+
+    def ef_sweep(self, index, queries, gt, nq, k, efs, steps, warmup, inflight, stop_at=None):
+        """recall@10 (first timed batch) and queries/sec over windows of >= 50 ms, one batch at a time and in flight."""
         torch = self.torch
         out = []
         n_b = queries.shape[0] // nq
         o = (torch.empty((nq, k), dtype=torch.int64, device="cuda"), torch.empty((nq, k), dtype=torch.float32, device="cuda"),
              torch.empty((nq,), dtype=torch.int32, device="cuda"))
-        streams = [torch.cuda.Stream() for _ in range(3)]
+        streams = self.streams[:inflight]
         for e_ in efs:
             def run(b, on):
                 index.search_batch_device(queries[b * nq:(b + 1) * nq].data_ptr(), nq, e_, k, o[0].data_ptr(), o[1].data_ptr(),
@@ -351,35 +439,42 @@ class Bench:
             run(warmup, self.stream)
             torch.cuda.synchronize()
             rec = self.recall(gt, o[0], k)
-            reps = max(4, min(steps, n_b - warmup))
-            t0 = time.perf_counter()
-            for j in range(reps):
-                run(warmup + j % (n_b - warmup), self.stream)
-            torch.cuda.synchronize()
-            t_seq = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            for j in range(reps):
-                run(warmup + j % (n_b - warmup), streams[j % 3].cuda_stream)  # outputs overwrite each other: timing only
-            torch.cuda.synchronize()
-            t_inf = time.perf_counter() - t0
-            out.append({"ef": e_, "recall_at_10": round(rec, 4), "qps": round(reps * nq / t_inf, 1),
-                        "qps_one_batch_at_a_time": round(reps * nq / t_seq, 1)})
+            nd = n_b - warmup
+            r_seq, reps = self.timed_window(lambda j: run(warmup + j, self.stream), nd)
+            cnt = [0]
+
+            def infl(j):  # outputs overwrite each other: timing only
+                run(warmup + j, streams[cnt[0] % len(streams)].cuda_stream)
+                cnt[0] += 1
+            r_inf, reps_i = self.timed_window(infl, nd)
+            out.append({"ef": e_, "recall_at_10": round(rec, 4), "qps": round(r_inf * nq, 1),
+                        "qps_one_batch_at_a_time": round(r_seq * nq, 1), "batches_timed": reps_i})
             if stop_at is not None and rec >= stop_at:
                 break
         return out
 
     # ---- the CPU oracle beside it ---------------------------------------------------------------------
-    def cpu_baseline(self, elements, builder, queries_host_batches, ef, k, g_ids, g_d, order=None, single_thread_queries=256):
-        """the ONLY use of oracle/ in this file: the CPU baseline + parity check."""
+    def host_index(self, elements, builder, order=None):
+        """the oracle's view of the index: host copies of the elements (parallel first touch: the pages end up spread
+        over the NUMA nodes of the threads that wrote them instead of all on one socket) and of the layers"""
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle as orc
         orc.build()
-        a = self.args
-        # host copy of the elements with parallel first touch: the pages end up spread over the NUMA
-        # nodes of the threads that wrote them instead of all on one socket
         n = elements.shape[0]
-        h_el = np.empty(tuple(elements.shape), np.float32 if elements.dtype == self.torch.float32 else np.int8)
-        parts = 32
+        np_dt = np.float32 if elements.dtype == self.torch.float32 else np.int8
+        # the rows the walks gather at random live in transparent huge pages when the kernel grants them (4 GB in 4 KB
+        # pages is a TLB miss per row): the baseline should not lose to page walks what a tuned host would not
+        nbytes = int(np.prod(elements.shape)) * np.dtype(np_dt).itemsize
+        try:
+            import mmap
+            buf = mmap.mmap(-1, max(nbytes, 1))
+            buf.madvise(mmap.MADV_HUGEPAGE)
+            h_el = np.frombuffer(buf, dtype=np_dt, count=int(np.prod(elements.shape))).reshape(tuple(elements.shape))
+            self._host_pages = "transparent huge pages requested (MADV_HUGEPAGE)"
+        except Exception:
+            h_el = np.empty(tuple(elements.shape), np_dt)
+            self._host_pages = "default pages"
+        parts = 64
         bounds = [n * i // parts for i in range(parts + 1)]
 
         def cp(i):
@@ -389,33 +484,46 @@ class Bench:
         oix = orc.Index(h_el, builder.layers())
         if order is not None:
             oix = oix.reordered(order)
-        h_q = queries_host_batches
+        return oix
+
+    def cpu_baseline(self, oix, h_q, ef, k, g_ids, g_d, single_thread_queries=256):
+        """the ONLY use of oracle/ in this file: the CPU baseline + parity check (the index view comes from host_index)."""
+        from oracle import oracle as orc
+        a = self.args
         nqs = h_q.shape[0]
         # thread count: the best of {OpenMP default, all logical CPUs} unless given (a cgroup quota below
         # the logical CPU count makes oversubscription much slower)
         cands = [a.cpu_threads] if a.cpu_threads else sorted({orc.lib().gro_max_threads(), os.cpu_count() or 1})
         best = None
         for th in cands:
-            oix.search_batch(h_q[:min(nqs, 1024)], ef, k, n_threads=th)  # touch pages / spin up threads
-            for _rep in range(3):  # best of three: the host is shared and noisy
-                t1 = time.time()
-                res = oix.search_batch(h_q, ef, k, n_threads=th)
-                dt = time.time() - t1
-                if best is None or dt < best[0]:
-                    best = (dt, th, res)
-        cpu_s, threads, (o_ids, o_d, o_c, o_ctr) = best
-        m1 = min(single_thread_queries, nqs)
-        t1 = time.time()
-        oix.search_batch(h_q[:m1], ef, k, n_threads=1)
-        single_s = time.time() - t1
+            # one untimed pass inside the same parallel region, then as many timed passes as fill cpu_seconds
+            probe, _, _, _ = oix.search_batch_timed(h_q, ef, k, n_threads=th, repeats=1)
+            reps = max(1, int(math.ceil(a.cpu_seconds / max(probe, 1e-6))))
+            sec, o_ids, o_d, o_c = oix.search_batch_timed(h_q, ef, k, n_threads=th, repeats=reps)
+            rate = reps * nqs / sec
+            if best is None or rate > best[0]:
+                best = (rate, th, sec, reps, o_ids, o_d)
+        rate, threads, cpu_s, reps, o_ids, o_d = best
+        # one thread, on queries it has not just walked (a repeated pass over a few hundred queries runs out of L3)
+        m1 = min(single_thread_queries, max(1, nqs // 2))
+        oix.search_batch(h_q[:8], ef, k, n_threads=1)
+        t1 = time.perf_counter()
+        oix.search_batch(h_q[nqs - m1:], ef, k, n_threads=1)
+        single = m1 / (time.perf_counter() - t1)
         ids_ok = bool((g_ids == o_ids).all())
         d_ok = g_d.tobytes() == o_d.tobytes()
+        phys = (os.cpu_count() or 2) // 2
         return {
-            "value": round(nqs / cpu_s, 1), "unit": "queries/s", "cores": threads, "kind": "port",
-            "single_thread": {"value": round(m1 / single_s, 1), "unit": "queries/s", "queries": int(m1)},
-            "sample": "%d queries of the timed workload, same index; oracle/granne_oracle.c (C restatement of the "
-                      "reference's search; Rust toolchain absent), OpenMP dynamic over queries; %.2f s wall; thread counts "
-                      "tried %s x 3 repeats, best reported; elements first-touched by 8 threads" % (nqs, cpu_s, cands),
+            "value": round(rate, 1), "unit": "queries/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": round(single, 1), "unit": "queries/s", "queries": int(m1)},
+            "parallel_efficiency": round(rate / (min(threads, phys) * single), 3),
+            "sample": "%d queries of the timed workload, same index, %d passes = %.2f s wall after one untimed pass "
+                      "(gro_search_batch_timed: one OpenMP region, dynamic schedule over queries, threads and their scratch kept "
+                      "between passes; OMP_PROC_BIND=%s OMP_PLACES=%s); oracle/granne_oracle.c (C restatement of the reference's "
+                      "search; Rust toolchain absent); thread counts tried %s, best reported; elements first-touched by 8 threads, %s; "
+                      "parallel_efficiency = value / (min(threads, %d physical cores) x single_thread)"
+                      % (nqs, reps, cpu_s, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), cands,
+                         getattr(self, "_host_pages", "default pages"), phys),
             "gpu_matches_oracle": {"ids_bit_exact": ids_ok, "dists_bit_exact": bool(d_ok), "queries_checked": int(nqs)},
         }
 
@@ -447,7 +555,7 @@ def run_replica(B, args):
     n, dim, nq, ef, k = args.n, args.dim, args.batch, args.ef, args.k
     esize = 4 if args.dtype == "f32" else 1
     n_batches = args.warmup + args.steps
-    inflight = max(1, args.inflight)
+    inflight = auto_inflight(args, args.dtype)
 
     t0 = time.time()
     elements = B.rows(args.data, SEED, 0, n, dim, args.dtype)
@@ -467,7 +575,7 @@ def run_replica(B, args):
     if rank == 0:
         log("gen %.1fs, gpu build %.1fs, layers %s, index %.2f GB HBM" % (t_gen, t_build, layer_sizes, index.hbm_bytes() / 1e9))
 
-    m = B.measure(index, queries, dim, esize, nq, ef, k, args.steps, args.warmup, inflight, contract=True)
+    m = B.measure(index, queries, dim, esize, nq, ef, k, args.steps, args.warmup, inflight, contract=True, steady_s=0.5)
     value = world * args.steps * nq / m["elapsed"]
     wl_key = "%d|%d|%s|%s|nq%d|ef%d|k%d|nn%d|ms%d|re%d" % (n, dim, args.dtype, args.data, nq, ef, k, args.num_neighbors,
                                                         args.build_max_search, args.build_reinsert)
@@ -477,25 +585,30 @@ def run_replica(B, args):
         "metric": "queries/sec (recall@10 alongside), 10M x 100-d angular, batch=1024",
         "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "inflight_batches": inflight, "slow_path_queries": m["slow"], "visited_spill_walks": m["spill"],
+        "inflight_batches": m["inflight"], "slow_path_queries": m["slow"], "visited_spill_walks": m["spill"],
         "sequential": {"value": round(args.steps * nq / m["seq_elapsed"], 1),
                        "ms_per_step": round(m["seq_elapsed"] / args.steps * 1e3, 4),
                        "note": "same K steps, one stream, one batch at a time (rank-local)"},
+        "steady": m["steady"],
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
-            "workload": "C2: %d x %d-d %s angular (BASELINE.json configs[1]), %s components, batch=%d, ef_search=%d, k=%d"
-                        % (n, dim, args.dtype, "i.i.d. uniform" if args.data == "uniform" else "16-d latent", nq, ef, k),
+            "workload": workload_label(n, dim, args.dtype, args.data, nq, ef, k),
             "n_elements": n, "dim": dim, "batch": nq, "ef_search": ef, "k": k, "layers": layer_sizes,
             "graph": {"builder": "gpu-batched", "num_neighbors": args.num_neighbors,
                       "max_search": args.build_max_search, "reinsert": bool(args.build_reinsert),
                       "layer_multiplier": 15.0, "batch_max": args.batch_max, "build_s": round(t_build, 1),
                       "reordered": bool(args.reorder), "reorder_s": round(t_reorder, 2)},
-            "parallelism": "replica x%d (one process per GPU, no data-path collective); %d batches in flight per GPU"
-                           % (world, inflight),
+            "parallelism": "replica x%d (one process per GPU, no data-path collective); %d batches in flight per GPU, "
+                           "GPU_MAX_HW_QUEUES=%s" % (world, m["inflight"], os.environ.get("GPU_MAX_HW_QUEUES")),
         },
         "roofline": B.roofline(m, wl_key, value / world, nq),
         "kernel_sources_sha": csrc_sha(),
     }
+
+    # ---- N > 1: the partitioned exchange over RCCL, as a sub-record (all ranks take part) ---------------
+    if (world > 1 or args.force_partitioned) and not args.no_partitioned:
+        out["partitioned"] = partitioned_record(B, args, n, dim, args.dtype, nq, ef, k, args.steps, args.warmup, 1,
+                                                seed_base=SEED + 100)
 
     # ---- rank 0, N = 1: recall, sweep, CPU baseline, sub-records --------------------------------------
     if rank == 0:
@@ -509,14 +622,16 @@ def run_replica(B, args):
             out["recall_at_10"] = round(B.recall(gt, got, k), 4)
             efs = [int(x) for x in args.sweep_ef.split(",") if x]
             if efs and order is None:
-                out["ef_sweep"] = B.ef_sweep(index, queries, gt, nq, k, efs, args.steps, args.warmup, stop_at=0.95)
+                out["ef_sweep"] = B.ef_sweep(index, queries, gt, nq, k, efs, args.steps, args.warmup, inflight, stop_at=0.95)
         if world == 1 and args.cpu_batches > 0:
             nb = min(args.cpu_batches, args.steps)
             h_q = queries[b0 * nq:(b0 + nb) * nq].cpu().numpy()
             g_ids = m["ids"][b0:b0 + nb].reshape(-1, k).cpu().numpy().astype(np.uint64)
             g_d = m["dists"][b0:b0 + nb].reshape(-1, k).cpu().numpy()
-            out["cpu_baseline"] = B.cpu_baseline(elements, builder, h_q, ef, k, g_ids, g_d, order)
+            oix = B.host_index(elements, builder, order)
+            out["cpu_baseline"] = B.cpu_baseline(oix, h_q, ef, k, g_ids, g_d)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+            del oix
         if world == 1 and not args.no_extras:
             out["latency_nq1"] = B.latency_nq1(index, queries, dim, ef, k)
             if order is None:
@@ -525,158 +640,176 @@ def run_replica(B, args):
         if world == 1 and not args.no_extras and args.dtype == "f32" and args.data == "uniform" and order is None:
             del index, builder, elements, queries
             torch.cuda.empty_cache()
-            out["int8"] = sub_record(B, args, "i8", "uniform")
-            out["secondary"] = sub_record(B, args, "f32", "latent")
+            out["int8"] = sub_record(B, args, "i8", "uniform", n, dim, nq, args.ef, args.steps, args.warmup,
+                                     cpu_batches=args.cpu_batches, scaling=True)
+            out["secondary"] = sub_record(B, args, "f32", "latent", n, dim, nq, args.ef, args.steps, args.warmup,
+                                          cpu_batches=args.cpu_batches, find_ef=True)
+            if args.c4_elements:
+                out["c4_shard"] = sub_record(B, args, "f32", "uniform", args.c4_elements, 200, 4096, 50, 10, 3, cpu_batches=1,
+                                             recall_queries=1024)
+            if args.c5_elements:
+                out["c5_shard"] = sub_record(B, args, "i8", "uniform", args.c5_elements, 100, 4096, 200, 10, 2, cpu_batches=1,
+                                             recall_queries=1024)
     return out
 
 
-def sub_record(B, args, dtype, data):
-    """The same measurement on another element type / data distribution, as a sub-record of the line."""
+def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=1, scaling=False, find_ef=False,
+               recall_queries=None):
+    """The same measurement on another element type / data distribution / shape, as a sub-record of the line."""
     torch = B.torch
-    n, dim, nq, k = args.n, args.dim, args.batch, args.k
+    k = args.k
     esize = 4 if dtype == "f32" else 1
-    steps, warmup = args.steps, args.warmup
+    t_sub = time.time()
     elements = B.rows(data, SEED, 0, n, dim, dtype)
     queries = B.rows(data, SEED + 1, 0, (warmup + steps) * nq, dim, dtype)
     builder, index, t_build = B.build_index(elements, dtype)
-    gt = B.ground_truth(elements, queries[warmup * nq:(warmup + 1) * nq], k, dtype)
-    ef = args.ef
-    rec = {"dtype": dtype, "data": "synthetic, %s" % ("i.i.d. uniform components (BASELINE.json configs[2])" if data == "uniform"
-                                                       else "16-d latent uniform cube through a fixed random linear map into 100-d"),
-           "build_s": round(t_build, 1)}
-    if data == "latent":
-        sweep = B.ef_sweep(index, queries, gt, nq, k, [20, 30, 50, 70, 100, 140, 200, 300, 400, 600, 800], steps, warmup, stop_at=0.95)
+    rq = min(nq, recall_queries or nq)
+    gt = B.ground_truth(elements, queries[warmup * nq:warmup * nq + rq], k, dtype)
+    inflight = auto_inflight(args, dtype)
+    layer_sizes = [builder.layer_len(l) for l in range(builder.num_layers())]
+    rec = {"workload": workload_label(n, dim, dtype, data, nq, ef, k), "dtype": dtype, "data": "synthetic",
+           "n_elements": n, "dim": dim, "layers": layer_sizes, "build_s": round(t_build, 1),
+           "index_hbm_gb": round(index.hbm_bytes() / 1e9, 2)}
+    if find_ef:
+        sweep = B.ef_sweep(index, queries, gt, nq, k, [20, 30, 50, 70, 100, 140, 200, 300, 400, 600, 800], steps, warmup,
+                           inflight, stop_at=0.95)
         rec["ef_sweep"] = sweep
         ok = [s for s in sweep if s["recall_at_10"] >= 0.95]
         ef = ok[0]["ef"] if ok else sweep[-1]["ef"]
         rec["smallest_ef_with_recall_0.95"] = ef if ok else None
-    m = B.measure(index, queries, dim, esize, nq, ef, k, steps, warmup, max(1, args.inflight))
+        rec["workload"] = workload_label(n, dim, dtype, data, nq, ef, k)
+    m = B.measure(index, queries, dim, esize, nq, ef, k, steps, warmup, inflight, steady_s=0.3)
     wl_key = "%d|%d|%s|%s|nq%d|ef%d|k%d|nn%d|ms%d|re%d" % (n, dim, dtype, data, nq, ef, k, args.num_neighbors,
                                                         args.build_max_search, args.build_reinsert)
     rec.update({
-        "value": round(m["value_local"], 1), "unit": "queries/s", "ef_search": ef, "batch": nq, "k": k,
-        "inflight_batches": max(1, args.inflight), "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
+        "value": round(m["value_local"], 1), "unit": "queries/s", "ef_search": ef, "batch": nq, "k": k, "steps": steps,
+        "inflight_batches": m["inflight"], "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
         "sequential": {"value": round(steps * nq / m["seq_elapsed"], 1), "ms_per_step": round(m["seq_elapsed"] / steps * 1e3, 4)},
+        "steady": m["steady"],
         "slow_path_queries": m["slow"], "visited_spill_walks": m["spill"],
-        "recall_at_10": round(B.recall(gt, m["ids"][warmup], k), 4),
+        "recall_at_10": round(B.recall(gt, m["ids"][warmup][:rq], k), 4),
         "roofline": B.roofline(m, wl_key, m["value_local"], nq),
     })
-    if data == "uniform":
+    if scaling:
         rec["launch_scaling"] = B.launch_scaling(index, data, dim, dtype, ef, k)
-    if args.cpu_batches > 0:
-        nb = min(args.cpu_batches, steps)  # the same bounded sample as the main record (a few thousand queries finish
-        # in hundredths of a second on 128 threads: thread wake-up, not search, is what such a sample times)
+    if cpu_batches > 0:
+        nb = min(cpu_batches, steps)  # a bounded sample, repeated until cpu_seconds have passed
         h_q = queries[warmup * nq:(warmup + nb) * nq].cpu().numpy()
         g_ids = m["ids"][warmup:warmup + nb].reshape(-1, k).cpu().numpy().astype(np.uint64)
         g_d = m["dists"][warmup:warmup + nb].reshape(-1, k).cpu().numpy()
-        rec["cpu_baseline"] = B.cpu_baseline(elements, builder, h_q, ef, k, g_ids, g_d, single_thread_queries=128)
+        oix = B.host_index(elements, builder)
+        rec["cpu_baseline"] = B.cpu_baseline(oix, h_q, ef, k, g_ids, g_d, single_thread_queries=128)
         rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 2)
+        del oix
     del m, index, builder, elements, queries
     torch.cuda.empty_cache()
+    rec["wall_s"] = round(time.time() - t_sub, 1)
     return rec
 
 
-def run_partitioned(B, args):
-    """BASELINE.json configs[3]/[4]: the element set split into world * shards_per_gpu id ranges, one
-    independent index per range (src/elements/embeddings/parsing.rs:63-100). A step = one batch through
-    every shard's search + ONE all-gather of the packed per-shard top-k + the merge kernel."""
+def partitioned_record(B, args, n, dim, dtype, nq, ef, k, steps, warmup, spg, seed_base, depth=2, with_cpu=True):
+    """The element set split into world * spg id ranges, one independent index per range
+    (src/elements/embeddings/parsing.rs:63-100). A step = one batch through every shard's search + ONE all-gather of the
+    packed per-shard top-k + the merge kernel; steps are pipelined `depth` deep (granne_amd/sharded.py). Collective:
+    every rank calls this with the same arguments. Returns the record (the same on every rank up to rank-local timings)."""
     torch, dist = B.torch, B.dist
     from granne_amd import sharded
     world, rank = B.world, B.rank
-    spg = max(1, args.shards_per_gpu)
     G = world * spg
-    n, dim, nq, ef, k = args.n, args.dim, args.batch, args.ef, args.k
-    esize = 4 if args.dtype == "f32" else 1
-    n_batches = args.warmup + args.steps
+    esize = 4 if dtype == "f32" else 1
+    n_batches = warmup + steps
     bounds = sharded.shard_bounds(n, G)
     offsets = [b[0] for b in bounds]
     mine = list(range(rank * spg, (rank + 1) * spg))
-
     t0 = time.time()
-    # per-shard seed, clear of the query stream's (SEED + 1): shard g is rows 0.. of stream SEED + 100 + g
-    elements = [B.rows(args.data, SEED + 100 + g, 0, bounds[g][1] - bounds[g][0], dim, args.dtype) for g in mine]
-    queries = B.rows(args.data, SEED + 1, 0, n_batches * nq, dim, args.dtype)  # the SAME batches on every rank
+    # per-shard seed, clear of the query stream's (SEED + 1): shard g is rows 0.. of stream seed_base + g
+    elements = [B.rows(args.data, seed_base + g, 0, bounds[g][1] - bounds[g][0], dim, dtype) for g in mine]
+    queries = B.rows(args.data, SEED + 1, 0, n_batches * nq, dim, dtype)  # the SAME batches on every rank
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     builders, indexes, t_build = [], [], 0.0
     for e in elements:
-        b, ix, tb = B.build_index(e, args.dtype)
+        b, ix, tb = B.build_index(e, dtype)
         builders.append(b)
         indexes.append(ix)
         t_build += tb
     layer_sizes = [builders[0].layer_len(l) for l in range(builders[0].num_layers())]
     if rank == 0:
-        log("gen %.1fs, gpu build %.1fs (%d local shards), shard layers %s" % (t_gen, t_build, spg, layer_sizes))
+        log("partitioned: gen %.1fs, gpu build %.1fs (%d local shards), shard layers %s" % (t_gen, t_build, spg, layer_sizes))
     sg = sharded.ShardedGranne(indexes, offsets)
+    batches = [queries[b * nq:(b + 1) * nq] for b in range(n_batches)]
 
-    out_ids = torch.empty((n_batches, nq, k), dtype=torch.int64, device="cuda")
-    out_d = torch.empty((n_batches, nq, k), dtype=torch.float32, device="cuda")
-
-    def step(b, timed=False):
-        i, d, c = sg.search_batch(queries[b * nq:(b + 1) * nq], ef, k, check_status=False, timed=timed)
-        out_ids[b].copy_(i)
-        out_d[b].copy_(d)
-
-    for b in range(args.warmup):
-        step(b)
+    sg.search_batches(batches[:max(warmup, depth)], ef, k, depth=depth)
     B.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    res = sg.search_batches(batches[warmup:], ef, k, depth=depth, check_status=False)
     B.barrier()
     elapsed = time.perf_counter() - t0
     if B.use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if int(sg._status[:, 0].sum().item()) != 0:
+    if bool(sg.status_of_last_batch(0)[:, 0].any().item()):
         raise RuntimeError("exact-search scratch exhausted during the timed steps")
-    value = args.steps * nq / elapsed  # every rank answers the same queries: the job's rate, not a sum over ranks
+    value = steps * nq / elapsed  # every rank answers the same queries: the job's rate, not a sum over ranks
+    out_ids = torch.stack([r[0] for r in res])
+    out_d = torch.stack([r[1] for r in res])
 
-    # phases of a step (HIP events on the stream; synchronised, so not the pipelined rate)
+    # the same steps strictly one batch at a time, and its phases (HIP events; synchronised, so not the pipelined rate)
+    B.barrier()
+    t0 = time.perf_counter()
+    for b in range(warmup, n_batches):
+        sg.search_batch(batches[b], ef, k, check_status=False)
+    B.barrier()
+    seq_elapsed = time.perf_counter() - t0
     ph = {"search_ms": [], "exchange_ms": [], "merge_ms": []}
-    for i in range(min(args.steps, 10)):
-        step(args.warmup + i, timed=True)
+    for i in range(min(steps, 10)):
+        sg.search_batch(batches[warmup + i], ef, k, check_status=False, timed=True)
         for key in ph:
             ph[key].append(sg.timings[key])
     phases = {key: round(float(np.mean(v)), 4) for key, v in ph.items()}
 
     # roofline of the dominant kernel: shard 0 of this rank, one launch at a time
-    m = B.measure(indexes[0], queries, dim, esize, nq, ef, k, args.steps, args.warmup, 1)
+    m = B.measure(indexes[0], queries, dim, esize, nq, ef, k, steps, warmup, 1)
     out = {
-        "metric": "queries/sec (recall@10 alongside), partitioned index, batch=%d" % nq,
-        "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "metric": "queries/sec, partitioned index (every rank searches every batch), batch=%d" % nq,
+        "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "partitioned",
+        "scaling_note": "the element set is split over the ranks and every rank answers the SAME queries: value is the job's "
+                        "rate (not a sum over ranks), per-GPU work shrinks as ranks are added",
+        "pipeline_depth": depth,
+        "sequential": {"value": round(steps * nq / seq_elapsed, 1), "ms_per_step": round(seq_elapsed / steps * 1e3, 4),
+                       "note": "one batch at a time: search, all-gather, merge, then the next batch"},
+        "dtype": dtype, "data": "synthetic",
         "config": {
-            "workload": "%d x %d-d %s angular in %d shards of %d (BASELINE.json configs[%d] shape), batch=%d, ef_search=%d, k=%d"
-                        % (n, dim, args.dtype, G, bounds[0][1] - bounds[0][0], 3 if args.dtype == "f32" else 4, nq, ef, k),
+            "workload": "%d x %d-d %s angular in %d shards of %d, batch=%d, ef_search=%d, k=%d"
+                        % (n, dim, dtype, G, bounds[0][1] - bounds[0][0], nq, ef, k),
             "n_elements": n, "shards": G, "shards_per_gpu": spg, "shard_elements": bounds[0][1] - bounds[0][0], "dim": dim,
             "batch": nq, "ef_search": ef, "k": k, "shard_layers": layer_sizes,
             "graph": {"builder": "gpu-batched", "num_neighbors": args.num_neighbors, "max_search": args.build_max_search,
                       "reinsert": bool(args.build_reinsert), "layer_multiplier": 15.0, "batch_max": args.batch_max,
                       "build_s": round(t_build, 1)},
-            "parallelism": "partitioned x%d (%d ranks x %d shards; one all-gather of the packed per-shard top-k per batch, "
-                           "then merge_topk_kernel)" % (G, world, spg),
+            "parallelism": "partitioned x%d (%d ranks x %d shards; one all-gather of the packed per-shard top-k + status words "
+                           "per batch, then merge_topk_kernel; %d batches pipelined)" % (G, world, spg, depth),
         },
         "exchange": {"collective": "all_gather_into_tensor (RCCL)" if world > 1 else "none (one rank)",
+                     "collectives_per_batch": 1 if world > 1 else 0,
                      "bytes_per_rank_per_batch": sg.exchange_bytes_per_rank(nq, k), "ranks": world},
         "phases_ms": phases,
-        "roofline": B.roofline(m, "partitioned|%d|%d|%s|nq%d|ef%d" % (bounds[0][1] - bounds[0][0], dim, args.dtype, nq, ef),
+        "roofline": B.roofline(m, "partitioned|%d|%d|%s|nq%d|ef%d" % (bounds[0][1] - bounds[0][0], dim, dtype, nq, ef),
                                m["value_local"], nq),
-        "kernel_sources_sha": csrc_sha(),
     }
     out["roofline"]["note"] = "search kernel of ONE shard (this rank's first), one launch at a time"
 
     # ---- recall against exact brute force over ALL shards --------------------------------------------
-    b0 = args.warmup
+    b0 = warmup
     if not args.no_recall:
         q0 = queries[b0 * nq:(b0 + 1) * nq]
         loc_v, loc_i = [], []
         for j, g in enumerate(mine):
-            gt = torch.from_numpy(B.ground_truth(elements[j], q0, k, args.dtype)).cuda()
+            gt = torch.from_numpy(B.ground_truth(elements[j], q0, k, dtype)).cuda()
             e = elements[j].float()
-            if args.dtype == "i8":
+            if dtype == "i8":
                 e = e / e.norm(dim=1, keepdim=True).clamp_min(1e-30)
             sims = (q0.float()[:, None, :] * e[gt]).sum(-1)
             loc_v.append(sims)
@@ -690,46 +823,50 @@ def run_partitioned(B, args):
             lv, li = torch.cat(av, 1), torch.cat(ai, 1)
         top = lv.topk(k, dim=1).indices
         gt_all = li.gather(1, top).cpu().numpy()
-        out["recall_at_10"] = round(B.recall(gt_all, out_ids[b0], k), 4)
+        out["recall_at_10"] = round(B.recall(gt_all, out_ids[0], k), 4)
 
     # ---- parity: this rank's first shard against the CPU oracle; the merge against the numpy merge ----
-    if args.cpu_batches > 0:
-        from oracle import oracle as orc  # the checker, as in replica mode
-        from oracle.merge import merge_topk_numpy, unpack_topk
-        orc.build()
+    if with_cpu and args.cpu_batches > 0:
+        from oracle.merge import merge_topk_numpy, unpack_topk  # the checker, as in replica mode
         q1 = queries[b0 * nq:(b0 + 1) * nq]
-        pb = sharded.packed_bytes(nq, k)
-        mine_buf = torch.empty((spg, pb), dtype=torch.uint8, device="cuda")
-        sg._gpu_local_search(q1, ef, k, mine_buf)
+        sg.search_batch(q1, ef, k)  # slot 0 now holds this batch's gathered per-shard results
         torch.cuda.synchronize()
-        if world > 1:
-            allb = torch.empty((world, spg, pb), dtype=torch.uint8, device="cuda")
-            dist.all_gather_into_tensor(allb.view(-1), mine_buf.view(-1))
-        else:
-            allb = mine_buf[None]
-        parts = [unpack_topk(allb.view(G, pb)[g].cpu().numpy(), nq, k) for g in range(G)]
+        gathered = sg._slots[0].gathered.view(G, -1).cpu().numpy()
+        parts = [unpack_topk(gathered[g], nq, k) for g in range(G)]
         w_ids, w_d, w_c = merge_topk_numpy(np.stack([p_[0] for p_ in parts]), np.stack([p_[1] for p_ in parts]),
                                            np.stack([p_[2] for p_ in parts]), offsets, k)
-        merge_ok = bool((out_ids[b0].cpu().numpy().astype(np.uint64) == w_ids).all()
-                        and out_d[b0].cpu().numpy().tobytes() == w_d.tobytes())
-        t1 = time.time()
-        oix = orc.Index(elements[0].cpu().numpy(), builders[0].layers())
-        o_ids, o_d, o_c, _ = oix.search_batch(q1.cpu().numpy(), ef, k, n_threads=0)
-        cpu_s = time.time() - t1
+        merge_ok = bool((out_ids[0].cpu().numpy().astype(np.uint64) == w_ids).all()
+                        and out_d[0].cpu().numpy().tobytes() == w_d.tobytes())
+        oix = B.host_index(elements[0], builders[0])
         mi, md, mc = parts[mine[0]]
-        shard_ok = bool((mi == o_ids).all() and md.tobytes() == o_d.tobytes() and (mc == o_c).all())
+        cb = B.cpu_baseline(oix, q1.cpu().numpy(), ef, k, mi, md, single_thread_queries=64)
+        shard_ok = bool(cb["gpu_matches_oracle"]["ids_bit_exact"] and cb["gpu_matches_oracle"]["dists_bit_exact"])
         ok = torch.tensor([int(merge_ok), int(shard_ok)], dtype=torch.int32, device="cuda")
         if B.use_dist:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        shard_rate = cb["value"]
         out["cpu_baseline"] = {
-            "value": round(nq / cpu_s / max(1, G), 1), "unit": "queries/s", "cores": orc.lib().gro_max_threads(), "kind": "port",
-            "sample": "%d queries on ONE shard of %d (oracle/granne_oracle.c, OpenMP over queries; includes building the host "
-                      "index view): %.2f s; a CPU host answering the partitioned index searches all %d shards per query, "
-                      "so the job rate is that shard rate / %d" % (nq, bounds[0][1] - bounds[0][0], cpu_s, G, G),
+            "value": round(shard_rate / max(1, G), 1), "unit": "queries/s", "cores": cb["cores"], "kind": "port",
+            "one_shard": {"value": shard_rate, "single_thread": cb["single_thread"], "parallel_efficiency": cb["parallel_efficiency"]},
+            "sample": "search only (the host index view is built outside the clock): " + cb["sample"] + "; measured on ONE shard of "
+                      "%d -- a CPU host answering the partitioned index searches all %d shards per query, so the job rate is that "
+                      "shard rate / %d" % (bounds[0][1] - bounds[0][0], G, G),
             "gpu_matches_oracle": {"every_rank_first_shard_bit_exact": bool(int(ok[1].item())),
                                    "merged_equals_numpy_merge_of_shard_results": bool(int(ok[0].item())),
                                    "queries_checked": int(nq)},
         }
+        del oix
+    del m, sg, indexes, builders, elements, queries
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_partitioned(B, args):
+    """BASELINE.json configs[3]/[4] shape: bench.py --mode partitioned [--shards-per-gpu S]."""
+    out = partitioned_record(B, args, args.n, args.dim, args.dtype, args.batch, args.ef, args.k, args.steps, args.warmup,
+                             max(1, args.shards_per_gpu), seed_base=SEED + 100)
+    out["vs_baseline"] = None
+    out["kernel_sources_sha"] = csrc_sha()
     return out
 
 

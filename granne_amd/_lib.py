@@ -86,6 +86,7 @@ SIGNATURES = {
     "granne_hip_packed_topk_bytes": (u64, [u32, u32]),
     "granne_hip_search_batch_packed_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp]),
     "granne_hip_merge_topk_packed_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, i32, vp]),
+    "granne_hip_merge_topk_packed_strided_device": (i32, [vp, u64, vp, u32, u32, u32, vp, vp, vp, i32, vp]),
     "granne_hip_sharded_create": (i32, [C.POINTER(vp), vp, vp, u32]),
     "granne_hip_sharded_destroy": (None, [vp]),
     "granne_hip_sharded_num_shards": (u32, [vp]),

@@ -1180,6 +1180,18 @@ extern "C" int granne_hip_merge_topk_packed_device(const void* d_packed, const u
                         shard_offsets, n_shards, nq, k, d_out_ids, d_out_dists, d_out_counts, device_id, stream);
 }
 
+extern "C" int granne_hip_merge_topk_packed_strided_device(const void* d_packed, uint64_t stride_bytes,
+                                                           const uint64_t* shard_offsets, uint32_t n_shards, uint32_t nq,
+                                                           uint32_t k, uint64_t* d_out_ids, float* d_out_dists,
+                                                           uint32_t* d_out_counts, int device_id, void* stream) {
+    const uint8_t* base = (const uint8_t*)d_packed;
+    if (!base && nq) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (stride_bytes < granne_hip_packed_topk_bytes(nq, k) || (stride_bytes & 3))
+        return fail(GRANNE_HIP_ERR_INVALID, "stride must be a multiple of 4 and at least granne_hip_packed_topk_bytes");
+    return merge_launch(base, base + packed_dists_off(nq, k), base + packed_counts_off(nq, k), stride_bytes, stride_bytes,
+                        stride_bytes, shard_offsets, n_shards, nq, k, d_out_ids, d_out_dists, d_out_counts, device_id, stream);
+}
+
 extern "C" int granne_hip_search_batch_packed_device(const granne_hip_index* ix, const void* d_queries, uint32_t nq,
                                                      uint32_t max_search, uint32_t num_neighbors, void* d_packed,
                                                      uint32_t* d_status, void* stream) {

@@ -4,9 +4,16 @@ The element set is split into independent indexes (the reference's own shard hel
 elements the same way, src/elements/embeddings/parsing.rs:63-100); a rank holds one or more
 shards on its GPU. Every rank answers the same query batch on its shards, writing each shard's
 top-k into ONE packed buffer ([nq*k u64 local ids][nq*k f32 dists][nq u32 counts]:
-granne_hip_packed_topk_bytes); ONE all-gather of those buffers is the exchange step
-(124 KB per shard at nq = 1024, k = 10 -- latency-, not bandwidth-bound over xGMI), then the merge
-kernel ranks the n_shards*k candidates of each query by (dist, global id). SURVEY.md 8e.
+granne_hip_packed_topk_bytes) followed by the shard's four status words; ONE all-gather of those
+buffers is the exchange step (124 KB per shard at nq = 1024, k = 10 -- latency-, not bandwidth-bound
+over xGMI), then the merge kernel ranks the n_shards*k candidates of each query by (dist, global id).
+The status words travel in the same collective, so a shard whose exact-search scratch ran out is seen
+by EVERY rank: all ranks raise together instead of diverging. SURVEY.md 8e.
+
+Batches are pipelined (`search_batches`): a batch's all-gather and merge run on a side stream while
+the next batch is searched on the shard streams -- the exchange costs one collective latency per
+batch, and that latency is hidden behind the next batch's search. `search_batch` is the one-batch
+form (and reports the phases when `timed`).
 
 torch.distributed supplies the collective (backend "nccl" = RCCL on ROCm; "gloo" in the CPU
 tests). The local search and the merge are the HIP kernels behind the C ABI; they are constructor
@@ -17,6 +24,8 @@ drives several GPUs from one process uses granne_hip_sharded_* (include/granne_h
 import ctypes as C
 
 import numpy as np
+
+STATUS_BYTES = 16  # u32[4] after each shard's packed top-k: [0] exact-search scratch exhausted, [1] hand-overs, [2] spills
 
 
 def shard_bounds(n_elements, n_shards):
@@ -29,11 +38,23 @@ def packed_bytes(nq, k):
     return (nq * k * 12 + nq * 4 + 15) & ~15
 
 
+class _Slot:
+    """One batch in flight: this rank's packed results, the gathered ones, and what marks the batch done."""
+
+    def __init__(self):
+        self.key = None
+        self.mine = self.gathered = None
+        self.out = None
+        self.done = None   # GPU: event recorded after the merge; CPU: the collective's work handle
+        self.busy = False
+        self.nq = self.k = 0
+
+
 class ShardedGranne:
     """`local_indexes`: this rank's granne_amd.Granne objects (local ids), in global shard order
     rank*len(local_indexes) + i. `all_offsets`: the first global id of EVERY shard of the job (known
     to every rank: shard_bounds is deterministic), world*len(local_indexes) entries.
-    Collective: every rank must call search_batch with the same queries."""
+    Collective: every rank must call search_batch / search_batches with the same queries."""
 
     def __init__(self, local_indexes, all_offsets, group=None, local_search=None, merge=None):
         import torch.distributed as dist
@@ -49,36 +70,59 @@ class ShardedGranne:
         self._on_gpu = local_search is None
         self._local_search = local_search or self._gpu_local_search
         self._merge = merge or self._gpu_merge
-        self._streams = None
-        self._status = None
+        self._streams = None      # one per local shard
+        self._xstream = None      # exchange + merge
+        self._slots = []
+        self._exhausted = None    # device flag: a shard of the job reported exhausted scratch (checked lazily)
         self.timings = None  # set by search_batch(timed=True): HIP-event ms of search / exchange / merge
 
     # ---- defaults: HIP kernels through the C ABI, tensors on this rank's GPU ---------------------
-    def _gpu_local_search(self, queries, max_search, k, out):
-        """Every local shard searches the batch on a stream of its own; results land in out[i] (packed)."""
+    def _device(self):
+        import torch
+        return torch.device("cuda", self.indexes[0].device) if self._on_gpu else torch.device("cpu")
+
+    def _gpu_streams(self):
+        import torch
+        if self._streams is None:
+            dev = self._device()
+            self._streams = [torch.cuda.Stream(device=dev) for _ in self.indexes]
+            self._xstream = torch.cuda.Stream(device=dev)
+        return self._streams
+
+    def _gpu_local_search(self, queries, max_search, k, out, wait_for=None):
+        """Every local shard searches the batch on a stream of its own; shard i's packed results and status words
+        land in out[i]. Returns the events recorded after each shard's search."""
         import torch
         from ._lib import check, lib
+        dev = self._device()
         q = queries if torch.is_tensor(queries) else torch.from_numpy(np.ascontiguousarray(queries))
-        dev = torch.device("cuda", self.indexes[0].device)
         q = q.to(dev).contiguous()
         nq = q.shape[0]
-        if self._streams is None:
-            self._streams = [torch.cuda.Stream(device=dev) for _ in self.indexes]
-            self._status = torch.zeros((self.local, 4), dtype=torch.int32, device=dev)
+        pb = packed_bytes(nq, k)
         cur = torch.cuda.current_stream(dev)
-        self._status.zero_()
+        if wait_for is not None:
+            cur.wait_event(wait_for)  # the slot's previous batch has been gathered and merged
+        out[:, pb:].zero_()  # the shards' status words
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        events = []
         for i, ix in enumerate(self.indexes):
-            s = self._streams[i]
-            s.wait_stream(cur)  # the queries (and `out`) are ready on the caller's stream
+            s = self._gpu_streams()[i]
+            s.wait_event(ready)  # the queries and `out` are ready on the caller's stream
+            if wait_for is not None:
+                s.wait_event(wait_for)
+            q.record_stream(s)
             check(lib().granne_hip_search_batch_packed_device(ix._h, C.c_void_p(q.data_ptr()), nq, int(max_search), int(k),
                                                               C.c_void_p(out[i].data_ptr()),
-                                                              C.c_void_p(self._status[i].data_ptr()),
+                                                              C.c_void_p(out[i].data_ptr() + pb),
                                                               C.c_void_p(s.cuda_stream)))
-        for s in self._streams:
-            cur.wait_stream(s)
-        return q
+            e = torch.cuda.Event()
+            e.record(s)
+            events.append(e)
+        return events
 
     def _gpu_merge(self, gathered, offsets, nq, k):
+        """gathered: [n_shards, packed_bytes + STATUS_BYTES] on the GPU; runs on the current stream."""
         import torch
         from ._lib import check, lib
         G = len(offsets)
@@ -87,48 +131,141 @@ class ShardedGranne:
         out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
         out_c = torch.empty(nq, dtype=torch.int32, device=dev)
         off = (C.c_uint64 * G)(*offsets)
-        check(lib().granne_hip_merge_topk_packed_device(C.c_void_p(gathered.data_ptr()), off, G, nq, k,
-                                                        C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_d.data_ptr()),
-                                                        C.c_void_p(out_c.data_ptr()), dev.index or 0,
-                                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        check(lib().granne_hip_merge_topk_packed_strided_device(
+            C.c_void_p(gathered.data_ptr()), gathered.stride(0), off, G, nq, k, C.c_void_p(out_ids.data_ptr()),
+            C.c_void_p(out_d.data_ptr()), C.c_void_p(out_c.data_ptr()), dev.index or 0,
+            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return out_ids, out_d, out_c
 
-    # ---- search + the one exchange step + merge ---------------------------------------------------------
+    # ---- one batch through search, the one exchange step and the merge ------------------------------------------
+    def _slot(self, i, nq, k):
+        import torch
+        while len(self._slots) <= i:
+            self._slots.append(_Slot())
+        sl = self._slots[i]
+        if sl.key != (nq, k):
+            dev = self._device()
+            pbs = packed_bytes(nq, k) + STATUS_BYTES
+            sl.mine = torch.zeros((self.local, pbs), dtype=torch.uint8, device=dev)  # this rank's shards write here
+            sl.gathered = (torch.zeros((self.world, self.local, pbs), dtype=torch.uint8, device=dev)
+                           if self.world > 1 else sl.mine[None])
+            sl.key, sl.nq, sl.k = (nq, k), nq, k
+            sl.done = None
+        return sl
+
+    def _start(self, sl, queries, max_search, k, ev=None):
+        """Enqueue one batch: shard searches, then (side stream) all-gather + merge."""
+        import torch
+        nq = sl.nq
+        if self._on_gpu:
+            dev = self._device()
+            cur = torch.cuda.current_stream(dev)
+            self._gpu_streams()
+            if ev:
+                ev[0].record(cur)
+            # the slot's buffers are free once its previous batch has been merged
+            searched = self._local_search(queries, max_search, k, sl.mine, wait_for=sl.done)
+            x = self._xstream
+            for e in searched:
+                x.wait_event(e)
+            with torch.cuda.stream(x):
+                if ev:
+                    ev[1].record(x)
+                if self.world > 1:
+                    # ONE collective: every rank's packed results (ids, dists, counts and status words together)
+                    self.dist.all_gather_into_tensor(sl.gathered.view(-1), sl.mine.reshape(-1), group=self.group)
+                if ev:
+                    ev[2].record(x)
+                sl.out = self._merge(sl.gathered.view(self.world * self.local, -1), self.offsets, nq, k)
+                if ev:
+                    ev[3].record(x)
+                sl.done = torch.cuda.Event()
+                sl.done.record(x)
+        else:
+            self._local_search(queries, max_search, k, sl.mine)
+            sl.done = None
+            if self.world > 1:
+                sl.done = self.dist.all_gather_into_tensor(sl.gathered.view(-1), sl.mine.reshape(-1), group=self.group,
+                                                           async_op=True)
+        sl.busy = True
+
+    def _finish(self, sl, check_status):
+        """The batch's results, usable on the caller's stream."""
+        import torch
+        nq, k = sl.nq, sl.k
+        if self._on_gpu:
+            cur = torch.cuda.current_stream(self._device())
+            cur.wait_event(sl.done)
+            for t in sl.out:
+                t.record_stream(cur)
+            out = sl.out
+        else:
+            if sl.done is not None:
+                sl.done.wait()
+            out = self._merge(sl.gathered.view(self.world * self.local, -1), self.offsets, nq, k)
+        sl.busy = False
+        if check_status:
+            # the status words of EVERY shard of the job came with the all-gather: a shard whose exact-search scratch
+            # ran out wrote empty results -- every rank sees it (and raises in _raise_if_exhausted), nobody merges silently
+            pb = packed_bytes(nq, k)
+            bad = sl.gathered.view(self.world * self.local, -1)[:, pb:pb + 4].any()
+            self._exhausted = bad if self._exhausted is None else (self._exhausted | bad)
+        return out
+
+    def _raise_if_exhausted(self):
+        bad, self._exhausted = self._exhausted, None
+        if bad is not None and bool(bad.item()):  # one synchronisation
+            from ._lib import ERR_OVERFLOW, GranneHipError
+            raise GranneHipError(ERR_OVERFLOW, "a shard's exact-search scratch is exhausted (raise OPT_SLOW_SLOTS)")
+
     def search_batch(self, queries, max_search, k, check_status=True, timed=False):
         """Returns (ids [nq,k] global, dists [nq,k], counts [nq]) -- identical on every rank."""
         import torch
         nq = int(queries.shape[0])
-        pb = packed_bytes(nq, k)
-        on_gpu = self._on_gpu
-        dev = torch.device("cuda", self.indexes[0].device) if on_gpu else torch.device("cpu")
-        mine = torch.empty((self.local, pb), dtype=torch.uint8, device=dev)  # this rank's shards write here
-        gathered = torch.empty((self.world, self.local, pb), dtype=torch.uint8, device=dev) if self.world > 1 else mine[None]
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (timed and on_gpu) else None
+        sl = self._slot(0, nq, k)
+        if sl.busy:
+            raise RuntimeError("search_batch while batches of search_batches are in flight")
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (timed and self._on_gpu) else None
+        self._start(sl, queries, max_search, k, ev)
+        out = self._finish(sl, check_status)
+        if check_status:
+            self._raise_if_exhausted()
         if ev:
-            ev[0].record()
-        self._local_search(queries, max_search, k, mine)
-        if ev:
-            ev[1].record()
-        if self.world > 1:
-            # ONE collective: every rank's packed results (ids, dists and counts together)
-            self.dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=self.group)
-        if ev:
-            ev[2].record()
-        out = self._merge(gathered.view(self.world * self.local, pb), self.offsets, nq, k)
-        if ev:
-            ev[3].record()
-            torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(self._device())
             self.timings = {"search_ms": ev[0].elapsed_time(ev[1]), "exchange_ms": ev[1].elapsed_time(ev[2]),
                             "merge_ms": ev[2].elapsed_time(ev[3])}
-        if check_status and on_gpu and self._status is not None:
-            # a shard whose exact-search scratch ran out wrote empty results: report, never merge silently
-            if int(self._status[:, 0].sum().item()) != 0:
-                from ._lib import ERR_OVERFLOW, GranneHipError
-                raise GranneHipError(ERR_OVERFLOW, "a shard's exact-search scratch is exhausted (raise OPT_SLOW_SLOTS)")
         return out
 
+    def search_batches(self, batches, max_search, k, depth=2, check_status=True):
+        """Pipelined: up to `depth` batches in flight -- batch i's all-gather + merge overlap batch i+1's search.
+        `batches`: a sequence of [nq, dim] query batches (the same on every rank). Returns the list of
+        (ids, dists, counts), in order; results are identical to search_batch's."""
+        depth = max(1, int(depth))
+        results = [None] * len(batches)
+        pending = []  # (batch index, slot)
+        for b, q in enumerate(batches):
+            if b % depth < len(self._slots) and self._slots[b % depth].busy:  # the slot's previous batch first
+                pb_, psl = pending.pop(0)
+                assert psl is self._slots[b % depth]
+                results[pb_] = self._finish(psl, check_status)
+            sl = self._slot(b % depth, int(q.shape[0]), k)
+            self._start(sl, q, max_search, k)
+            pending.append((b, sl))
+        for pb_, psl in pending:
+            results[pb_] = self._finish(psl, check_status)
+        if check_status:
+            self._raise_if_exhausted()  # once for the whole run of batches: every rank raises together
+        return results
+
+    def status_of_last_batch(self, slot=0):
+        """[n_shards, 4] int32: the status words of every shard of the job for the last batch of that slot."""
+        import torch
+        sl = self._slots[slot]
+        pb = packed_bytes(sl.nq, sl.k)
+        return sl.gathered.view(self.world * self.local, -1)[:, pb:pb + STATUS_BYTES].contiguous().view(torch.int32)
+
     def exchange_bytes_per_rank(self, nq, k):
-        return self.local * packed_bytes(nq, k)
+        return self.local * (packed_bytes(nq, k) + STATUS_BYTES)
 
 
 def replica_query_rows(rank, world_size, n_batches, batch):

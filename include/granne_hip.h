@@ -247,6 +247,13 @@ int granne_hip_search_batch_packed_device(const granne_hip_index* index, const v
 int granne_hip_merge_topk_packed_device(const void* d_packed, const uint64_t* shard_offsets, uint32_t n_shards,
                                         uint32_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_dists,
                                         uint32_t* d_out_counts, int device_id, void* stream);
+/* The same with shard s's buffer at d_packed + s * stride_bytes (stride_bytes >= granne_hip_packed_topk_bytes, a
+ * multiple of 4): a rank can append words of its own to each packed buffer -- granne_amd/sharded.py sends every
+ * shard's four status words through the same all-gather, so that all ranks see a shard that ran out of scratch. */
+int granne_hip_merge_topk_packed_strided_device(const void* d_packed, uint64_t stride_bytes,
+                                                const uint64_t* shard_offsets, uint32_t n_shards, uint32_t nq,
+                                                uint32_t k, uint64_t* d_out_ids, float* d_out_dists,
+                                                uint32_t* d_out_counts, int device_id, void* stream);
 
 /* ---- a partitioned index driven by one host process ----------------------------------------------
  * SURVEY.md 8b's `device_ids / n_devices / partitioned`: shard s is a granne_hip_index of its own

@@ -83,6 +83,12 @@ int gro_search_batch(const gro_index* ix, const void* queries, size_t nq, size_t
                      size_t num_neighbors, uint64_t* out_ids, float* out_dists,
                      uint32_t* out_counts, gro_counters* ctr, int n_threads);
 
+/* bench.py's CPU-baseline clock: one untimed pass, then `repeats` timed passes over the same batch inside one
+ * parallel region (threads and their scratch stay warm). Returns wall seconds of the timed passes, < 0 on panic. */
+double gro_search_batch_timed(const gro_index* ix, const void* queries, size_t nq, size_t max_search,
+                              size_t num_neighbors, uint64_t* out_ids, float* out_dists,
+                              uint32_t* out_counts, int n_threads, int repeats);
+
 /* ---- build half, src/index/mod.rs:364-402, 645-960 ------------------------------------- */
 typedef struct {
     float layer_multiplier;     /* 15.0 */

@@ -85,6 +85,9 @@ def lib():
         L.gro_search_batch.restype = C.c_int
         L.gro_search_batch.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.gro_search_batch_timed.restype = C.c_double
+        L.gro_search_batch_timed.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.gro_build_config_default.restype = None
         L.gro_build_config_default.argtypes = [C.POINTER(_BuildConfig)]
         L.gro_builder_create.restype = C.c_void_p
@@ -253,6 +256,20 @@ class Index:
         if rc != 0:
             raise RuntimeError("max_search == 0 (reference panics, src/index/mod.rs:1019)")
         return ids, ds, cnt, ctr
+
+    def search_batch_timed(self, queries, max_search, num_neighbors, n_threads=0, repeats=1):
+        """bench.py's CPU baseline: one warm-up pass, then `repeats` timed passes over `queries` with the threads and
+        their scratch kept alive (gro_search_batch_timed). Returns (seconds of the timed passes, ids, dists, counts)."""
+        q = np.ascontiguousarray(queries, self.elements.dtype)
+        nq = q.shape[0]
+        ids = np.full((nq, num_neighbors), np.iinfo(np.uint64).max, np.uint64)
+        ds = np.full((nq, num_neighbors), np.inf, np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        sec = lib().gro_search_batch_timed(C.byref(self._c), _p(q), nq, max_search, num_neighbors, _p(ids), _p(ds),
+                                           _p(cnt), n_threads, repeats)
+        if sec < 0:
+            raise RuntimeError("max_search == 0 (reference panics, src/index/mod.rs:1019)")
+        return sec, ids, ds, cnt
 
     # ---- Granne::reorder (src/index/reorder.rs) -------------------------------------------------
     def compute_order(self, n_threads=0):

@@ -63,7 +63,8 @@ def _worker(rank, world, port, out_dir):
     def local_search(queries, max_search, k, out):  # CPU stand-in for the HIP searches: same packed outputs
         for i, ix in enumerate(local):
             ids, ds, cnt, _ = ix.search_batch(np.asarray(queries), max_search, k)
-            out[i].copy_(torch.from_numpy(pack_topk(ids, ds, cnt)))
+            packed = torch.from_numpy(pack_topk(ids, ds, cnt))
+            out[i][:packed.numel()].copy_(packed)  # (the shard's status words follow: zero)
 
     def merge(gathered, offsets, nq, k):
         parts = [unpack_topk(gathered[g].numpy(), nq, k) for g in range(gathered.shape[0])]
@@ -74,7 +75,32 @@ def _worker(rank, world, port, out_dir):
     sg = sharded.ShardedGranne([None] * LOCAL, [b[0] for b in bounds], local_search=local_search, merge=merge)
     ids, ds, cnt = sg.search_batch(q, 20, 5)
     assert calls["all_gather"] == 1, "the exchange is ONE collective per batch"
-    assert sg.exchange_bytes_per_rank(len(q), 5) == LOCAL * ((len(q) * 5 * 12 + len(q) * 4 + 15) & ~15)
+    assert sg.exchange_bytes_per_rank(len(q), 5) == LOCAL * (((len(q) * 5 * 12 + len(q) * 4 + 15) & ~15) + 16)
+    # pipelined: five batches, two in flight; still one collective per batch, same results as one at a time
+    batches = [q[:8], q[8:16], q[16:], q[4:12], q]
+    calls["all_gather"] = 0
+    piped = sg.search_batches(batches, 20, 5, depth=2)
+    assert calls["all_gather"] == len(batches)
+    for b, (pi, pd, pc) in zip(batches, piped):
+        si, sd, sc = sg.search_batch(b, 20, 5)
+        assert (pi == si).all() and pd.numpy().tobytes() == sd.numpy().tobytes() and (pc == sc).all()
+    # a shard that reports exhausted scratch is seen by EVERY rank (its status words ride in the all-gather)
+    if True:
+        real_ls = sg._local_search
+
+        def failing(queries, max_search, k, out):
+            real_ls(queries, max_search, k, out)
+            if rank == 1:
+                out[0][sharded.packed_bytes(len(queries), k)] = 1  # shard 2 of the job: status word 0
+        sg._local_search = failing
+        from granne_amd._lib import GranneHipError
+        try:
+            sg.search_batch(q, 20, 5)
+            raised = False
+        except GranneHipError:
+            raised = True
+        assert raised, "rank %d did not see the other rank's exhausted shard" % rank
+        sg._local_search = real_ls
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ids=ids.numpy(), ds=ds.numpy(), cnt=cnt.numpy(),
              offsets=np.array(sg.offsets))
     # replica mode: disjoint query rows, all rows covered
