@@ -14,6 +14,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OVERFLOW, ERR_IO = -1, -2, -3, -4, -5
 
 OPT_VISITED_SLOTS, OPT_FORCE_SLOW, OPT_SLOW_SLOTS, OPT_SLOW_BLOCKS, OPT_OVERFLOW_SLOTS = 1, 2, 3, 4, 5
+OPT_VISITED16, OPT_VISITED16_LG = 6, 7
 
 
 class GranneHipError(RuntimeError):

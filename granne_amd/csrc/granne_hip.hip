@@ -112,6 +112,8 @@ struct granne_hip_index {
     uint64_t opt_slow_slots = 1u << 18;
     uint64_t opt_slow_blocks = 16;
     uint64_t opt_overflow_slots = 0; // 0 auto, 1 off, else slots per overflow table
+    uint64_t opt_visited16 = 0;      // 0 auto, 1 off
+    uint64_t opt_visited16_lg = 0;   // 0 auto, else log2(buckets)
     std::atomic<uint64_t> last_slow_count{0};
     // host-pointer searches (granne_hip_search / _search_batch): a stream, a device buffer and a pinned
     // staging buffer per concurrent caller, kept for the life of the index -- the reference's API is one
@@ -463,6 +465,15 @@ extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uin
             return fail(GRANNE_HIP_ERR_INVALID, "overflow slots must be 0 (auto), 1 (off) or a power of two in [512, 2^20]");
         ix->opt_overflow_slots = value;
         return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_VISITED16:
+        if (value > 1) return fail(GRANNE_HIP_ERR_INVALID, "visited16 must be 0 (auto) or 1 (off)");
+        ix->opt_visited16 = value;
+        return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_VISITED16_LG:
+        if (value != 0 && (value < V16_MIN_LG || value > 12))
+            return fail(GRANNE_HIP_ERR_INVALID, "visited16 log2(buckets) must be 0 (auto) or in [6, 12]");
+        ix->opt_visited16_lg = value;
+        return GRANNE_HIP_OK;
     default:
         return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
     }
@@ -476,6 +487,8 @@ extern "C" int granne_hip_index_get_option(const granne_hip_index* ix, int optio
     case GRANNE_HIP_OPT_SLOW_SLOTS: *value = ix->opt_slow_slots; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_SLOW_BLOCKS: *value = ix->opt_slow_blocks; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_OVERFLOW_SLOTS: *value = ix->opt_overflow_slots; return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_VISITED16: *value = ix->opt_visited16; return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_VISITED16_LG: *value = ix->opt_visited16_lg; return GRANNE_HIP_OK;
     default: return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -499,6 +512,7 @@ struct SearchTarget {
     uint32_t n_layers;
     uint32_t max_dev_width;
     uint64_t opt_visited_slots, opt_force_slow, opt_slow_slots, opt_slow_blocks, opt_overflow_slots;
+    uint64_t opt_visited16 = 0, opt_visited16_lg = 0;
     ScratchCache* scratch; // search_launch's per-stream scratch blocks
 };
 
@@ -518,6 +532,8 @@ static SearchTarget target_of(const granne_hip_index* ix) {
     T.opt_slow_slots = ix->opt_slow_slots;
     T.opt_slow_blocks = ix->opt_slow_blocks;
     T.opt_overflow_slots = ix->opt_overflow_slots;
+    T.opt_visited16 = ix->opt_visited16;
+    T.opt_visited16_lg = ix->opt_visited16_lg;
     T.scratch = &const_cast<granne_hip_index*>(ix)->scratch;
     return T;
 }
@@ -595,7 +611,7 @@ static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail
 
 struct LaunchPlan {
     uint32_t visited_slots, upper_slots, maxc, lrow_bytes, stage_bytes, adjspec_bytes, lds_bytes;
-    bool v16;
+    bool v16; // the 16-bit two-choice visited table (VisitedSet16)
 };
 
 // LDS plan. The visited table dominates; the f32 stage gets what keeps four walkers per CU
@@ -610,7 +626,8 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
     // and ~5.8 * nb ids before the first one spills (two-choice, 8 entries per bucket). A walk visits ~40 x
     // max_search nodes on 10M uniform points: nb = 8 * max_search rounded up to a power of two -- 512 buckets =
     // 8 KB at max_search 50 (the 32-bit table: 16 KB), so twice the walkers fit a CU's LDS.
-    if (fastS >= 1 && fastS <= 4 && !trail && knobs().v16 && !ix->opt_visited_slots) {
+    // Id spaces beyond the tags (32767 ids per bucket: 125M ids would need 64 KB) keep the 32-bit table.
+    if (fastS >= 1 && fastS <= 4 && !trail && knobs().v16 && !ix->opt_visited_slots && ix->opt_visited16 != 1) {
         const uint32_t lg_ids = v16_lg_for_ids(ix->n_elements);
         uint32_t lg = V16_MIN_LG;
         while ((1u << lg) < ef * 8u) ++lg;
@@ -618,11 +635,12 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         const uint32_t lg_cap = nq >= 2048 ? 10u : 11u;
         if (lg > lg_cap) lg = lg_cap;
         if (knobs().v16_lg) lg = (uint32_t)knobs().v16_lg;
+        if (ix->opt_visited16_lg) lg = (uint32_t)ix->opt_visited16_lg;
         if (lg < lg_ids) lg = lg_ids;
-        if (lg <= 11) {
+        if (lg <= lg_cap || ((knobs().v16_lg || ix->opt_visited16_lg) && lg <= 12)) {
             P.v16 = true;
             P.visited_slots = lg;
-            P.upper_slots = lg_ids < lg ? lg_ids : lg; // upper layers: the smallest table whose tags hold the ids
+            P.upper_slots = lg_ids; // upper layers: the smallest table whose tags hold the ids (<= lg)
             P.maxc = 0;
             P.lrow_bytes = 16;
             P.stage_bytes = 0;
@@ -773,7 +791,8 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     const size_t list_bytes = ((size_t)nq * 4 + 15) & ~(size_t)15;
     size_t off_list = SCRATCH_FIXED;
     size_t off_ovf = off_list + list_bytes;
-    size_t off_vis = off_ovf + (size_t)ovf_regions * ovf_slots * 4;
+    const uint32_t ovf_stride = ovf_slots;
+    size_t off_vis = off_ovf + (size_t)ovf_regions * ovf_stride * 4;
     size_t off_pq = off_vis + (size_t)slow_blocks * slots * 4;
     size_t off_res = off_pq + (size_t)slow_blocks * slots * 8;
     size_t total = off_res + (size_t)slow_blocks * ef * 8;
@@ -821,6 +840,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.ovf.tables = (uint32_t*)(scratch + off_ovf);
     p.ovf.state = (uint32_t*)(scratch + SCRATCH_STATE_OFF);
     p.ovf.slots = ovf_slots;
+    p.ovf.stride = ovf_stride;
     p.ovf.regions = ovf_regions;
     p.ovf.spilled = d_status ? d_status + 2 : ctl + CTL_SPILLED;
     p.trail_out = d_trail;

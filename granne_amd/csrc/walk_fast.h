@@ -258,8 +258,8 @@ __host__ __device__ inline uint32_t fast_query_bytes(bool i8, bool gen, uint32_t
     return ngroups * GEN_GROUP * 128u + 128u;
 }
 
-// V16: the visited set's front table holds 16-bit entries in two-choice buckets (VisitedSet16, wave_prims.h) --
-// half the LDS of the 32-bit table for id spaces of up to 32767 ids per bucket; the host picks it when the ids fit.
+// V16: the visited set's front table holds 16-bit entries in two-choice buckets (VisitedSet16, wave_prims.h) -- half
+// the LDS of the 32-bit table, for id spaces of up to 32767 ids per bucket; the host picks it when the ids fit.
 template <int DT, int DIM, int S, bool V16 = false>
 struct FastWalker {
     static constexpr bool F32 = (DT == DT_F32);

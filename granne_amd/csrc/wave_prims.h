@@ -139,9 +139,10 @@ struct SortedList {
 // the walk continues where it is, nothing is recomputed. The set stays exact: an id is in the set
 // iff it is in one of the two tables.
 struct OverflowPool {
-    uint32_t* tables;  // [regions][slots] u32, global
-    uint32_t* state;   // [regions] 0 = free, 1 = taken (zeroed per launch)
-    uint32_t slots;    // per region, power of two; 0 = no overflow: a full front table bails
+    uint32_t* tables;  // [regions][stride] u32, global: a region = [overflow table: slots][id mirror: stride - slots]
+    uint32_t* state;   // [regions] 0 = free, 1 = taken (all zero between launches: every walker gives its region back)
+    uint32_t slots;    // overflow table of a region, power of two; 0 = no overflow: a full front table bails
+    uint32_t stride;   // u32 words per region (>= slots)
     uint32_t regions;
     uint32_t* spilled; // optional statistics: += 1 per walk that spilled
 };
@@ -237,7 +238,7 @@ struct VisitedSet {
                 }
             }
             if (absent) {
-                uint32_t* otab = pool.tables + (size_t)region * pool.slots;
+                uint32_t* otab = pool.tables + (size_t)region * pool.stride;
                 const uint32_t omask = pool.slots - 1; // the overflow tables are powers of two
                 const uint32_t ost = step(id);         // odd
                 uint32_t slot = (hash(id) >> 3) & omask;
@@ -276,7 +277,7 @@ struct VisitedSet {
             if (region == NONE) return false;
         }
         uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
-        uint4* t4 = reinterpret_cast<uint4*>(pool.tables + (size_t)region * pool.slots);
+        uint4* t4 = reinterpret_cast<uint4*>(pool.tables + (size_t)region * pool.stride);
         for (uint32_t i = lane; i < (pool.slots >> 2); i += 64) t4[i] = e;
         __threadfence(); // the wipe is complete before any lane's atomicCAS on the table
         ocount = 0;
@@ -308,6 +309,13 @@ struct VisitedSet {
 // of its buckets full goes to the walk's overflow table in global memory, exactly as with the 32-bit table, and is
 // looked up there by every later pair that finds both of its buckets full. Buckets never lose entries, so an id is
 // in the set iff it is in b1, in b2, or (both full) in the overflow table.
+//
+// Id spaces beyond 32767 * nb (125M ids would need 4096 buckets = 64 KB) keep the 32-bit table. Measured and dropped
+// (round 3): 15-bit tags as a filter with the entries' full ids mirrored in the walk's global region and read back on a
+// tag match. 97 % of a walk's lookups find no matching tag and never leave LDS, but every insert then costs a scattered
+// 4-byte store (a read-modify-write at the memory side: as many transactions as the int8 row gather itself) whose
+// acknowledgement every later vmcnt wait also waits for: 0.28 ms per launch against 0.185 ms with the 32-bit table on
+// 40M int8 rows at max_search 50, no better than it at max_search 200.
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
     uint32_t r;
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -322,6 +330,13 @@ __device__ __forceinline__ uint32_t pk_min1_u16(uint32_t a) { // min(each half, 
     uint32_t r;
     asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
     return r;
+}
+// The lane id, computed where it is used. (Table wipes run once per layer; the compiler otherwise keeps their loop
+// counters -- lane, lane + 64 -- alive through the whole walk, and under the f32 walkers' register pressure spills them.)
+__device__ __forceinline__ uint32_t lane_id_here() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
+    return l;
 }
 __device__ __forceinline__ uint32_t dpp_pair_swap(uint32_t v) { // the other lane of the pair (lane ^ 1)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
@@ -350,29 +365,77 @@ struct VisitedSet16 {
         region = NONE;
         ocount = 0;
     }
+    __device__ __forceinline__ uint32_t acquire(const OverflowPool& pool, uint32_t lane) {
+        uint32_t got = NONE;
+        if (pool.slots != 0 && lane == 0) {
+            uint32_t r = (blockIdx.x * 0x9E3779B1u) % pool.regions;
+            for (uint32_t tries = 0; tries < pool.regions; ++tries) {
+                if (atomicCAS(&pool.state[r], 0u, 1u) == 0u) { got = r; break; }
+                r = (r + 1 == pool.regions) ? 0u : r + 1;
+            }
+        }
+        return (uint32_t)__shfl((int)got, 0, 64);
+    }
     __device__ __forceinline__ void reset(uint32_t* lds, uint32_t lg_, uint32_t lane) {
         tab = lds;
         lg = lg_;
         count = 0;
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         uint4* t4 = reinterpret_cast<uint4*>(lds);
-        for (uint32_t i = lane; i < (1u << lg_); i += 64) t4[i] = z;
+        (void)lane;
+        for (uint32_t i = lane_id_here(); i < (1u << lg_); i += 64) t4[i] = z;
         if (region != NONE && ocount != 0) ocount = NONE; // a borrowed region is wiped before it is used again
     }
     __device__ __forceinline__ void added(uint32_t) {}
+
+    // One probe of the pair's two buckets, written without branches (bit operations and selects; only the claim itself
+    // runs under a mask): every lane executes it, lanes without `pending` change nothing. A lane with `pending` looks the
+    // id up and, when it is absent and a bucket has room, claims the bucket's first free entry. Outcome per pair (the
+    // same in both of its lanes):
+    //   fresh     the id was inserted (it was not in the set)
+    //   both_full it is in neither bucket and both are full: the overflow table decides
+    // `pending` stays set for a pair that lost its entry to another pair of the same expansion; it goes round again (and
+    // finds the id present if that other pair held the same id: a row that lists a neighbor twice).
+    __device__ __forceinline__ void probe(uint32_t h, uint4* slot4, uint32_t entry, bool& pending, bool& fresh, bool& both_full) {
+        const uint4 w = *slot4;
+        const uint32_t pat = entry | (entry << 16);
+        const uint32_t m = pk_min_u16(pk_min_u16(w.x ^ pat, w.y ^ pat), pk_min_u16(w.z ^ pat, w.w ^ pat));
+        const uint32_t match = (uint32_t)((m & 0xFFFFu) == 0u) | (uint32_t)(m < 0x10000u);
+        const uint32_t c2 = pk_add_u16(pk_add_u16(pk_min1_u16(w.x), pk_min1_u16(w.y)),
+                                       pk_add_u16(pk_min1_u16(w.z), pk_min1_u16(w.w)));
+        const uint32_t cnt = (c2 & 0xFFFFu) + (c2 >> 16);
+        // one exchange: fill count in the low bits, "the tag is here" above them
+        const uint32_t other = dpp_pair_swap(cnt | (match << 8));
+        const uint32_t cnt_o = other & 0xFFu;
+        const bool present = (match | (other >> 8)) != 0u; // the tag names the id: it is in the set
+        const bool full2 = (cnt >= 8u) & (cnt_o >= 8u);
+        // this lane's bucket is the emptier one (ties: b1): it claims the bucket's first free entry
+        const bool mine_emptier = h ? (cnt < cnt_o) : (cnt <= cnt_o);
+        const bool claim = pending & !present & !full2 & mine_emptier;
+        const uint32_t wi = cnt >> 1;
+        const uint32_t old = wi == 0u ? w.x : wi == 1u ? w.y : wi == 2u ? w.z : w.w;
+        uint32_t ok = 0u;
+        if (claim) {
+            const uint32_t got = atomicCAS(reinterpret_cast<uint32_t*>(slot4) + (wi & 3u), old, old | (entry << ((cnt & 1u) * 16u)));
+            ok = got == old ? 1u : 0u;
+        }
+        const bool okp = (ok | dpp_pair_swap(ok)) != 0u;
+        fresh = fresh | (pending & okp);
+        both_full = both_full | (pending & !present & full2);
+        pending = pending & !present & !full2 & !okp;
+    }
 
     // HashSet::insert for the id both lanes of a pair hold (h = lane & 1). `active` is the same in both lanes.
     // Returns true in BOTH lanes iff the id was not present.
     __device__ __forceinline__ bool insert(uint32_t id, bool active, uint32_t h, const OverflowPool& pool, uint32_t lane,
                                            bool& bail) {
-        const uint32_t mask = (1u << lg) - 1u;
-        const uint32_t q = id >> lg;
         const uint32_t sh = 32u - lg;
-        const uint32_t b1 = (id ^ ((q * 0x9E3779B1u) >> sh)) & mask;
-        const uint32_t g = ((q * 0x85EBCA6Bu) >> sh) | 1u;
-        const uint32_t mine = h ? (b1 ^ g) : b1;
-        const uint32_t entry = (q + 1u) | (h << 15);
-        const uint32_t pat = entry | (entry << 16);
+        const uint32_t q = id >> lg;
+        const uint32_t b1 = (id ^ ((q * 0x9E3779B1u) >> sh)) & ((1u << lg) - 1u);
+        const uint32_t mine = h ? (b1 ^ (((q * 0x85EBCA6Bu) >> sh) | 1u)) : b1;
+        // tag: 15 bits of q, never 0. While q < 32767 (exact mode: the host sizes the table for it) it names q exactly
+        const uint32_t t15 = (q ^ (q >> 15)) & 0x7FFFu;
+        const uint32_t entry = (t15 ? t15 : 0x7FFFu) | (h << 15);
         uint4* slot4 = reinterpret_cast<uint4*>(tab) + mine;
         bool pending = active, fresh = false, both_full = false;
 #if GRANNE_HIP_PHASE_TIMERS
@@ -382,64 +445,26 @@ struct VisitedSet16 {
 #if GRANNE_HIP_PHASE_TIMERS
             r_ += 1;
 #endif
-            if (pending) {
-                const uint4 w = *slot4;
-                const uint32_t m = pk_min_u16(pk_min_u16(w.x ^ pat, w.y ^ pat), pk_min_u16(w.z ^ pat, w.w ^ pat));
-                const uint32_t found_mine = (((m & 0xFFFFu) == 0u) || (m < 0x10000u)) ? 1u : 0u;
-                const uint32_t c2 = pk_add_u16(pk_add_u16(pk_min1_u16(w.x), pk_min1_u16(w.y)),
-                                               pk_add_u16(pk_min1_u16(w.z), pk_min1_u16(w.w)));
-                const uint32_t cnt = (c2 & 0xFFFFu) + (c2 >> 16);
-                // one exchange: fill count in the low bits, "present here" above them
-                const uint32_t other = dpp_pair_swap(cnt | (found_mine << 8));
-                const uint32_t cnt_o = other & 0xFFu;
-                if (found_mine | (other >> 8)) {
-                    pending = false; // already in the set
-                } else if (cnt >= 8u && cnt_o >= 8u) {
-                    pending = false; // both buckets full: the overflow table decides
-                    both_full = true;
-                } else {
-                    const bool claim = h ? (cnt < cnt_o) : (cnt <= cnt_o); // the emptier bucket, ties to b1
-                    uint32_t ok = 0u;
-                    if (claim) {
-                        const uint32_t wi = cnt >> 1;
-                        const uint32_t old = wi == 0u ? w.x : wi == 1u ? w.y : wi == 2u ? w.z : w.w;
-                        const uint32_t neww = old | (entry << ((cnt & 1u) * 16u));
-                        const uint32_t got = atomicCAS(reinterpret_cast<uint32_t*>(slot4) + wi, old, neww);
-                        ok = got == old ? 1u : 0u;
-                    }
-                    if (ok | dpp_pair_swap(ok)) {
-                        pending = false;
-                        fresh = true;
-                    }
-                }
-            }
+            probe(h, slot4, entry, pending, fresh, both_full);
         }
 #if GRANNE_HIP_PHASE_TIMERS
         pt_rounds += r_;
 #endif
         if (wave_ballot(both_full)) { // rare: the walk outgrew its table's two-choice capacity
             if (region == NONE) {
-                uint32_t got = NONE;
-                if (pool.slots != 0 && lane == 0) {
-                    uint32_t r = (blockIdx.x * 0x9E3779B1u) % pool.regions;
-                    for (uint32_t tries = 0; tries < pool.regions; ++tries) {
-                        if (atomicCAS(&pool.state[r], 0u, 1u) == 0u) { got = r; break; }
-                        r = (r + 1 == pool.regions) ? 0u : r + 1;
-                    }
-                    if (got != NONE && pool.spilled) atomicAdd(pool.spilled, 1u);
-                }
-                region = (uint32_t)__shfl((int)got, 0, 64);
+                region = acquire(pool, lane);
                 ocount = NONE;
             }
             if (region == NONE) {
                 bail = true; // no overflow configured or none left: the exact global-memory walker takes the query
                 return false;
             }
-            uint32_t* otab = pool.tables + (size_t)region * pool.slots;
+            uint32_t* otab = pool.tables + (size_t)region * pool.stride;
             if (ocount == NONE) { // first use (in this layer): wipe
+                if (lane == 0 && pool.spilled) atomicAdd(pool.spilled, 1u);
                 const uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
                 uint4* t4 = reinterpret_cast<uint4*>(otab);
-                for (uint32_t i = lane; i < (pool.slots >> 2); i += 64) t4[i] = e;
+                for (uint32_t i = lane_id_here(); i < (pool.slots >> 2); i += 64) t4[i] = e;
                 __threadfence();
                 ocount = 0;
             }

@@ -344,8 +344,13 @@ enum {
     GRANNE_HIP_OPT_FORCE_SLOW = 2,    /* 1: route every query through the exact global-memory path */
     GRANNE_HIP_OPT_SLOW_SLOTS = 3,    /* global visited/queue slots per slow-path query (pow2)      */
     GRANNE_HIP_OPT_SLOW_BLOCKS = 4,   /* concurrent slow-path walkers                               */
-    GRANNE_HIP_OPT_OVERFLOW_SLOTS = 5 /* global overflow slots per walk for a full LDS visited table:
+    GRANNE_HIP_OPT_OVERFLOW_SLOTS = 5,/* global overflow slots per walk for a full LDS visited table:
                                          0 = auto, 1 = off (such walks go to the slow path), else pow2 */
+    GRANNE_HIP_OPT_VISITED16 = 6,     /* the register walkers' 16-bit two-choice visited table (half the LDS of the
+                                         32-bit one; exact by its tags): 0 = auto (used for max_search <= 252 when the
+                                         index's ids fit the tags -- 32767 ids per bucket -- and VISITED_SLOTS is not
+                                         set), 1 = off */
+    GRANNE_HIP_OPT_VISITED16_LG = 7   /* log2 of its bucket count (a bucket = 8 entries = 16 bytes): 0 = auto, else 6..12 */
 };
 int granne_hip_index_set_option(granne_hip_index* index, int option, uint64_t value);
 int granne_hip_index_get_option(const granne_hip_index* index, int option, uint64_t* value);

@@ -376,6 +376,58 @@ def test_visited_set_spills_to_global_overflow(ga, oracle, int8, ef, lds_slots, 
     assert (ids.cpu().numpy().astype(np.uint64) == want[0]).all()
 
 
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("mode,lg,ovf", [(0, 0, 0), (1, 0, 0), (0, 6, 0), (0, 7, 2048), (0, 6, 1), (0, 12, 0)])
+def test_visited16_modes(ga, oracle, int8, mode, lg, ovf):
+    """The register walkers' 16-bit two-choice visited table (wave_prims.h VisitedSet16): on (auto), off (the 32-bit
+    table), with tables so small (64 buckets = 512 entries) that most ids of a max_search-100 walk find both buckets
+    full and go to the global overflow table, and with the overflow pool off (such walks are handed to the exact
+    walker). Same ids, distance bits and counters in every mode."""
+    from granne_amd import _lib
+    rng = np.random.default_rng(160 + 3 * mode + lg + int8)
+    el = prep(oracle, random_floats(rng, 6000, 100), int8)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
+    gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 128, 100), int8)
+    gix.set_option(_lib.OPT_VISITED16, mode)
+    gix.set_option(_lib.OPT_VISITED16_LG, lg)
+    gix.set_option(_lib.OPT_OVERFLOW_SLOTS, ovf)
+    for ef, k in [(1, 1), (50, 10), (100, 10), (200, 10), (250, 30)]:
+        assert_same(oix, gix, q, ef, k)
+        slow = gix.last_slow_count()
+        if ovf == 0:
+            assert slow == 0, (ef, slow)  # (a 2048-slot overflow table fills up at max_search 200: handed over)
+        elif lg == 6 and ef >= 100 and mode == 0:
+            assert slow > 0  # no overflow table to spill to: handed over, still the same results
+    # members as queries, duplicates of one query in a batch, a batch of one
+    assert_same(oix, gix, el[:64], 30, 5)
+    assert_same(oix, gix, np.repeat(q[:1], 5, axis=0), 60, 10)
+    assert_same(oix, gix, q[:1], 60, 10)
+
+
+def test_visited16_duplicate_neighbor_ids_in_a_row(ga, oracle):
+    """A row that lists the same neighbor twice: the reference's HashSet::insert is false the second time
+    (src/index/mod.rs:1026); the pair of lanes that comes second must see the first pair's entry."""
+    from granne_amd import _lib
+    rng = np.random.default_rng(77)
+    el = prep(oracle, random_floats(rng, 3000, 100), False)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
+    layers = [l.copy() for l in oix.layers]
+    bottom = layers[-1]
+    for r in range(0, len(bottom), 3):  # duplicate the first neighbor into the last used place (or the next free one)
+        row = bottom[r]
+        used = int((row != 0xFFFFFFFF).sum())
+        if used >= 2:
+            row[min(used, len(row) - 1)] = row[0]
+    dup = oracle.Index(el, layers)
+    q = prep(oracle, random_floats(rng, 64, 100), False)
+    for mode in (0, 1):
+        gix = ga.Granne("angular", el, layers)
+        gix.set_option(_lib.OPT_VISITED16, mode)
+        assert_same(dup, gix, q, 50, 10)
+        assert_same(dup, gix, q, 150, 10)
+
+
 def test_slow_scratch_exhaustion_is_reported(ga, oracle):
     from granne_amd import _lib
     rng = np.random.default_rng(15)
