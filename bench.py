@@ -365,25 +365,42 @@ class Bench:
         return r
 
     # ---- ground truth / recall -----------------------------------------------------------------------
-    def ground_truth(self, elements, q0, k, dtype):
+    def ground_truth(self, index, q0, k, dtype, timing=None, n=None):
+        """exact k nearest elements by the library's scan on the matrix cores (granne_hip_brute_force_device,
+        granne_amd/csrc/brute_force.h): ids [nq, k]. `timing`: a dict that receives the scan's rate."""
         torch = self.torch
-        n = elements.shape[0]
         nq = q0.shape[0]
-        q0 = q0.float()
-        best_v = torch.full((nq, k), -3.0e38, device="cuda")
-        best_i = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
-        chunk = 1_000_000
-        for c0 in range(0, n, chunk):
-            e = elements[c0:c0 + chunk].float()
-            if dtype == "i8":  # cosine on the quantised rows
-                e = e / e.norm(dim=1, keepdim=True).clamp_min(1e-30)
-            sim = q0 @ e.T
-            v, i = sim.topk(k, dim=1)
-            cat_v = torch.cat([best_v, v], 1)
-            cat_i = torch.cat([best_i, i + c0], 1)
-            best_v, sel = cat_v.topk(k, dim=1)
-            best_i = cat_i.gather(1, sel)
-        return best_i.cpu().numpy()
+        ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        ds = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        cnt = torch.empty(nq, dtype=torch.int32, device="cuda")
+        q0 = q0.contiguous()
+
+        def run():
+            index.brute_force_device(q0.data_ptr(), nq, k, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), self.stream)
+        run()
+        torch.cuda.synchronize()
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            n, dim = (n or len(index)), index.dim
+            if dtype == "f32":
+                flops = 2.0 * nq * n * dim
+                timing.update({"kernel": "bf_f32_kernel (v_mfma_f32_32x32x2_f32) + merge + exact re-ranking", "ms": round(ms, 3),
+                               "bound": "mfma", "achieved": round(flops / ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s",
+                               "frac": round(flops / ms / 1e9 / 157.3, 4), "queries": nq, "elements": n, "dim": dim,
+                               "note": "2 * nq * n * dim flops / wall of the whole operator (HIP events); peak = dense f32 MFMA"})
+            else:
+                tiles = (nq + 255) // 256
+                byts = float(tiles) * n * 128
+                timing.update({"kernel": "bf_i8_kernel (v_mfma_i32_32x32x16_i8) + merge + exact re-ranking", "ms": round(ms, 3),
+                               "bound": "hbm", "achieved": round(byts / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(byts / ms / 1e6 / HBM_PEAK_GBPS, 4), "queries": nq, "elements": n, "dim": dim,
+                               "note": "every tile of 256 queries streams the n 128-byte rows once: %d passes" % tiles})
+        return ids.cpu().numpy()
 
     @staticmethod
     def recall(gt, got, k):
@@ -615,7 +632,9 @@ def run_replica(B, args):
         b0 = args.warmup
         gt = None
         if not args.no_recall:
-            gt = B.ground_truth(elements, queries[b0 * nq:(b0 + 1) * nq], k, args.dtype)
+            bf = {}
+            gt = B.ground_truth(index, queries[b0 * nq:(b0 + 1) * nq], k, args.dtype, timing=bf)
+            out["brute_force"] = bf
             got = m["ids"][b0]
             if order is not None:  # ground truth is in build ids, results in reordered ids
                 got = torch.from_numpy(order.astype(np.int64)).cuda()[got.clamp_min(0)]
@@ -664,12 +683,13 @@ def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=
     queries = B.rows(data, SEED + 1, 0, (warmup + steps) * nq, dim, dtype)
     builder, index, t_build = B.build_index(elements, dtype)
     rq = min(nq, recall_queries or nq)
-    gt = B.ground_truth(elements, queries[warmup * nq:warmup * nq + rq], k, dtype)
+    bf = {}
+    gt = B.ground_truth(index, queries[warmup * nq:warmup * nq + rq], k, dtype, timing=bf)
     inflight = auto_inflight(args, dtype)
     layer_sizes = [builder.layer_len(l) for l in range(builder.num_layers())]
     rec = {"workload": workload_label(n, dim, dtype, data, nq, ef, k), "dtype": dtype, "data": "synthetic",
            "n_elements": n, "dim": dim, "layers": layer_sizes, "build_s": round(t_build, 1),
-           "index_hbm_gb": round(index.hbm_bytes() / 1e9, 2)}
+           "index_hbm_gb": round(index.hbm_bytes() / 1e9, 2), "brute_force": bf}
     if find_ef:
         sweep = B.ef_sweep(index, queries, gt, nq, k, [20, 30, 50, 70, 100, 140, 200, 300, 400, 600, 800], steps, warmup,
                            inflight, stop_at=0.95)
@@ -807,7 +827,7 @@ def partitioned_record(B, args, n, dim, dtype, nq, ef, k, steps, warmup, spg, se
         q0 = queries[b0 * nq:(b0 + 1) * nq]
         loc_v, loc_i = [], []
         for j, g in enumerate(mine):
-            gt = torch.from_numpy(B.ground_truth(elements[j], q0, k, dtype)).cuda()
+            gt = torch.from_numpy(B.ground_truth(indexes[j], q0, k, dtype)).cuda()
             e = elements[j].float()
             if dtype == "i8":
                 e = e / e.norm(dim=1, keepdim=True).clamp_min(1e-30)

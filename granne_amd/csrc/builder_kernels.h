@@ -325,6 +325,11 @@ struct RowWork {
     // Only the distances node<->entries (the reference's elements.dists, :938) and x<->entries are evaluated:
     // 2c row products instead of c + (c+1)c/2, the same values the full pass would compare. Returns the new
     // count, or 0xFFFFFFFF when the row is not sorted after all (the caller takes the full pass).
+    // Invariant this rests on: a distance is a pure function of its two rows whichever kernel evaluates it -- the
+    // walker that proposed an earlier extra (walk_fast.h / search_kernel.h) and dist_lds here produce the same bits
+    // (dist.h: one operation order for all of them). Held by tests/test_gpu_builder.py: every GPU build must equal,
+    // row for row, the oracle's build, which runs the reference's FULL add_and_limit_neighbors every time -- for the
+    // unrolled f32 dims, the streamed run-time dims, tiny dims and int8.
     __device__ __forceinline__ uint32_t add_one_to_selected(uint32_t c, uint32_t ex_id, float ex_d, uint32_t num_neighbors) {
         uint32_t id = ID_EMPTY;
         if (lane < c) id = L.cur[lane];

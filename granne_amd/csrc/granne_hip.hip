@@ -16,6 +16,7 @@
 #include "walk_fast.h"
 #include "slow_kernel.h"
 #include "util_kernels.h"
+#include "brute_force.h"
 
 using namespace granne_hip;
 
@@ -985,10 +986,13 @@ extern "C" int granne_hip_search_batch(const granne_hip_index* cix, const void* 
 
     granne_hip_index::HostCall* c = host_call_acquire(ix);
     if (!c) return fail(GRANNE_HIP_ERR_HIP, "cannot create a stream");
-    struct Release {
-        granne_hip_index* ix;
+    struct Release { // the context goes back to the pool only once its stream is idle: on an error return kernels and
+        granne_hip_index* ix; // copies of this call may still be running on it, reading and writing the caller's buffers
         granne_hip_index::HostCall* c;
-        ~Release() { host_call_release(ix, c); }
+        ~Release() {
+            (void)hipStreamSynchronize(c->stream);
+            host_call_release(ix, c);
+        }
     } release{ix, c};
     if (staged && c->h_cap < total) {
         if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -1127,6 +1131,99 @@ extern "C" int granne_hip_dists_device(const granne_hip_index* ix, const void* d
                                        void* stream) {
     if (nq && m == 0) return GRANNE_HIP_OK;
     return dists_launch(ix, d_queries, nullptr, m ? m : 1, d_ids, (uint64_t)nq * m, d_out, d_status, stream);
+}
+
+static int merge_launch(const uint8_t* ids, const uint8_t* dists, const uint8_t* counts, uint64_t ids_stride,
+                        uint64_t dists_stride, uint64_t counts_stride, const uint64_t* shard_offsets, uint32_t n_shards,
+                        uint32_t nq, uint32_t k, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                        int device_id, void* stream);
+
+// exact k nearest elements by a scan of all of them on the matrix cores (brute_force.h)
+extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const void* d_queries, uint32_t nq, uint32_t k,
+                                             uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, void* stream) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (nq == 0) return GRANNE_HIP_OK;
+    if (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (k == 0 || k > BF_KMAX) return fail(GRANNE_HIP_ERR_INVALID, "k must be in [1, %u]", BF_KMAX);
+    if (ix->dtype == GRANNE_HIP_F32 && ix->dim > 256) return fail(GRANNE_HIP_ERR_INVALID, "the scan takes f32 rows of up to 256 dimensions");
+    if (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes > 128) return fail(GRANNE_HIP_ERR_INVALID, "the scan takes int8 rows of up to 128 dimensions");
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t n = ix->n_elements;
+    const uint32_t kk = k + BF_EXTRA < BF_KMAX ? k + BF_EXTRA : BF_KMAX;
+    // element ranges: the lists of up to 64 ranges are merged; a range is a whole number of tiles
+    uint32_t R = 4, lds = 0;
+    void (*fn)(const BruteParams) = nullptr;
+    if (ix->dtype == GRANNE_HIP_I8) {
+        R = 4;
+        fn = bf_i8_kernel<4>;
+        lds = 32u * R * (128u + 16u) + 32u * R * 4u;
+    } else if (ix->dim <= 104) {
+        R = 4;
+        fn = bf_f32_kernel<52, 4>;
+        lds = 32u * R * (2u * 52u + 4u) * 4u;
+    } else if (ix->dim <= 200) {
+        R = 2;
+        fn = bf_f32_kernel<100, 2>;
+        lds = 32u * R * (2u * 100u + 4u) * 4u;
+    } else {
+        R = 1;
+        fn = bf_f32_kernel<128, 1>;
+        lds = 32u * R * (2u * 128u + 4u) * 4u;
+    }
+    const uint64_t tile = 32ull * R;
+    uint64_t G = (n + tile - 1) / tile;
+    if (G > 64) G = 64;
+    if (G < 1) G = 1;
+    uint64_t per_range = (n + G - 1) / G;
+    per_range = (per_range + tile - 1) / tile * tile;
+    if (per_range < tile) per_range = tile;
+    const size_t lists = (size_t)G * nq;
+    const size_t o_pid = 0, o_pd = o_pid + lists * kk * 8, o_pc = o_pd + lists * kk * 4;
+    const size_t o_mid = (o_pc + lists * 4 + 15) & ~(size_t)15, o_md = o_mid + (size_t)nq * kk * 8, o_mc = o_md + (size_t)nq * kk * 4;
+    const size_t o_cand = (o_mc + (size_t)nq * 4 + 15) & ~(size_t)15, o_ex = o_cand + (size_t)nq * kk * 4;
+    const size_t total = o_ex + (size_t)nq * kk * 4;
+    uint8_t* scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
+    struct Release {
+        void* p;
+        hipStream_t s;
+        ~Release() { (void)hipFreeAsync(p, s); }
+    } release{scratch, s};
+    BruteParams P;
+    P.elements = ix->d_elements;
+    P.n = n;
+    P.row_bytes = ix->row_bytes;
+    P.dim = ix->dim;
+    P.queries = (const uint8_t*)d_queries;
+    P.nq = nq;
+    P.kk = kk;
+    P.per_range = per_range;
+    P.part_ids = (uint64_t*)(scratch + o_pid);
+    P.part_d = (float*)(scratch + o_pd);
+    P.part_c = (uint32_t*)(scratch + o_pc);
+    if (lds > 64u * 1024u) HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3((nq + BF_QT - 1) / BF_QT, (uint32_t)G), dim3(BF_THREADS), lds, s, P);
+    HIP_TRY(hipGetLastError());
+    uint64_t zeros[64];
+    memset(zeros, 0, sizeof(zeros)); // the lists hold global ids already
+    int rc = merge_launch((const uint8_t*)P.part_ids, (const uint8_t*)P.part_d, (const uint8_t*)P.part_c, (uint64_t)nq * kk * 8,
+                          (uint64_t)nq * kk * 4, (uint64_t)nq * 4, zeros, (uint32_t)G, nq, kk, (uint64_t*)(scratch + o_mid),
+                          (float*)(scratch + o_md), (uint32_t*)(scratch + o_mc), ix->device, stream);
+    if (rc) return rc;
+    // the candidates' distances in the reference's own arithmetic, then the k best by (distance, id)
+    const uint32_t pairs = nq * kk;
+    hipLaunchKernelGGL(bf_narrow_ids_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, (const uint64_t*)(scratch + o_mid),
+                       (const uint32_t*)(scratch + o_mc), nq, kk, (uint32_t*)(scratch + o_cand));
+    HIP_TRY(hipGetLastError());
+    rc = dists_launch(ix, d_queries, nullptr, kk, (const uint32_t*)(scratch + o_cand), (uint64_t)pairs, (float*)(scratch + o_ex),
+                      nullptr, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bf_final_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, (const uint32_t*)(scratch + o_cand),
+                       (const float*)(scratch + o_ex), nq, kk, k, d_out_ids, d_out_dists, d_out_counts);
+    HIP_TRY(hipGetLastError());
+    return GRANNE_HIP_OK;
 }
 
 extern "C" int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,

@@ -133,6 +133,20 @@ extern "C" int granne_hip_sharded_search_batch(granne_hip_sharded* sh, const voi
     const uint32_t G = (uint32_t)sh->shards.size();
     if ((uint64_t)G * num_neighbors > 4096) return fail(GRANNE_HIP_ERR_INVALID, "n_shards * num_neighbors must be <= 4096");
     std::lock_guard<std::mutex> lk(sh->mu);
+    // Whatever way this call ends, nothing it enqueued may still be running when it returns: the shard streams read the
+    // caller's `queries` and write buffers the next call may regrow (grow() frees), the merge stream writes the caller's
+    // outputs. On success everything has been waited for already and this costs nothing.
+    struct Quiesce {
+        granne_hip_sharded* sh;
+        ~Quiesce() {
+            for (auto& S : sh->shards) {
+                DeviceGuard g(S.ix->device);
+                (void)hipStreamSynchronize(S.stream);
+            }
+            DeviceGuard g(sh->merge_device);
+            (void)hipStreamSynchronize(sh->merge_stream);
+        }
+    } quiesce{sh};
     const size_t k = num_neighbors;
     const size_t qb = (size_t)nq * sh->dim * elem_size(sh->dtype);
     const size_t pb = (size_t)granne_hip_packed_topk_bytes(nq, num_neighbors);

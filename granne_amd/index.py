@@ -269,6 +269,29 @@ class Granne:
                                                          C.c_void_p(d_counts), C.c_void_p(d_stats), C.c_void_p(d_status),
                                                          C.c_void_p(stream), C.c_void_p(ev_before), C.c_void_p(ev_after)))
 
+    def brute_force_device(self, d_queries, nq, k, d_ids, d_dists, d_counts, stream=0):
+        """Exact k nearest elements of every query by a scan of all elements on the matrix cores
+        (granne_hip_brute_force_device). Raw device pointers (int), asynchronous on `stream`."""
+        check(lib().granne_hip_brute_force_device(self._h, C.c_void_p(d_queries), int(nq), int(k), C.c_void_p(d_ids),
+                                                  C.c_void_p(d_dists), C.c_void_p(d_counts), C.c_void_p(stream)))
+
+    def brute_force(self, queries, k):
+        """Host convenience over brute_force_device (torch moves the buffers): ids [nq, k] u64, dists [nq, k] f32,
+        counts [nq] u32, ascending by (distance, id) -- the exact answer Granne::search approximates."""
+        import torch
+        q = np.ascontiguousarray(queries, dtype=self.np_dtype)
+        if q.ndim == 1:
+            q = q[None]
+        dev = torch.device("cuda", self.device)
+        tq = torch.from_numpy(q.view(np.uint8).reshape(q.shape[0], -1)).to(dev)
+        ids = torch.empty((q.shape[0], k), dtype=torch.int64, device=dev)
+        ds = torch.empty((q.shape[0], k), dtype=torch.float32, device=dev)
+        cnt = torch.empty(q.shape[0], dtype=torch.int32, device=dev)
+        self.brute_force_device(tq.data_ptr(), q.shape[0], k, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(),
+                                torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize(dev)
+        return ids.cpu().numpy().astype(np.uint64), ds.cpu().numpy(), cnt.cpu().numpy().astype(np.uint32)
+
     def dists_device(self, d_queries, nq, d_ids, m, d_out, d_status=0, stream=0):
         """ElementContainer::dists (src/elements/mod.rs:35-39) batched on device: out[q, j] =
         dist(element ids[q, j], query q). Raw device pointers (int), asynchronous on `stream`."""

@@ -235,6 +235,17 @@ int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, co
                                  uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
                                  int device_id, void* stream);
 
+/* Exact k nearest elements of every query by a scan of ALL elements on the matrix cores: the many-to-many form of
+ * ElementContainer::dists (src/elements/mod.rs:35-39, src/elements/dense_vector.rs:157-163) -- the recall ground truth
+ * next to the graph walk, and the one contraction-shaped piece of the element side (v_mfma_f32_32x32x2_f32 /
+ * v_mfma_i32_32x32x16_i8; granne_amd/csrc/brute_force.h). Candidates are SELECTED by the MFMA score; the returned
+ * distances are recomputed in the reference's arithmetic (bit-exact for the returned ids) and the results are ordered
+ * ascending by (distance, id). The id set can differ from a scalar scan only between elements whose distances to the
+ * query are within the MFMA's rounding (~1e-6) of each other at the k-th place. k <= 16; f32 rows of up to 256
+ * dimensions, int8 rows of up to 128. queries: dense [nq][dim], prepared like the elements. Asynchronous on `stream`. */
+int granne_hip_brute_force_device(const granne_hip_index* index, const void* d_queries, uint32_t nq, uint32_t k,
+                                  uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, void* stream);
+
 /* The per-shard top-k of one batch as ONE buffer -- what a rank contributes to the single exchange
  * step of the partitioned mode (one all-gather, or one peer copy):
  *   [nq*k u64 local ids][nq*k f32 dists][nq u32 counts], padded to 16 bytes.                      */

@@ -33,6 +33,9 @@ CASES = [
     (2000, 6, False, 31, 40, True, 128),
     (1500, 6, False, 32, 40, True, 128),
     (2500, 8, True, 30, 40, True, 256),
+    # the streamed run-time-dim walker proposes the extras, dist_lds re-evaluates them: same bits (add_one_to_selected)
+    (1500, 50, False, 30, 40, True, 128),
+    (1200, 97, False, 30, 40, True, 128),
 ]
 
 

@@ -10,7 +10,8 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
     for r in rows:
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         agg[r["Kernel_Name"]].append(dur)
-        if ("search_kernel" in r["Kernel_Name"] or "fast_kernel" in r["Kernel_Name"]) and int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0)) == 65536:
+        # the benchmark's launches: 1024 walker blocks + the tail blocks (slow_kernel.h), 64 threads each
+        if ("search_kernel" in r["Kernel_Name"] or "fast_kernel" in r["Kernel_Name"]) and 65536 <= int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0)) <= 65536 + 64 * 64:
             bench.append(dur)
     tot = sum(sum(v) for v in agg.values())
     lines.append("# kernel trace: kernel, calls, total_ms, avg_us, min_us, max_us, pct")
@@ -18,21 +19,24 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
         lines.append("%s,%d,%.3f,%.2f,%.2f,%.2f,%.2f" % (k[:100], len(v), sum(v) / 1e3, statistics.mean(v), min(v), max(v), 100 * sum(v) / tot))
     if bench:
         t = bench[3:] if len(bench) > 3 else bench
-        lines.append("# walker launches of the timed steps (grid 1024x64): n=%d mean %.1f us min %.1f us max %.1f us" % (len(t), statistics.mean(t), min(t), max(t)))
+        lines.append("# walker launches of the timed steps (grid (1024 + tail) x 64): n=%d mean %.1f us min %.1f us max %.1f us" % (len(t), statistics.mean(t), min(t), max(t)))
 # pmc
 for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         rows = list(csv.DictReader(open(f)))
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows:
+            if r["Kernel_Name"].startswith("void granne_hip::bf_") or "::bf_" in r["Kernel_Name"][:40]:
+                agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                continue
             if "search_kernel" not in r["Kernel_Name"] and "fast_kernel" not in r["Kernel_Name"]:
                 continue
             gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
-            if gs != 65536:
+            if not (65536 <= gs <= 65536 + 64 * 64):
                 continue
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in agg.items():
-            lines.append("# PMC (%s) %s, per launch of the benchmark's search_kernel (mean over %d launches)" % (os.path.basename(d), k[:80], len(next(iter(cs.values())))))
+            lines.append("# PMC (%s) %s, per launch (mean over %d launches of the benchmark's batches / of the scan)" % (os.path.basename(d), k[:80], len(next(iter(cs.values())))))
             for c, v in sorted(cs.items()):
                 lines.append("%s,%.1f" % (c, statistics.mean(v)))
 open(out, "w").write("\n".join(lines) + "\n")
