@@ -238,8 +238,10 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     const uint32_t bmax = b->cfg.batch_max;
     const uint32_t lrow = ((b->row_bytes / 16) | 1u) * 16u;
     const BuildKernels K = pick_build_kernels(b->dtype, b->dim);
-    const uint32_t lds = build_lds_bytes(lrow, cap);
-    const uint32_t lds_rows = build_lds_bytes_rows(lrow, cap); // apply / final_prune (<= lds)
+    // (apply / final_prune only ever see cap + 1 candidates: their arrays keep the minimum size)
+    const uint32_t cand_cap = build_cand_cap(max_search);
+    const uint32_t lds = build_lds_bytes(lrow, cap, cand_cap);
+    const uint32_t lds_rows = build_lds_bytes_rows(lrow, cap, cand_cap); // apply / final_prune (<= lds)
     if (lds > 160u * 1024u)
         return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the GPU builder: select_neighbors stages %u candidate rows "
                     "of %u bytes in LDS (%u bytes, a CU has 163840)", cap + 1, lrow, lds);
@@ -287,6 +289,7 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     P.seg_start = S.seg_start;
     P.n_seg = S.counters;
     P.selected = S.selected;
+    P.cand_cap = cand_cap;
     HIP_TRY(hipMemsetAsync(S.selected, 0, layer_len ? layer_len : 1, s)); // nothing is known about the rows of a pass
 
     const bool debug = getenv("GRANNE_HIP_DEBUG") != nullptr;

@@ -30,7 +30,8 @@ __host__ __device__ inline uint32_t op_pos(uint64_t key) { return (uint32_t)(key
 __host__ __device__ inline uint32_t op_phase(uint64_t key) { return (uint32_t)(key >> 8) & 1u; }
 constexpr int OP_KEY_BITS = 61;
 constexpr uint32_t BUILD_MAX_NEIGHBORS = 63; // one lane per neighbor, +1 for the extra candidate
-constexpr uint32_t BUILD_MAX_CAND = 256;     // search candidates per element (max_search <= 256)
+constexpr uint32_t BUILD_MAX_CAND = 1024;    // search candidates per element: max_search up to the register walker's longest list
+constexpr uint32_t BUILD_MIN_CAND_CAP = 256; // the candidate arrays' LDS size follows the build's max_search from here up
 constexpr uint32_t BUILD_CHUNK = 32;         // candidate rows staged per gather round
 constexpr float EPS100 = 100.0f * 1.1920929e-07f; // 100.0 * f32::EPSILON (mod.rs:813, 829)
 
@@ -58,6 +59,7 @@ struct BuildParams {
     uint32_t* seg_start;
     uint32_t* n_seg;
     uint8_t* selected;             // [layer_len]: 1 = the row is the untouched output of select_neighbors (see apply_kernel)
+    uint32_t cand_cap;             // entries of the candidate arrays in LDS (>= max_search, >= cap + 1; a multiple of 64)
 };
 
 // LDS carve-up shared by the three kernels
@@ -65,8 +67,8 @@ struct BuildLds {
     uint8_t* qrow;    // [lrow]
     uint8_t* chunk;   // [BUILD_CHUNK][lrow]
     uint8_t* selrows; // [cap][lrow]
-    uint32_t* cid;    // [BUILD_MAX_CAND]
-    float* cd;        // [BUILD_MAX_CAND]
+    uint32_t* cid;    // [cand_cap]
+    float* cd;        // [cand_cap]
     uint32_t* sid;    // [64]
     float* sd;        // [64]
     uint32_t* cur;    // [64]
@@ -74,17 +76,21 @@ struct BuildLds {
     float* pair;      // [BUILD_CHUNK][BUILD_CHUNK], aliases selrows when that is large enough
 };
 constexpr uint32_t PAIR_BYTES = BUILD_CHUNK * BUILD_CHUNK * 4; // pairwise distances of one chunk of candidates
-__host__ __device__ inline uint32_t build_lds_bytes(uint32_t lrow, uint32_t cap) {
+__host__ __device__ inline uint32_t build_cand_cap(uint32_t max_search) {
+    const uint32_t c = (max_search + 63u) & ~63u;
+    return c < BUILD_MIN_CAND_CAP ? BUILD_MIN_CAND_CAP : c;
+}
+__host__ __device__ inline uint32_t build_lds_bytes(uint32_t lrow, uint32_t cap, uint32_t cand_cap) {
     // the pairwise matrix shares the selected-rows stage when that is large enough
-    return lrow * (1 + BUILD_CHUNK + cap) + (lrow * cap < PAIR_BYTES ? PAIR_BYTES : 0u) + BUILD_MAX_CAND * 8 + 64 * 4 * 4;
+    return lrow * (1 + BUILD_CHUNK + cap) + (lrow * cap < PAIR_BYTES ? PAIR_BYTES : 0u) + cand_cap * 8 + 64 * 4 * 4;
 }
 // apply_kernel / final_prune_kernel only ever limit a row of at most cap + 1 candidates: while that is one chunk
 // (select_neighbors_pairs) the selected-rows stage is never touched and is left out -- 21 KB instead of 29 KB per
 // wave at 100-d f32, seven waves per CU instead of five
 __host__ __device__ inline bool build_lds_compact(uint32_t cap) { return cap + 1u <= BUILD_CHUNK; }
-__host__ __device__ inline uint32_t build_lds_bytes_rows(uint32_t lrow, uint32_t cap) {
-    if (!build_lds_compact(cap)) return build_lds_bytes(lrow, cap);
-    return lrow * (1 + BUILD_CHUNK) + PAIR_BYTES + BUILD_MAX_CAND * 8 + 64 * 4 * 4;
+__host__ __device__ inline uint32_t build_lds_bytes_rows(uint32_t lrow, uint32_t cap, uint32_t cand_cap) {
+    if (!build_lds_compact(cap)) return build_lds_bytes(lrow, cap, cand_cap);
+    return lrow * (1 + BUILD_CHUNK) + PAIR_BYTES + cand_cap * 8 + 64 * 4 * 4;
 }
 
 template <int DT, int DIM>
@@ -108,8 +114,8 @@ struct RowWork {
             a += PAIR_BYTES;
         }
         L.cid = reinterpret_cast<uint32_t*>(a);
-        L.cd = reinterpret_cast<float*>(a + BUILD_MAX_CAND * 4);
-        a += BUILD_MAX_CAND * 8;
+        L.cd = reinterpret_cast<float*>(a + p.cand_cap * 4);
+        a += p.cand_cap * 8;
         L.sid = reinterpret_cast<uint32_t*>(a);
         L.sd = reinterpret_cast<float*>(a + 256);
         L.cur = reinterpret_cast<uint32_t*>(a + 512);
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(64) void select_kernel(const BuildParams P) {
     uint32_t nsel = 0;
     if (!skip) {
         // candidates.filter(id != idx), :822
-        const uint32_t cnt = min(P.s_counts[t], BUILD_MAX_CAND);
+        const uint32_t cnt = min(P.s_counts[t], P.cand_cap);
         uint32_t m = 0;
         for (uint32_t base = 0; base < cnt; base += 64) {
             uint32_t i = base + lane;

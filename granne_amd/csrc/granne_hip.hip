@@ -599,11 +599,28 @@ static search_fn pick_fast_s(uint32_t S, bool trail, bool v16) {
 }
 static bool fast_shape(const SearchTarget* ix) {
     if (ix->max_dev_width != 32 || ix->n_elements > WALK_MAX_ELEMENTS) return false;
-    if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128;
+    if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128 || ix->row_bytes == 256 || ix->row_bytes == 512; // dims <= 512
     return ix->dim >= 32; // 100 and 200 fully unrolled, any other dim with at least one 32-float chunk streamed
 }
 static bool fast_generic(const SearchTarget* ix) { return ix->dtype == GRANNE_HIP_F32 && ix->dim != 100 && ix->dim != 200; }
+// the longest max_search the register walker is instantiated for, by shape
+static uint32_t fast_max_search(const SearchTarget* ix) {
+    if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128 ? FAST_MAX_SEARCH : 252u; // wide int8 rows: lists of up to 4 x 64 keys
+    return fast_generic(ix) ? 508u : FAST_MAX_SEARCH;                                       // streamed f32 dims: up to 8 x 64 keys
+}
+// int8 rows of 256 / 512 bytes (dims 129..512, e.g. the 200- and 300-d rows of benches/distance_computation.rs:29-39)
+template <int ROWB>
+static search_fn pick_fast_i8_wide(uint32_t S, bool trail, bool v16) {
+    if (trail) return fast_kernel<DT_I8, ROWB, 1, true>;
+    switch (S) {
+    case 1: return v16 ? fast_kernel<DT_I8, ROWB, 1, false, true> : fast_kernel<DT_I8, ROWB, 1>;
+    case 2: return v16 ? fast_kernel<DT_I8, ROWB, 2, false, true> : fast_kernel<DT_I8, ROWB, 2>;
+    default: return v16 ? fast_kernel<DT_I8, ROWB, 4, false, true> : fast_kernel<DT_I8, ROWB, 4>;
+    }
+}
 static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail, bool v16) {
+    if (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes == 256) return pick_fast_i8_wide<256>(S, trail, v16);
+    if (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes == 512) return pick_fast_i8_wide<512>(S, trail, v16);
     if (ix->dtype == GRANNE_HIP_I8) return pick_fast_s<DT_I8, 0>(S, trail, v16);
     if (ix->dim == 100) return pick_fast_s<DT_F32, 100>(S, trail, v16);
     if (ix->dim == 200) return pick_fast_s<DT_F32, 200>(S, trail, v16);
@@ -762,7 +779,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     if (!d_queries || (!d_trail && (!d_ids || !d_dists || !d_counts))) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
 
     // (the streamed run-time-dim walker is instantiated up to 8 x 64 keys: beyond that the exact walker)
-    const bool fast = fast_shape(ix) && ef <= (fast_generic(ix) ? 508u : FAST_MAX_SEARCH);
+    const bool fast = fast_shape(ix) && ef <= fast_max_search(ix);
     const uint32_t fastS = fast ? fast_list_slots(ef) : 0u;
     const uint32_t ef_walk = fast ? ef : (ef > 256 ? 256 : ef); // what the register/LDS walker is sized for
     const bool all_slow = ix->opt_force_slow || (!fast && ef > 256);
@@ -786,7 +803,14 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     }
 
     // scratch: [control words][region states] (zero between launches) [hand-over list][overflow tables][exact walker]
-    const uint32_t slow_blocks = (uint32_t)ix->opt_slow_blocks;
+    // The exact walker's blocks: a few as the tail of a register-walker launch (hand-overs are rare), many when the whole
+    // batch is its to walk (max_search beyond the register lists, GRANNE_HIP_OPT_FORCE_SLOW): one block per query up to
+    // 32x the option (512 at its default of 16) -- each block owns 12 bytes x slow_slots of global scratch.
+    uint32_t slow_blocks = (uint32_t)ix->opt_slow_blocks;
+    if (all_slow) {
+        const uint32_t most = slow_blocks * 32u;
+        slow_blocks = nq < most ? (nq > slow_blocks ? nq : slow_blocks) : most;
+    }
     const uint32_t n_tail = all_slow ? 0u : (slow_blocks < nq ? slow_blocks : nq);
     const uint32_t slots = (uint32_t)ix->opt_slow_slots;
     const size_t list_bytes = ((size_t)nq * 4 + 15) & ~(size_t)15;

@@ -1,5 +1,5 @@
 // walk_fast.h -- the walker of the common shapes (every layer 32 ids wide on the device; f32 rows
-// of a compile-time dim, or int8 rows of 128 bytes): one wavefront per query, all layers in one
+// of a compile-time or streamed dim, or int8 rows of 128 / 256 / 512 bytes): one wavefront per query, all layers in one
 // launch (Granne::search -> search_internal -> find_entrypoint -> search_for_neighbors,
 // /root/reference/src/index/mod.rs:140-150, 963-1037).
 //
@@ -269,7 +269,9 @@ struct FastWalker {
     static constexpr int NB = F32 ? (GEN ? (int)GEN_GROUP : DIM / 32) : 0; // full 32-float chunks (GEN: per group)
     static constexpr int TU = F32 ? (DIM % 32) / 4 : 0;  // 16-byte units of the tail
     static constexpr bool QREG = F32 && fast_query_in_regs(false, GEN, (uint32_t)DIM, (uint32_t)S);
-    static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u;
+    static constexpr int NBI = F32 ? 1 : (DIM ? DIM / 128 : 1); // int8: 128-byte blocks per row (DIM = row bytes; 0 = 128)
+    static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u * NBI;
+    static_assert(F32 || DIM == 0 || DIM == 256 || DIM == 512, "fast int8 rows: 128, 256 or 512 bytes");
     static constexpr uint32_t CAP = 64u * S;
     static_assert(!F32 || GEN || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
@@ -280,7 +282,7 @@ struct FastWalker {
     uint32_t* vis_tab;
     float qh[QREG ? NB * 16 : 1];
     float qt[(QREG && TU) ? TU * 4 : 1];
-    uint4 qi8[F32 ? 1 : 4]; // i8: bytes 64h..64h+63 of the query
+    uint4 qi8[F32 ? 1 : 4 * NBI]; // i8: bytes 64h..64h+63 of every 128-byte block of the query
     float sy;               // i8: sqrt(sum of squares of the query) as f32
     uint32_t g_nbk, g_ngroups, g_tu; // GEN: full chunks, groups of them, 16-byte units of the (zero padded) tail
     typename std::conditional<V16, VisitedSet16, VisitedSet>::type vis;
@@ -336,7 +338,7 @@ struct FastWalker {
             const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
             int8_t* l = reinterpret_cast<int8_t*>(lds_q);
             int part = 0;
-            for (uint32_t i = lane; i < 128u; i += 64) {
+            for (uint32_t i = lane; i < ROWB; i += 64) {
                 const int v = (i < p.dim) ? (int)q[i] : 0;
                 l[i] = (int8_t)v;
                 part += v * v;
@@ -345,7 +347,9 @@ struct FastWalker {
             sy = __builtin_sqrtf((float)part); // sqrt(dy), angular_int.rs:53
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) qi8[k] = *reinterpret_cast<const uint4*>(lds_q + h * 64u + k * 16u);
+            for (int b = 0; b < NBI; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qi8[b * 4 + k] = *reinterpret_cast<const uint4*>(lds_q + b * 128u + h * 64u + k * 16u);
         }
     }
 
@@ -353,7 +357,7 @@ struct FastWalker {
     struct RowRegs {
         float4 v[NB ? NB : 1][4];
         float4 vt[TU ? TU : 1];
-        uint4 x[4];
+        uint4 x[4 * NBI];
         const uint8_t* row; // GEN: the row, for the groups and the tail that finish_rows loads itself
     };
 
@@ -384,9 +388,11 @@ struct FastWalker {
 #pragma unroll
             for (int u = 0; u < TU; ++u) rr.vt[u] = *reinterpret_cast<const float4*>(row + NB * 128 + u * 16);
         } else {
-            const uint8_t* e = p.elements + (size_t)idl * 128u + h * 64u;
+            const uint8_t* e = p.elements + (size_t)idl * ROWB + h * 64u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rr.x[k] = *reinterpret_cast<const uint4*>(e + k * 16);
+            for (int b = 0; b < NBI; ++b)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rr.x[b * 4 + k] = *reinterpret_cast<const uint4*>(e + b * 128 + k * 16);
         }
         asm volatile("" ::: "memory"); // the loads are issued here, whatever follows runs under them
     }
@@ -483,7 +489,7 @@ struct FastWalker {
         } else {
             int r = 0, dx = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 4 * NBI; ++k) {
                 r = dot4_i8(rr.x[k].x, qi8[k].x, r); r = dot4_i8(rr.x[k].y, qi8[k].y, r);
                 r = dot4_i8(rr.x[k].z, qi8[k].z, r); r = dot4_i8(rr.x[k].w, qi8[k].w, r);
                 dx = dot4_i8(rr.x[k].x, rr.x[k].x, dx); dx = dot4_i8(rr.x[k].y, rr.x[k].y, dx);
@@ -829,6 +835,7 @@ constexpr int fast_waves_per_simd(int DT, int DIM, int S) {
 #if GRANNE_HIP_PHASE_TIMERS
     return 1; // the phase clocks live in registers too: no cap, the diagnostics run is one wave per SIMD anyway
 #endif
+    if (DT == DT_I8 && DIM >= 256) return DIM == 256 ? 3 : 2; // 2 / 4 blocks of row data and of query per lane
     if (DT == DT_I8) return S == 1 ? 5 : S <= 4 ? 4 : S == 8 ? 3 : 2;
     if (DIM == 0) return 2; // the streamed walker keeps a group of chunks, the tail and the accumulators: ~210 VGPRs
     if (DIM > 128) return S == 1 ? 3 : 2;

@@ -354,7 +354,8 @@ enum {
     GRANNE_HIP_OPT_VISITED_SLOTS = 1, /* LDS visited-table slots per query: 2^k or 3 * 2^k in [256, 32768]; 0 = auto */
     GRANNE_HIP_OPT_FORCE_SLOW = 2,    /* 1: route every query through the exact global-memory path */
     GRANNE_HIP_OPT_SLOW_SLOTS = 3,    /* global visited/queue slots per slow-path query (pow2)      */
-    GRANNE_HIP_OPT_SLOW_BLOCKS = 4,   /* concurrent slow-path walkers                               */
+    GRANNE_HIP_OPT_SLOW_BLOCKS = 4,   /* concurrent slow-path walkers serving hand-overs; a batch that is the exact walker's
+                                         as a whole (max_search beyond the register lists) runs up to 32x as many */
     GRANNE_HIP_OPT_OVERFLOW_SLOTS = 5,/* global overflow slots per walk for a full LDS visited table:
                                          0 = auto, 1 = off (such walks go to the slow path), else pow2 */
     GRANNE_HIP_OPT_VISITED16 = 6,     /* the register walkers' 16-bit two-choice visited table (half the LDS of the

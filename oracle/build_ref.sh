@@ -16,6 +16,8 @@ OUT="$HERE/_ref"
 if [ ! -d /root/reference ]; then
   echo "build_ref: /root/reference is absent: nothing to pin against (parity stays unpinned)"; exit 0
 fi
+# a toolchain installed by rustup lives outside PATH in non-login shells
+if ! command -v cargo >/dev/null 2>&1 && [ -x "$HOME/.cargo/bin/cargo" ]; then export PATH="$HOME/.cargo/bin:$PATH"; fi
 if ! command -v cargo >/dev/null 2>&1; then
   echo "build_ref: no cargo/rustc in this image: the reference cannot be executed here (parity stays unpinned)."
   echo "build_ref: on a box with a Rust toolchain run:  bash oracle/build_ref.sh  &&  python -m pytest tests/test_ref_fixtures.py"

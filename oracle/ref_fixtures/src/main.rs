@@ -13,6 +13,10 @@
 //!   queries.bin         [nq][dim] PREPARED query scalars (f32 normalised / i8 quantised)
 //!   search_ms<M>_k<K>.bin   per query: [u32 count][count x (u64 id, u32 distance bits)]
 //!   dists.bin           [nq] u32: distance bits of query i to element i (`Dist::dist`)
+//!   reorder_order.bin   (cases with `reorder`) [n] u64: the permutation `Granne::reorder` returned
+//!   reordered_elements.bin, reordered_search_ms<M>_k<K>.bin   the elements and the same searches after it
+//! Cases with `distinct < n` repeat rows (row i is synthetic row i % distinct): exactly equal distances, the
+//! tie-breaking comparisons of search_for_neighbors / MaxSizeHeap::push decide.
 use granne::{angular, angular_int, BuildConfig, Builder, GranneBuilder, Index};
 use std::fs::{create_dir_all, File};
 use std::io::{BufWriter, Write};
@@ -46,12 +50,16 @@ struct Case {
     num_neighbors: usize,
     build_max_search: usize,
     searches: &'static [(usize, usize)], // (max_search, num_neighbors)
+    distinct: usize,                     // row i is synthetic row i % distinct (== n: all rows differ)
+    reorder: bool,                       // also run Granne::reorder and search again
 }
 
 const CASES: &[Case] = &[
-    Case { name: "f32_d100", n: 3000, dim: 100, nq: 64, num_neighbors: 30, build_max_search: 50, searches: &[(1, 1), (50, 10), (200, 50), (300, 300)] },
-    Case { name: "f32_d28", n: 700, dim: 28, nq: 32, num_neighbors: 20, build_max_search: 30, searches: &[(5, 5), (40, 10)] },
-    Case { name: "f32_d200", n: 2000, dim: 200, nq: 32, num_neighbors: 30, build_max_search: 40, searches: &[(50, 10)] },
+    Case { name: "f32_d100", n: 3000, dim: 100, nq: 64, num_neighbors: 30, build_max_search: 50, searches: &[(1, 1), (50, 10), (200, 50), (300, 300), (1024, 10)], distinct: 3000, reorder: true },
+    Case { name: "f32_d28", n: 700, dim: 28, nq: 32, num_neighbors: 20, build_max_search: 30, searches: &[(5, 5), (40, 10)], distinct: 700, reorder: false },
+    Case { name: "f32_d200", n: 2000, dim: 200, nq: 32, num_neighbors: 30, build_max_search: 40, searches: &[(50, 10)], distinct: 2000, reorder: false },
+    // every vector three times: ties everywhere (the walk's strict / non-strict comparisons, (dist, id) order)
+    Case { name: "ties_d32", n: 1500, dim: 32, nq: 48, num_neighbors: 20, build_max_search: 30, searches: &[(1, 1), (20, 10), (60, 60), (130, 20)], distinct: 500, reorder: false },
 ];
 
 fn write_results<W: Write>(w: &mut W, res: &[(usize, f32)]) -> std::io::Result<()> {
@@ -71,7 +79,7 @@ macro_rules! emit_case {
         // elements: Vector::from(Vec<f32>) normalises (angular.rs:55-61) / quantises (angular_int.rs:19-45)
         let mut elements = $module::Vectors::new();
         for i in 0..case.n {
-            let v: $module::Vector = synth_row(SEED, i as u64, case.dim).into();
+            let v: $module::Vector = synth_row(SEED, (i % case.distinct) as u64, case.dim).into();
             elements.push(&v);
         }
         let queries: Vec<$module::Vector> = (0..case.nq).map(|i| synth_row(SEED + 1, i as u64, case.dim).into()).collect();
@@ -111,13 +119,33 @@ macro_rules! emit_case {
                 w.write_all(&d.to_bits().to_le_bytes())?;
             }
         }
+        let mut reorder_files = Vec::new();
+        if case.reorder {
+            // Granne::reorder (src/index/reorder.rs:59-85) on an owned copy: the permutation, the permuted elements and
+            // the same searches afterwards (equal to the ones before modulo the permutation, reorder.rs:297-323)
+            let mut owned = index.to_owned();
+            let order = owned.reorder(false);
+            let mut w = BufWriter::new(File::create(dir.join("reorder_order.bin"))?);
+            for &o in &order {
+                w.write_all(&(o as u64).to_le_bytes())?;
+            }
+            owned.write_elements(&mut BufWriter::new(File::create(dir.join("reordered_elements.bin"))?))?;
+            for &(ms, k) in case.searches {
+                let name = format!("reordered_search_ms{}_k{}.bin", ms, k);
+                let mut w = BufWriter::new(File::create(dir.join(&name))?);
+                for q in &queries {
+                    write_results(&mut w, &owned.search(q, ms, k))?;
+                }
+                reorder_files.push(format!("{{\"file\":\"{}\",\"max_search\":{},\"num_neighbors\":{}}}", name, ms, k));
+            }
+        }
         let layers: Vec<String> = (0..index.num_layers()).map(|l| index.layer_len(l).to_string()).collect();
         let manifest = format!(
             "{{\"case\":\"{}{}\",\"element_type\":\"{}\",\"n\":{},\"dim\":{},\"nq\":{},\"seed\":{},\"num_neighbors\":{},\
              \"build_max_search\":{},\"reinsert_elements\":true,\"layer_multiplier\":15.0,\"feature\":\"singlethreaded\",\
-             \"granne_version\":\"0.5.2\",\"layer_lens\":[{}],\"searches\":[{}]}}\n",
+             \"granne_version\":\"0.5.2\",\"layer_lens\":[{}],\"searches\":[{}],\"distinct\":{},\"reordered_searches\":[{}]}}\n",
             case.name, $tag, stringify!($module), case.n, case.dim, case.nq, SEED, case.num_neighbors, case.build_max_search,
-            layers.join(","), files.join(",")
+            layers.join(","), files.join(","), case.distinct, reorder_files.join(",")
         );
         File::create(dir.join("manifest.json"))?.write_all(manifest.as_bytes())?;
         eprintln!("wrote {}", dir.display());

@@ -36,6 +36,10 @@ CASES = [
     # the streamed run-time-dim walker proposes the extras, dist_lds re-evaluates them: same bits (add_one_to_selected)
     (1500, 50, False, 30, 40, True, 128),
     (1200, 97, False, 30, 40, True, 128),
+    # build max_search beyond 256 (the candidate arrays in LDS follow it, up to the register walker's longest list)
+    (1200, 32, False, 20, 300, True, 128),
+    (900, 100, True, 30, 600, False, 64),
+    (700, 100, False, 16, 1024, True, 64),
 ]
 
 

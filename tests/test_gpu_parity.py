@@ -146,6 +146,12 @@ CASES = [
     (2000, 100, True, 30, 30),
     (500, 32, True, 20, 20),
     (700, 130, True, 12, 20),
+    # int8 rows of 256 and 512 bytes on the register walker (the reference benches 200- and 300-d int8 rows,
+    # benches/distance_computation.rs:29-39); 513+ dims take the general walker
+    (700, 200, True, 20, 20),
+    (600, 300, True, 20, 20),
+    (500, 512, True, 16, 20),
+    (300, 600, True, 16, 20),
     # f32 dims that take the streamed run-time-dim walker (walk_fast.h, DIM = 0): one chunk exactly, chunks + tails
     # of every length class, not a multiple of 4 (zero-padded tail unit), more than one group of three chunks
     (900, 32, False, 30, 30),
@@ -324,6 +330,20 @@ def test_large_max_search_stays_on_the_register_walker(ga, oracle, int8, ms):
     assert_same(oix, gix, q, ms, ms)
     if not int8:
         assert gix.last_slow_count() == 0
+
+
+def test_max_search_beyond_the_register_lists(ga, oracle):
+    """max_search above 1024 (above 252 for wide int8 rows, 508 for streamed f32 dims) is the exact global-memory
+    walker's as a whole batch -- its own launch, one block per query up to 32 x OPT_SLOW_BLOCKS. Same results."""
+    rng = np.random.default_rng(41)
+    for int8, dim, ms in [(False, 100, 1500), (True, 100, 2048), (True, 200, 300), (False, 50, 600)]:
+        el = prep(oracle, random_floats(rng, 5000, dim), int8)
+        oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
+        gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
+        q = prep(oracle, random_floats(rng, 200, dim), int8)
+        assert_same(oix, gix, q, ms, 10)
+        assert gix.last_slow_count() == 200
+        assert_same(oix, gix, q[:3], ms, 10)
 
 
 def test_visited_table_overflow_hands_over(ga, oracle):

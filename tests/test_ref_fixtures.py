@@ -7,7 +7,10 @@ these tests compare, bit for bit:
   * the oracle's Vector::from (normalize / quantize) with the reference's elements file,
   * the oracle's single-threaded build with the reference's graph (neighbor sets per node),
   * the product's index-file writer with the reference's index file (byte for byte),
-  * the oracle's search -- and on a GPU the HIP search -- with the reference's (id, distance bits).
+  * the oracle's search -- and on a GPU the HIP search -- with the reference's (id, distance bits), including a case
+    whose rows repeat (exact distance ties) and max_search 1024,
+  * Granne::reorder: the oracle's permutation, permuted elements and searches afterwards -- and on a GPU the HIP
+    reorder -- with the reference's.
 Without them (no Rust toolchain in this image: oracle/build_ref.sh says why) every test SKIPS with
 the reason "parity unpinned": the oracle is then pinned by the reference's known-answer tests and the
 independent second restatement only."""
@@ -76,8 +79,9 @@ def _decode_layers(index_bytes, width):
 @pytest.mark.parametrize("manifest", CASES)
 def test_oracle_elements_equal_reference(oracle, manifest):
     d, m, i8, el, q, _ = _load(manifest)
-    raw = oracle.synth_rows(SEED, 0, m["n"], m["dim"])
-    mine = oracle.quantize(raw) if i8 else oracle.normalize_f32(raw)
+    distinct = m.get("distinct", m["n"])
+    raw = oracle.synth_rows(SEED, 0, distinct, m["dim"])
+    mine = (oracle.quantize(raw) if i8 else oracle.normalize_f32(raw))[np.arange(m["n"]) % distinct]
     assert mine.tobytes() == el.tobytes()
     rq = oracle.synth_rows(SEED + 1, 0, m["nq"], m["dim"])
     assert (oracle.quantize(rq) if i8 else oracle.normalize_f32(rq)).tobytes() == q.tobytes()
@@ -105,6 +109,27 @@ def test_oracle_build_and_search_equal_reference(oracle, manifest):
         want = _results(os.path.join(d, s["file"]), m["nq"])
         for i in range(m["nq"]):
             got = oix.search(q[i], s["max_search"], s["num_neighbors"])
+            assert [g[0] for g in got] == [w[0] for w in want[i]], (s, i)
+            assert [np.float32(g[1]).view(np.uint32) for g in got] == [w[1] for w in want[i]], (s, i)
+
+
+@pytest.mark.parametrize("manifest", CASES)
+def test_oracle_reorder_equals_reference(oracle, manifest):
+    d, m, i8, el, q, index_bytes = _load(manifest)
+    if not m.get("reordered_searches"):
+        pytest.skip("no reorder in this case")
+    ref_layers = _decode_layers(index_bytes, m["num_neighbors"])
+    oix = oracle.Index(el, ref_layers)
+    want_order = np.fromfile(os.path.join(d, "reorder_order.bin"), "<u8")
+    order = oix.compute_order(n_threads=1)
+    assert (order == want_order).all()
+    rix = oix.reordered(order)
+    eb = open(os.path.join(d, "reordered_elements.bin"), "rb").read()
+    assert np.frombuffer(eb, el.dtype, offset=8).tobytes() == rix.elements.tobytes()
+    for s in m["reordered_searches"]:
+        want = _results(os.path.join(d, s["file"]), m["nq"])
+        for i in range(m["nq"]):
+            got = rix.search(q[i], s["max_search"], s["num_neighbors"])
             assert [g[0] for g in got] == [w[0] for w in want[i]], (s, i)
             assert [np.float32(g[1]).view(np.uint32) for g in got] == [w[1] for w in want[i]], (s, i)
 
@@ -139,3 +164,13 @@ def test_gpu_search_equals_reference(manifest):
             c = int(cnt[i])
             assert ids[i, :c].tolist() == [w[0] for w in want[i]], (s, i)
             assert ds[i, :c].view(np.uint32).tolist() == [w[1] for w in want[i]], (s, i)
+    if m.get("reordered_searches"):  # Granne::reorder on the device against the reference's
+        order = gix.reorder()
+        assert (order == np.fromfile(os.path.join(d, "reorder_order.bin"), "<u8")).all()
+        for s in m["reordered_searches"]:
+            want = _results(os.path.join(d, s["file"]), m["nq"])
+            ids, ds, cnt = gix.search_batch(q, s["max_search"], s["num_neighbors"])
+            for i in range(m["nq"]):
+                c = int(cnt[i])
+                assert ids[i, :c].tolist() == [w[0] for w in want[i]], (s, i)
+                assert ds[i, :c].view(np.uint32).tolist() == [w[1] for w in want[i]], (s, i)
