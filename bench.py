@@ -28,6 +28,9 @@ Rank 0 prints ONE JSON line. Besides the contract fields it carries
   int8          the same workload on angular_int (BASELINE.json configs[2]) as a sub-record
   secondary     a second synthetic workload on which recall@10 >= 0.95 is reachable (the headline
                 data is i.i.d. uniform in 100-d, where it is not): QPS at the smallest such ef
+  brute_force   the exact scan on the matrix cores (granne_hip_brute_force_device: the recall ground truth): its rate
+                against the f32 MFMA peak, queries/s at recall 1.0, the oracle's scan as check and CPU baseline --
+                on i.i.d. uniform 100-d data no max_search reaches recall 0.95, the scan does
   c4_shard      one shard of BASELINE.json configs[3] (12.5M x 200-d f32, batch 4096, ef 50) and
   c5_shard      one shard of configs[4] (125M x 100-d int8, batch 4096, ef 200), measured the same way
   partitioned   (WORLD_SIZE > 1 only) C2's 10M points split into WORLD_SIZE id ranges, one per rank: every rank
@@ -390,6 +393,7 @@ class Bench:
             if dtype == "f32":
                 flops = 2.0 * nq * n * dim
                 timing.update({"kernel": "bf_f32_kernel (v_mfma_f32_32x32x2_f32) + merge + exact re-ranking", "ms": round(ms, 3),
+                               "value": round(nq / (ms * 1e-3), 1), "value_unit": "queries/s at recall 1.0 (exact scan)",
                                "bound": "mfma", "achieved": round(flops / ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s",
                                "frac": round(flops / ms / 1e9 / 157.3, 4), "queries": nq, "elements": n, "dim": dim,
                                "note": "2 * nq * n * dim flops / wall of the whole operator (HIP events); peak = dense f32 MFMA"})
@@ -397,10 +401,30 @@ class Bench:
                 tiles = (nq + 255) // 256
                 byts = float(tiles) * n * 128
                 timing.update({"kernel": "bf_i8_kernel (v_mfma_i32_32x32x16_i8) + merge + exact re-ranking", "ms": round(ms, 3),
+                               "value": round(nq / (ms * 1e-3), 1), "value_unit": "queries/s at recall 1.0 (exact scan)",
                                "bound": "hbm", "achieved": round(byts / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(byts / ms / 1e6 / HBM_PEAK_GBPS, 4), "queries": nq, "elements": n, "dim": dim,
                                "note": "every tile of 256 queries streams the n 128-byte rows once: %d passes" % tiles})
+        self._gt_dists = ds.cpu().numpy()
         return ids.cpu().numpy()
+
+    def check_scan(self, oix, h_q, gt_ids, k, bf, n_check=32):
+        """The exact scan against the oracle's scan (the reference's Dist for every (query, element) pair, OpenMP over
+        the elements) on the first queries of the batch: its check and its CPU baseline. Adds to the brute_force record."""
+        from oracle import oracle as orc
+        m = min(n_check, h_q.shape[0])
+        sec, o_ids, o_d = oix.scan_topk(h_q[:m], k, n_threads=0)
+        g_ids, g_d = gt_ids[:m].astype(np.uint64), self._gt_dists[:m]
+        bf["cpu_baseline"] = {"value": round(m / sec, 1), "unit": "queries/s", "cores": orc.lib().gro_max_threads(), "kind": "port",
+                              "sample": "%d queries against all %d elements: the reference's Dist per pair (oracle gro_scan_topk, "
+                                        "OpenMP over the elements, every row evaluated against all queries while it is in L1), "
+                                        "%.2f s" % (m, len(oix.elements), sec)}
+        bf["speedup_vs_cpu"] = round(bf["value"] / bf["cpu_baseline"]["value"], 1)
+        bf["matches_oracle_scan"] = {"ids_equal_fraction": round(float((g_ids == o_ids).mean()), 5),
+                                     "dists_bit_exact": bool(g_d.tobytes() == o_d.tobytes()),
+                                     "max_abs_dist_diff": float(np.abs(g_d - o_d).max()), "queries_checked": int(m),
+                                     "note": "tolerance mode: candidates are selected by the MFMA score, distances recomputed "
+                                             "in the reference's arithmetic (granne_amd/csrc/brute_force.h)"}
 
     @staticmethod
     def recall(gt, got, k):
@@ -650,6 +674,8 @@ def run_replica(B, args):
             oix = B.host_index(elements, builder, order)
             out["cpu_baseline"] = B.cpu_baseline(oix, h_q, ef, k, g_ids, g_d)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+            if gt is not None and order is None and out.get("brute_force"):
+                B.check_scan(oix, h_q[:nq], gt, k, out["brute_force"])
             del oix
         if world == 1 and not args.no_extras:
             out["latency_nq1"] = B.latency_nq1(index, queries, dim, ef, k)
@@ -685,6 +711,7 @@ def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=
     rq = min(nq, recall_queries or nq)
     bf = {}
     gt = B.ground_truth(index, queries[warmup * nq:warmup * nq + rq], k, dtype, timing=bf)
+    gt_dists = B._gt_dists
     inflight = auto_inflight(args, dtype)
     layer_sizes = [builder.layer_len(l) for l in range(builder.num_layers())]
     rec = {"workload": workload_label(n, dim, dtype, data, nq, ef, k), "dtype": dtype, "data": "synthetic",
@@ -720,6 +747,9 @@ def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=
         oix = B.host_index(elements, builder)
         rec["cpu_baseline"] = B.cpu_baseline(oix, h_q, ef, k, g_ids, g_d, single_thread_queries=128)
         rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 2)
+        if n <= 20_000_000:  # (the oracle's scan of 125M rows is not worth its minute)
+            B._gt_dists = gt_dists
+            B.check_scan(oix, h_q[:rq], gt, k, bf, n_check=16)
         del oix
     del m, index, builder, elements, queries
     torch.cuda.empty_cache()

@@ -658,6 +658,69 @@ double gro_search_batch_timed(const gro_index* ix, const void* queries, size_t n
     return t1 - t0;
 }
 
+/* Exact k nearest elements of every query by a scan of ALL elements: what a caller gets from
+ * ElementContainer::dists over every index (src/elements/mod.rs:35-39) followed by a sort by (distance, id) -- the
+ * checker and the CPU baseline of granne_hip_brute_force_device. Threads split the elements; a thread walks its rows
+ * once and evaluates every query against a row while the row is in L1 (queries are few: they stay cached), keeping
+ * the k best per query; the per-thread lists are merged at the end. Distances are the reference's own (gro_dist_*).
+ * Returns wall seconds of the scan. out_ids / out_dists: [nq][k], padded with ~0 / +inf when n < k. */
+typedef struct { float d; uint64_t id; } scan_ent;
+static int scan_less(float da, uint64_t ia, float db, uint64_t ib) { return da < db || (da == db && ia < ib); }
+double gro_scan_topk(const gro_index* ix, const void* queries, size_t nq, size_t k, uint64_t* out_ids, float* out_dists,
+                     int n_threads) {
+    if (n_threads <= 0) n_threads = gro_max_threads();
+    const size_t esz = elem_size(ix->dtype), rowb = (size_t)ix->dim * esz;
+    const uint64_t n = ix->n_elements;
+    scan_ent* all = (scan_ent*)malloc(sizeof(scan_ent) * (size_t)n_threads * nq * k);
+    for (size_t i = 0; i < (size_t)n_threads * nq * k; ++i) { all[i].d = INFINITY; all[i].id = ~(uint64_t)0; }
+    const double t0 = gro_wtime();
+#pragma omp parallel num_threads(n_threads)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int t = 0, T = 1;
+#endif
+        scan_ent* mine = all + (size_t)t * nq * k;
+        const uint64_t lo = n * (uint64_t)t / (uint64_t)T, hi = n * (uint64_t)(t + 1) / (uint64_t)T;
+        for (uint64_t e = lo; e < hi; ++e) {
+            const char* row = (const char*)ix->elements + (size_t)e * rowb;
+            for (size_t q = 0; q < nq; ++q) {
+                const char* qp = (const char*)queries + q * rowb;
+                const float d = ix->dtype == GRO_F32 ? gro_dist_f32((const float*)row, (const float*)qp, ix->dim)
+                                                     : gro_dist_i8((const int8_t*)row, (const int8_t*)qp, ix->dim);
+                scan_ent* L = mine + q * k;
+                if (scan_less(d, e, L[k - 1].d, L[k - 1].id)) { /* insertion into the sorted k-list */
+                    size_t p = k - 1;
+                    while (p > 0 && scan_less(d, e, L[p - 1].d, L[p - 1].id)) { L[p] = L[p - 1]; --p; }
+                    L[p].d = d;
+                    L[p].id = e;
+                }
+            }
+        }
+    }
+    for (size_t q = 0; q < nq; ++q) { /* merge the threads' lists */
+        for (size_t j = 0; j < k; ++j) { out_ids[q * k + j] = ~(uint64_t)0; out_dists[q * k + j] = INFINITY; }
+        for (int t = 0; t < n_threads; ++t) {
+            const scan_ent* L = all + ((size_t)t * nq + q) * k;
+            for (size_t j = 0; j < k && L[j].id != ~(uint64_t)0; ++j) {
+                if (!scan_less(L[j].d, L[j].id, out_dists[q * k + k - 1], out_ids[q * k + k - 1])) break;
+                size_t p = k - 1;
+                while (p > 0 && scan_less(L[j].d, L[j].id, out_dists[q * k + p - 1], out_ids[q * k + p - 1])) {
+                    out_dists[q * k + p] = out_dists[q * k + p - 1];
+                    out_ids[q * k + p] = out_ids[q * k + p - 1];
+                    --p;
+                }
+                out_dists[q * k + p] = L[j].d;
+                out_ids[q * k + p] = L[j].id;
+            }
+        }
+    }
+    const double dt = gro_wtime() - t0;
+    free(all);
+    return dt;
+}
+
 /* ======================================================================================
  * build half, src/index/mod.rs:364-402, 645-960
  * ====================================================================================== */

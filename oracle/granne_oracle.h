@@ -89,6 +89,11 @@ double gro_search_batch_timed(const gro_index* ix, const void* queries, size_t n
                               size_t num_neighbors, uint64_t* out_ids, float* out_dists,
                               uint32_t* out_counts, int n_threads, int repeats);
 
+/* Exact k nearest elements by a scan of all elements (ElementContainer::dists over every index + a sort by
+ * (distance, id)): the checker and CPU baseline of granne_hip_brute_force_device. Returns wall seconds. */
+double gro_scan_topk(const gro_index* ix, const void* queries, size_t nq, size_t k, uint64_t* out_ids, float* out_dists,
+                     int n_threads);
+
 /* ---- build half, src/index/mod.rs:364-402, 645-960 ------------------------------------- */
 typedef struct {
     float layer_multiplier;     /* 15.0 */

@@ -88,6 +88,8 @@ def lib():
         L.gro_search_batch_timed.restype = C.c_double
         L.gro_search_batch_timed.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.gro_scan_topk.restype = C.c_double
+        L.gro_scan_topk.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.gro_build_config_default.restype = None
         L.gro_build_config_default.argtypes = [C.POINTER(_BuildConfig)]
         L.gro_builder_create.restype = C.c_void_p
@@ -270,6 +272,15 @@ class Index:
         if sec < 0:
             raise RuntimeError("max_search == 0 (reference panics, src/index/mod.rs:1019)")
         return sec, ids, ds, cnt
+
+    def scan_topk(self, queries, k, n_threads=0):
+        """Exact k nearest elements of every query by a scan of all elements, ascending by (distance, id):
+        (seconds, ids [nq, k] u64, dists [nq, k] f32)."""
+        q = np.ascontiguousarray(queries, self.elements.dtype)
+        ids = np.empty((q.shape[0], k), np.uint64)
+        ds = np.empty((q.shape[0], k), np.float32)
+        sec = lib().gro_scan_topk(C.byref(self._c), _p(q), q.shape[0], k, _p(ids), _p(ds), n_threads)
+        return sec, ids, ds
 
     # ---- Granne::reorder (src/index/reorder.rs) -------------------------------------------------
     def compute_order(self, n_threads=0):
