@@ -113,7 +113,7 @@ struct granne_hip_index {
     uint64_t opt_slow_slots = 1u << 18;
     uint64_t opt_slow_blocks = 16;
     uint64_t opt_overflow_slots = 0; // 0 auto, 1 off, else slots per overflow table
-    uint64_t opt_visited16 = 0;      // 0 auto, 1 off
+    uint64_t opt_visited16 = 0;      // 0 auto, 1 off, 2 always the 20-bit entries (tests)
     uint64_t opt_visited16_lg = 0;   // 0 auto, else log2(buckets)
     std::atomic<uint64_t> last_slow_count{0};
     // host-pointer searches (granne_hip_search / _search_batch): a stream, a device buffer and a pinned
@@ -467,7 +467,7 @@ extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uin
         ix->opt_overflow_slots = value;
         return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_VISITED16:
-        if (value > 1) return fail(GRANNE_HIP_ERR_INVALID, "visited16 must be 0 (auto) or 1 (off)");
+        if (value > 2) return fail(GRANNE_HIP_ERR_INVALID, "visited16 must be 0 (auto), 1 (off) or 2 (20-bit entries whatever the ids)");
         ix->opt_visited16 = value;
         return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_VISITED16_LG:
@@ -585,12 +585,12 @@ static search_fn pick_kernel(int dtype, uint32_t ef) {
 constexpr uint32_t FAST_MAX_SEARCH = 1024;
 static uint32_t fast_list_slots(uint32_t ef) { return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : 17u; }
 template <int DT, int DIM>
-static search_fn pick_fast_s(uint32_t S, bool trail, bool v16) {
+static search_fn pick_fast_s(uint32_t S, bool trail, int v16 /* 0: 32-bit table, 1: 16-bit entries, 2: 20-bit entries */) {
     if (trail) return fast_kernel<DT, DIM, 1, true>;
     switch (S) {
-    case 1: return v16 ? fast_kernel<DT, DIM, 1, false, true> : fast_kernel<DT, DIM, 1>;
-    case 2: return v16 ? fast_kernel<DT, DIM, 2, false, true> : fast_kernel<DT, DIM, 2>;
-    case 4: return v16 ? fast_kernel<DT, DIM, 4, false, true> : fast_kernel<DT, DIM, 4>;
+    case 1: return v16 == 2 ? fast_kernel<DT, DIM, 1, false, 2> : v16 ? fast_kernel<DT, DIM, 1, false, 1> : fast_kernel<DT, DIM, 1>;
+    case 2: return v16 == 2 ? fast_kernel<DT, DIM, 2, false, 2> : v16 ? fast_kernel<DT, DIM, 2, false, 1> : fast_kernel<DT, DIM, 2>;
+    case 4: return v16 == 2 ? fast_kernel<DT, DIM, 4, false, 2> : v16 ? fast_kernel<DT, DIM, 4, false, 1> : fast_kernel<DT, DIM, 4>;
     case 8: return fast_kernel<DT, DIM, 8>;
     default:
         if constexpr (DT == DT_F32 && DIM == 0) return fast_kernel<DT, DIM, 8>; // not reached: max_search <= 508 there
@@ -610,15 +610,15 @@ static uint32_t fast_max_search(const SearchTarget* ix) {
 }
 // int8 rows of 256 / 512 bytes (dims 129..512, e.g. the 200- and 300-d rows of benches/distance_computation.rs:29-39)
 template <int ROWB>
-static search_fn pick_fast_i8_wide(uint32_t S, bool trail, bool v16) {
+static search_fn pick_fast_i8_wide(uint32_t S, bool trail, int v16) { // (16-bit entries or the 32-bit table)
     if (trail) return fast_kernel<DT_I8, ROWB, 1, true>;
     switch (S) {
-    case 1: return v16 ? fast_kernel<DT_I8, ROWB, 1, false, true> : fast_kernel<DT_I8, ROWB, 1>;
-    case 2: return v16 ? fast_kernel<DT_I8, ROWB, 2, false, true> : fast_kernel<DT_I8, ROWB, 2>;
-    default: return v16 ? fast_kernel<DT_I8, ROWB, 4, false, true> : fast_kernel<DT_I8, ROWB, 4>;
+    case 1: return v16 ? fast_kernel<DT_I8, ROWB, 1, false, 1> : fast_kernel<DT_I8, ROWB, 1>;
+    case 2: return v16 ? fast_kernel<DT_I8, ROWB, 2, false, 1> : fast_kernel<DT_I8, ROWB, 2>;
+    default: return v16 ? fast_kernel<DT_I8, ROWB, 4, false, 1> : fast_kernel<DT_I8, ROWB, 4>;
     }
 }
-static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail, bool v16) {
+static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail, int v16) {
     if (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes == 256) return pick_fast_i8_wide<256>(S, trail, v16);
     if (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes == 512) return pick_fast_i8_wide<512>(S, trail, v16);
     if (ix->dtype == GRANNE_HIP_I8) return pick_fast_s<DT_I8, 0>(S, trail, v16);
@@ -629,7 +629,7 @@ static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail
 
 struct LaunchPlan {
     uint32_t visited_slots, upper_slots, maxc, lrow_bytes, stage_bytes, adjspec_bytes, lds_bytes;
-    bool v16; // the 16-bit two-choice visited table (VisitedSet16)
+    int v16; // the visited set's front table: 0 = 32-bit open addressing, 1 / 2 = two-choice buckets of 16- / 20-bit entries
 };
 
 // LDS plan. The visited table dominates; the f32 stage gets what keeps four walkers per CU
@@ -638,15 +638,15 @@ struct LaunchPlan {
 static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, uint32_t fastS /* 0: general walker */,
                               bool trail) {
     LaunchPlan P;
-    P.v16 = false;
+    P.v16 = 0;
     // The register walkers with short lists keep the visited set in 16-bit two-choice buckets (VisitedSet16,
     // wave_prims.h) whenever the ids fit its tags: nb buckets of 16 bytes hold up to 32767 * nb ids' worth of id space
     // and ~5.8 * nb ids before the first one spills (two-choice, 8 entries per bucket). A walk visits ~40 x
     // max_search nodes on 10M uniform points: nb = 8 * max_search rounded up to a power of two -- 512 buckets =
     // 8 KB at max_search 50 (the 32-bit table: 16 KB), so twice the walkers fit a CU's LDS.
-    // Id spaces beyond the tags (32767 ids per bucket: 125M ids would need 64 KB) keep the 32-bit table.
+    // Id spaces beyond the 16-bit entries' tags (32767 ids per bucket: 125M ids would need 64 KB) take 20-bit entries
+    // (524286 ids per bucket, six entries per bucket instead of eight); wide int8 rows have no 20-bit instantiation.
     if (fastS >= 1 && fastS <= 4 && !trail && knobs().v16 && !ix->opt_visited_slots && ix->opt_visited16 != 1) {
-        const uint32_t lg_ids = v16_lg_for_ids(ix->n_elements);
         uint32_t lg = V16_MIN_LG;
         while ((1u << lg) < ef * 8u) ++lg;
         // big launches keep more walkers resident with a smaller table and let the largest walks spill
@@ -654,9 +654,18 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         if (lg > lg_cap) lg = lg_cap;
         if (knobs().v16_lg) lg = (uint32_t)knobs().v16_lg;
         if (ix->opt_visited16_lg) lg = (uint32_t)ix->opt_visited16_lg;
-        if (lg < lg_ids) lg = lg_ids;
-        if (lg <= lg_cap || ((knobs().v16_lg || ix->opt_visited16_lg) && lg <= 12)) {
-            P.v16 = true;
+        if (lg > 12) lg = 12;
+        const bool wide_i8 = ix->dtype == GRANNE_HIP_I8 && ix->row_bytes != 128;
+        int kind = 0;
+        uint32_t lg_ids = v16_lg_for_ids(ix->n_elements, V16_TAG_MAX);
+        if (lg_ids <= lg && ix->opt_visited16 != 2) {
+            kind = 1;
+        } else if (!wide_i8) {
+            lg_ids = v16_lg_for_ids(ix->n_elements, V20_TAG_MAX);
+            if (lg_ids <= lg) kind = 2;
+        }
+        if (kind) {
+            P.v16 = kind;
             P.visited_slots = lg;
             P.upper_slots = lg_ids; // upper layers: the smallest table whose tags hold the ids (<= lg)
             P.maxc = 0;

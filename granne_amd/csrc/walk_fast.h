@@ -258,9 +258,10 @@ __host__ __device__ inline uint32_t fast_query_bytes(bool i8, bool gen, uint32_t
     return ngroups * GEN_GROUP * 128u + 128u;
 }
 
-// V16: the visited set's front table holds 16-bit entries in two-choice buckets (VisitedSet16, wave_prims.h) -- half
-// the LDS of the 32-bit table, for id spaces of up to 32767 ids per bucket; the host picks it when the ids fit.
-template <int DT, int DIM, int S, bool V16 = false>
+// V16: the form of the visited set's front table. 0 = 32-bit open addressing (VisitedSet); 1 = 16-bit entries in
+// two-choice buckets (half the LDS; id spaces of up to 32767 ids per bucket); 2 = 20-bit entries (three eighths more
+// LDS per id than 16-bit ones, id spaces of up to 524286 ids per bucket). wave_prims.h; the host picks by the ids.
+template <int DT, int DIM, int S, int V16 = 0>
 struct FastWalker {
     static constexpr bool F32 = (DT == DT_F32);
     // DIM == 0: any f32 dim >= 32, known at run time. The chunks stream through the registers in groups of
@@ -285,7 +286,7 @@ struct FastWalker {
     uint4 qi8[F32 ? 1 : 4 * NBI]; // i8: bytes 64h..64h+63 of every 128-byte block of the query
     float sy;               // i8: sqrt(sum of squares of the query) as f32
     uint32_t g_nbk, g_ngroups, g_tu; // GEN: full chunks, groups of them, 16-byte units of the (zero padded) tail
-    typename std::conditional<V16, VisitedSet16, VisitedSet>::type vis;
+    typename std::conditional<V16 == 0, VisitedSet, typename std::conditional<V16 == 1, VisitedSet16, VisitedSet20>::type>::type vis;
     WalkList<S> L;
     WalkStats st;
     bool bail;
@@ -612,7 +613,7 @@ struct FastWalker {
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
                                                  bool d0_known = false, float d0_value = 0.0f) {
         PT_RESET();
-        if constexpr (V16) { // `slots` is log2(buckets) here (the host sizes it for the ids' tags: SearchParams)
+        if constexpr (V16 != 0) { // `slots` is log2(buckets) here (the host sizes it for the ids' tags: SearchParams)
             vis.reset(vis_tab, slots, lane);
         } else {
             vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
@@ -627,7 +628,7 @@ struct FastWalker {
         // to the same query was evaluated there: the same operations on the same inputs give the same bits, so
         // the value is reused (the evaluation still counts) and the layer starts one memory round trip earlier.
         pre_nb = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
-        if constexpr (V16) vis.insert(entrypoint, R == 0u, h, p.ovf, lane, bail);
+        if constexpr (V16 != 0) vis.insert(entrypoint, R == 0u, h, p.ovf, lane, bail);
         else vis.insert(entrypoint, lane == 0, p.ovf);
         vis.count = 1;
         st.n_dist += 1;
@@ -680,7 +681,7 @@ struct FastWalker {
 
             // visited set under the loads, then the distances (mod.rs:1026-1027)
             bool fresh;
-            if constexpr (V16) fresh = vis.insert(nb, R < nvalid, h, p.ovf, lane, bail) && h == 0u;
+            if constexpr (V16 != 0) fresh = vis.insert(nb, R < nvalid, h, p.ovf, lane, bail) && h == 0u;
             else fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
             PT_MARK(2); // visited set (under the loads)
             PT_WAIT_VM();
@@ -729,7 +730,7 @@ struct FastWalker {
     }
 };
 
-template <int DT, int DIM, int S, bool TRAIL, bool V16>
+template <int DT, int DIM, int S, bool TRAIL, int V16>
 __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint32_t qi, uint8_t* smem) {
     const uint32_t lane = threadIdx.x;
     if (p.force_slow) {
@@ -843,7 +844,7 @@ constexpr int fast_waves_per_simd(int DT, int DIM, int S) {
 }
 
 // Blocks nq.. are the tail (slow_kernel.h): they serve the hand-over list inside the same launch.
-template <int DT, int DIM, int S, bool TRAIL = false, bool V16 = false>
+template <int DT, int DIM, int S, bool TRAIL = false, int V16 = 0>
 __global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S)) void fast_kernel(const SlowParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     if (blockIdx.x < P.sp.nq) {

@@ -342,15 +342,22 @@ __device__ __forceinline__ uint32_t dpp_pair_swap(uint32_t v) { // the other lan
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
 }
 
-constexpr uint32_t V16_TAG_MAX = 32767u;   // tags 1..32767
+constexpr uint32_t V16_TAG_MAX = 32767u;   // 16-bit entries: tags 1..32767
+constexpr uint32_t V20_TAG_MAX = 524287u;  // 20-bit entries: tags 1..524287
 constexpr uint32_t V16_MIN_LG = 6;         // smallest table: 64 buckets = 1 KB (upper layers)
-__host__ __device__ inline uint32_t v16_lg_for_ids(uint64_t n_ids) { // smallest log2(nb) whose tags hold n_ids ids
+__host__ __device__ inline uint32_t v16_lg_for_ids(uint64_t n_ids, uint32_t tag_max = V16_TAG_MAX) { // smallest log2(nb) whose tags hold n_ids ids
     uint32_t lg = V16_MIN_LG;
-    while (((uint64_t)V16_TAG_MAX << lg) < n_ids && lg < 31) ++lg;
+    while (((uint64_t)tag_max << lg) < n_ids && lg < 31) ++lg;
     return lg;
 }
 
-struct VisitedSet16 {
+// TB = bits of an entry: 16 (8 entries per bucket, tags of 15 bits: up to 32767 ids per bucket) or 20 (6 entries per bucket
+// -- three per 64-bit half, claimed with a 64-bit ds_cmpst -- tags of 19 bits: up to 524286 ids per bucket, which puts
+// the 125M-id shards of BASELINE.json's configs[4] into a 16 KB table). Everything but the probe is shared.
+template <int TB>
+struct VisitedSetB {
+    static_assert(TB == 16 || TB == 20, "entries of 16 or 20 bits");
+    static constexpr uint32_t PER_BUCKET = TB == 16 ? 8u : 6u;
     uint32_t* tab;     // LDS: nb buckets of 4 words
     uint32_t lg;       // log2(nb)
     static constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -396,7 +403,7 @@ struct VisitedSet16 {
     //   both_full it is in neither bucket and both are full: the overflow table decides
     // `pending` stays set for a pair that lost its entry to another pair of the same expansion; it goes round again (and
     // finds the id present if that other pair held the same id: a row that lists a neighbor twice).
-    __device__ __forceinline__ void probe(uint32_t h, uint4* slot4, uint32_t entry, bool& pending, bool& fresh, bool& both_full) {
+    __device__ __forceinline__ void probe16(uint32_t h, uint4* slot4, uint32_t entry, bool& pending, bool& fresh, bool& both_full) {
         const uint4 w = *slot4;
         const uint32_t pat = entry | (entry << 16);
         const uint32_t m = pk_min_u16(pk_min_u16(w.x ^ pat, w.y ^ pat), pk_min_u16(w.z ^ pat, w.w ^ pat));
@@ -425,6 +432,41 @@ struct VisitedSet16 {
         pending = pending & !present & !full2 & !okp;
     }
 
+    // the same with 20-bit entries: a bucket is two 64-bit halves of three entries each (bits 0-19, 20-39, 40-59)
+    __device__ __forceinline__ void probe20(uint32_t h, uint4* slot4, uint32_t entry, bool& pending, bool& fresh, bool& both_full) {
+        const uint4 w = *slot4;
+        const uint32_t M = 0xFFFFFu;
+        const uint32_t f0 = w.x & M, f1 = __builtin_amdgcn_alignbit(w.y, w.x, 20) & M, f2 = (w.y >> 8) & M;
+        const uint32_t f3 = w.z & M, f4 = __builtin_amdgcn_alignbit(w.w, w.z, 20) & M, f5 = (w.w >> 8) & M;
+        const uint32_t match = (uint32_t)(f0 == entry) | (uint32_t)(f1 == entry) | (uint32_t)(f2 == entry) |
+                               (uint32_t)(f3 == entry) | (uint32_t)(f4 == entry) | (uint32_t)(f5 == entry);
+        const uint32_t cnt = (uint32_t)(f0 != 0u) + (uint32_t)(f1 != 0u) + (uint32_t)(f2 != 0u) + (uint32_t)(f3 != 0u) +
+                             (uint32_t)(f4 != 0u) + (uint32_t)(f5 != 0u); // entries fill front to back
+        const uint32_t other = dpp_pair_swap(cnt | (match << 8));
+        const uint32_t cnt_o = other & 0xFFu;
+        const bool present = (match | (other >> 8)) != 0u;
+        const bool full2 = (cnt >= 6u) & (cnt_o >= 6u);
+        const bool mine_emptier = h ? (cnt < cnt_o) : (cnt <= cnt_o);
+        const bool claim = pending & !present & !full2 & mine_emptier;
+        const bool hi = cnt >= 3u;
+        const uint32_t pos = hi ? cnt - 3u : cnt;
+        const uint64_t old = hi ? (((uint64_t)w.w << 32) | w.z) : (((uint64_t)w.y << 32) | w.x);
+        uint32_t ok = 0u;
+        if (claim) {
+            unsigned long long* half = reinterpret_cast<unsigned long long*>(slot4) + (hi ? 1 : 0);
+            const unsigned long long got = atomicCAS(half, (unsigned long long)old, (unsigned long long)(old | ((uint64_t)entry << (pos * 20u))));
+            ok = got == old ? 1u : 0u;
+        }
+        const bool okp = (ok | dpp_pair_swap(ok)) != 0u;
+        fresh = fresh | (pending & okp);
+        both_full = both_full | (pending & !present & full2);
+        pending = pending & !present & !full2 & !okp;
+    }
+    __device__ __forceinline__ void probe(uint32_t h, uint4* slot4, uint32_t entry, bool& pending, bool& fresh, bool& both_full) {
+        if constexpr (TB == 16) probe16(h, slot4, entry, pending, fresh, both_full);
+        else probe20(h, slot4, entry, pending, fresh, both_full);
+    }
+
     // HashSet::insert for the id both lanes of a pair hold (h = lane & 1). `active` is the same in both lanes.
     // Returns true in BOTH lanes iff the id was not present.
     __device__ __forceinline__ bool insert(uint32_t id, bool active, uint32_t h, const OverflowPool& pool, uint32_t lane,
@@ -433,9 +475,8 @@ struct VisitedSet16 {
         const uint32_t q = id >> lg;
         const uint32_t b1 = (id ^ ((q * 0x9E3779B1u) >> sh)) & ((1u << lg) - 1u);
         const uint32_t mine = h ? (b1 ^ (((q * 0x85EBCA6Bu) >> sh) | 1u)) : b1;
-        // tag: 15 bits of q, never 0. While q < 32767 (exact mode: the host sizes the table for it) it names q exactly
-        const uint32_t t15 = (q ^ (q >> 15)) & 0x7FFFu;
-        const uint32_t entry = (t15 ? t15 : 0x7FFFu) | (h << 15);
+        // tag: q + 1 (never 0: 0 is "empty"); the host sizes the table so that it fits the entry's tag bits
+        const uint32_t entry = (q + 1u) | (h << (TB - 1));
         uint4* slot4 = reinterpret_cast<uint4*>(tab) + mine;
         bool pending = active, fresh = false, both_full = false;
 #if GRANNE_HIP_PHASE_TIMERS
@@ -498,5 +539,8 @@ struct VisitedSet16 {
         }
     }
 };
+
+typedef VisitedSetB<16> VisitedSet16;
+typedef VisitedSetB<20> VisitedSet20;
 
 } // namespace granne_hip

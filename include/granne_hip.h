@@ -358,10 +358,11 @@ enum {
                                          as a whole (max_search beyond the register lists) runs up to 32x as many */
     GRANNE_HIP_OPT_OVERFLOW_SLOTS = 5,/* global overflow slots per walk for a full LDS visited table:
                                          0 = auto, 1 = off (such walks go to the slow path), else pow2 */
-    GRANNE_HIP_OPT_VISITED16 = 6,     /* the register walkers' 16-bit two-choice visited table (half the LDS of the
-                                         32-bit one; exact by its tags): 0 = auto (used for max_search <= 252 when the
-                                         index's ids fit the tags -- 32767 ids per bucket -- and VISITED_SLOTS is not
-                                         set), 1 = off */
+    GRANNE_HIP_OPT_VISITED16 = 6,     /* the register walkers' two-choice bucket visited table (exact by its tags): 0 = auto
+                                         (used for max_search <= 252 unless VISITED_SLOTS is set: 16-bit entries -- half
+                                         the LDS of the 32-bit table -- when the index's ids fit their tags, 32767 ids
+                                         per bucket; else 20-bit entries, 524286 ids per bucket), 1 = off, 2 = 20-bit
+                                         entries whatever the ids (tests) */
     GRANNE_HIP_OPT_VISITED16_LG = 7   /* log2 of its bucket count (a bucket = 8 entries = 16 bytes): 0 = auto, else 6..12 */
 };
 int granne_hip_index_set_option(granne_hip_index* index, int option, uint64_t value);

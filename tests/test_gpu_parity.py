@@ -397,12 +397,14 @@ def test_visited_set_spills_to_global_overflow(ga, oracle, int8, ef, lds_slots, 
 
 
 @pytest.mark.parametrize("int8", [False, True])
-@pytest.mark.parametrize("mode,lg,ovf", [(0, 0, 0), (1, 0, 0), (0, 6, 0), (0, 7, 2048), (0, 6, 1), (0, 12, 0)])
+@pytest.mark.parametrize("mode,lg,ovf", [(0, 0, 0), (1, 0, 0), (0, 6, 0), (0, 7, 2048), (0, 6, 1), (0, 12, 0),
+                                         (2, 0, 0), (2, 6, 0), (2, 7, 2048), (2, 6, 1)])
 def test_visited16_modes(ga, oracle, int8, mode, lg, ovf):
-    """The register walkers' 16-bit two-choice visited table (wave_prims.h VisitedSet16): on (auto), off (the 32-bit
-    table), with tables so small (64 buckets = 512 entries) that most ids of a max_search-100 walk find both buckets
-    full and go to the global overflow table, and with the overflow pool off (such walks are handed to the exact
-    walker). Same ids, distance bits and counters in every mode."""
+    """The register walkers' two-choice bucket visited table (wave_prims.h VisitedSetB): 16-bit entries (auto: the ids
+    fit their tags here), off (the 32-bit table), 20-bit entries (mode 2: what id spaces beyond 32767 ids per bucket
+    run -- the 125M-id shards), with tables so small (64 buckets) that most ids of a max_search-100 walk find both
+    buckets full and go to the global overflow table, and with the overflow pool off (such walks are handed to the
+    exact walker). Same ids, distance bits and counters in every mode."""
     from granne_amd import _lib
     rng = np.random.default_rng(160 + 3 * mode + lg + int8)
     el = prep(oracle, random_floats(rng, 6000, 100), int8)
@@ -417,7 +419,7 @@ def test_visited16_modes(ga, oracle, int8, mode, lg, ovf):
         slow = gix.last_slow_count()
         if ovf == 0:
             assert slow == 0, (ef, slow)  # (a 2048-slot overflow table fills up at max_search 200: handed over)
-        elif lg == 6 and ef >= 100 and mode == 0:
+        elif lg == 6 and ef >= 100 and mode != 1:
             assert slow > 0  # no overflow table to spill to: handed over, still the same results
     # members as queries, duplicates of one query in a batch, a batch of one
     assert_same(oix, gix, el[:64], 30, 5)
@@ -441,7 +443,7 @@ def test_visited16_duplicate_neighbor_ids_in_a_row(ga, oracle):
             row[min(used, len(row) - 1)] = row[0]
     dup = oracle.Index(el, layers)
     q = prep(oracle, random_floats(rng, 64, 100), False)
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         gix = ga.Granne("angular", el, layers)
         gix.set_option(_lib.OPT_VISITED16, mode)
         assert_same(dup, gix, q, 50, 10)
