@@ -600,7 +600,7 @@ static search_fn pick_fast_s(uint32_t S, bool trail, int v16 /* 0: 32-bit table,
 static bool fast_shape(const SearchTarget* ix) {
     if (ix->max_dev_width != 32 || ix->n_elements > WALK_MAX_ELEMENTS) return false;
     if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128 || ix->row_bytes == 256 || ix->row_bytes == 512; // dims <= 512
-    return ix->dim >= 32; // 100 and 200 fully unrolled, any other dim with at least one 32-float chunk streamed
+    return true; // f32: 100 and 200 fully unrolled, any other dim streamed (dims below 32: the tail alone)
 }
 static bool fast_generic(const SearchTarget* ix) { return ix->dtype == GRANNE_HIP_F32 && ix->dim != 100 && ix->dim != 200; }
 // the longest max_search the register walker is instantiated for, by shape

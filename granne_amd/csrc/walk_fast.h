@@ -264,7 +264,7 @@ __host__ __device__ inline uint32_t fast_query_bytes(bool i8, bool gen, uint32_t
 template <int DT, int DIM, int S, int V16 = 0>
 struct FastWalker {
     static constexpr bool F32 = (DT == DT_F32);
-    // DIM == 0: any f32 dim >= 32, known at run time. The chunks stream through the registers in groups of
+    // DIM == 0: any f32 dim, known at run time (below 32 the row is its tail only). The chunks stream through the registers in groups of
     // GEN_GROUP (the first group's loads are the ones issued ahead), the query is read from LDS.
     static constexpr bool GEN = F32 && DIM == 0;
     static constexpr int NB = F32 ? (GEN ? (int)GEN_GROUP : DIM / 32) : 0; // full 32-float chunks (GEN: per group)
@@ -357,7 +357,7 @@ struct FastWalker {
     // The element rows of one expansion in flight: lane (R,h) holds half h of row R.
     struct RowRegs {
         float4 v[NB ? NB : 1][4];
-        float4 vt[TU ? TU : 1];
+        float4 vt[GEN ? 8 : (TU ? TU : 1)]; // GEN: the (zero padded) tail, up to 31 floats
         uint4 x[4 * NBI];
         const uint8_t* row; // GEN: the row, for the groups and the tail that finish_rows loads itself
     };
@@ -378,7 +378,12 @@ struct FastWalker {
     __device__ __forceinline__ void issue_rows(uint32_t idl, RowRegs& rr) {
         if constexpr (GEN) {
             rr.row = p.elements + (size_t)idl * p.row_bytes;
-            load_group(rr, 0u);
+            if (g_nbk) load_group(rr, 0u); // (dims below 32 have no full chunk: the row is its tail)
+            // the tail (dim % 32 floats, zero padded to 16-byte units) is read by every lane, used by the odd one
+            const uint8_t* tailp = rr.row + (size_t)g_nbk * 128u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if ((uint32_t)u < g_tu) rr.vt[u] = *reinterpret_cast<const float4*>(tailp + u * 16);
         } else if constexpr (F32) {
             const uint8_t* row = p.elements + (size_t)idl * ROWB;
             const uint8_t* e = row + h * 64u;
@@ -402,12 +407,6 @@ struct FastWalker {
     __device__ __forceinline__ float finish_rows(RowRegs& rr) {
         float d;
         if constexpr (GEN) {
-            // the tail (dim % 32 floats, zero padded to 16-byte units) is read by every lane, used by the odd one
-            float4 vt[8];
-            const uint8_t* tailp = rr.row + (size_t)g_nbk * 128u;
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if ((uint32_t)u < g_tu) vt[u] = *reinterpret_cast<const float4*>(tailp + u * 16);
             float acc[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -436,10 +435,10 @@ struct FastWalker {
             for (int u = 0; u < 8; ++u) {
                 if ((uint32_t)u < g_tu) {
                     const float4 qq = *reinterpret_cast<const float4*>(qtail + u * 16);
-                    r = __builtin_fmaf(vt[u].x, qq.x, r);
-                    r = __builtin_fmaf(vt[u].y, qq.y, r);
-                    r = __builtin_fmaf(vt[u].z, qq.z, r);
-                    r = __builtin_fmaf(vt[u].w, qq.w, r);
+                    r = __builtin_fmaf(rr.vt[u].x, qq.x, r);
+                    r = __builtin_fmaf(rr.vt[u].y, qq.y, r);
+                    r = __builtin_fmaf(rr.vt[u].z, qq.z, r);
+                    r = __builtin_fmaf(rr.vt[u].w, qq.w, r);
                 }
             }
             d = angular_from_dot(r);

@@ -161,6 +161,12 @@ CASES = [
     (700, 128, False, 20, 20),
     (600, 300, False, 30, 30),
     (400, 768, False, 30, 20),
+    # dims below 32 on the same walker: no full chunk, the row is its tail (the reference benches 3-d rows)
+    (500, 1, False, 8, 10),
+    (500, 2, False, 8, 10),
+    (500, 5, False, 12, 20),
+    (600, 16, False, 16, 20),
+    (600, 31, False, 16, 20),
 ]
 
 
@@ -175,7 +181,8 @@ def test_search_parity(ga, oracle, n, dim, int8, nn, ms):
         assert_same(oix, gix, q, max_search, k)
     # the elements themselves as queries (verify_search, src/index/tests.rs:50-62)
     ids, _, _ = assert_same(oix, gix, el[:200], 20, 1)
-    assert (ids[:, 0] == np.arange(200)).mean() > 0.95
+    if dim >= 3:  # (in 1 or 2 dimensions normalised rows coincide: the smallest id among equals wins, for both sides)
+        assert (ids[:, 0] == np.arange(200)).mean() > 0.95
 
 
 def test_get_element_and_neighbors(ga, oracle):
