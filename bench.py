@@ -53,8 +53,9 @@ import time
 # (tools/inflight_probe.py: four streams on the default setting run like two). Must be set before HIP starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # the CPU baseline's OpenMP team: one thread per core, spread over both sockets (read when libgomp loads)
-os.environ.setdefault("OMP_PROC_BIND", "spread")
-os.environ.setdefault("OMP_PLACES", "cores")
+if int(os.environ.get("WORLD_SIZE", "1")) <= 1:  # (several ranks on one host would all bind to the same cores)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np
 
@@ -889,7 +890,12 @@ def partitioned_record(B, args, n, dim, dtype, nq, ef, k, steps, warmup, spg, se
                         and out_d[0].cpu().numpy().tobytes() == w_d.tobytes())
         oix = B.host_index(elements[0], builders[0])
         mi, md, mc = parts[mine[0]]
+        saved = (args.cpu_threads, args.cpu_seconds)
+        if world > 1:  # every rank runs this on the same host: share the cores, keep it short
+            args.cpu_threads = max(1, (os.cpu_count() or 2) // (2 * world))
+            args.cpu_seconds = min(args.cpu_seconds, 0.5)
         cb = B.cpu_baseline(oix, q1.cpu().numpy(), ef, k, mi, md, single_thread_queries=64)
+        args.cpu_threads, args.cpu_seconds = saved
         shard_ok = bool(cb["gpu_matches_oracle"]["ids_bit_exact"] and cb["gpu_matches_oracle"]["dists_bit_exact"])
         ok = torch.tensor([int(merge_ok), int(shard_ok)], dtype=torch.int32, device="cuda")
         if B.use_dist:
