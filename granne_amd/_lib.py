@@ -84,6 +84,7 @@ SIGNATURES = {
     "granne_hip_index_file_info": (i32, [vp, u64, C.POINTER(u32), vp, vp, u32]),
     "granne_hip_index_file_decode_layer": (i32, [vp, u64, u32, vp, vp]),
     "granne_hip_brute_force_device": (i32, [vp, vp, u32, u32, vp, vp, vp, vp]),
+    "granne_hip_brute_force": (i32, [vp, vp, u32, u32, vp, vp, vp]),
     "granne_hip_merge_topk_device": (i32, [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp, i32, vp]),
     "granne_hip_packed_topk_bytes": (u64, [u32, u32]),
     "granne_hip_search_batch_packed_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp]),

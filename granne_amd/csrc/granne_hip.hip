@@ -1259,6 +1259,36 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     return GRANNE_HIP_OK;
 }
 
+// host convenience over the scan: host buffers in and out
+extern "C" int granne_hip_brute_force(const granne_hip_index* ix, const void* queries, uint32_t nq, uint32_t k,
+                                      uint64_t* out_ids, float* out_dists, uint32_t* out_counts) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (nq == 0) return GRANNE_HIP_OK;
+    if (!queries || !out_ids || !out_dists || !out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    if (k == 0 || k > BF_KMAX) return fail(GRANNE_HIP_ERR_INVALID, "k must be in [1, %u]", BF_KMAX);
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+    const size_t qb = (size_t)nq * ix->dim * elem_size(ix->dtype);
+    const size_t o_ids = (qb + 255) & ~(size_t)255, o_d = o_ids + (size_t)nq * k * 8, o_c = o_d + (((size_t)nq * k * 4 + 15) & ~(size_t)15);
+    const size_t total = o_c + (size_t)nq * 4;
+    uint8_t* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, total));
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemcpy(buf, queries, qb, hipMemcpyHostToDevice));
+        int rc = granne_hip_brute_force_device(ix, buf, nq, k, (uint64_t*)(buf + o_ids), (float*)(buf + o_d), (uint32_t*)(buf + o_c), nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out_ids, buf + o_ids, (size_t)nq * k * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_dists, buf + o_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_counts, buf + o_c, (size_t)nq * 4, hipMemcpyDeviceToHost));
+        return GRANNE_HIP_OK;
+    };
+    const int rc = body();
+    (void)hipDeviceSynchronize();
+    (void)hipFree(buf);
+    return rc;
+}
+
 extern "C" int granne_hip_synth_rows_device(float* d_out, uint64_t seed, uint64_t row0, uint64_t n, uint32_t dim,
                                             int device_id, void* stream) {
     if (!d_out && n) return fail(GRANNE_HIP_ERR_INVALID, "out is null");

@@ -155,6 +155,25 @@ public:
         return out;
     }
 
+    // The exact k nearest elements of every query by a scan of all elements on the matrix cores (k <= 16): what
+    // ElementContainer::dists over every index + a sort would give (src/elements/mod.rs:35-39); the recall ground truth.
+    std::vector<std::vector<std::pair<size_t, float>>> brute_force(const Element* elements, size_t nq, size_t k) const {
+        const size_t dim = granne_hip_index_dim(h_.get());
+        std::vector<typename decltype(Element::data)::value_type> q(nq * dim);
+        for (size_t i = 0; i < nq; ++i) {
+            if (elements[i].len() != dim) throw std::runtime_error("query dimension mismatch");
+            std::memcpy(q.data() + i * dim, elements[i].as_slice(), dim * sizeof(q[0]));
+        }
+        std::vector<uint64_t> ids(nq * k);
+        std::vector<float> ds(nq * k);
+        std::vector<uint32_t> counts(nq);
+        check(granne_hip_brute_force(h_.get(), q.data(), (uint32_t)nq, (uint32_t)k, ids.data(), ds.data(), counts.data()));
+        std::vector<std::vector<std::pair<size_t, float>>> out(nq);
+        for (size_t i = 0; i < nq; ++i)
+            for (uint32_t j = 0; j < counts[i]; ++j) out[i].emplace_back((size_t)ids[i * k + j], ds[i * k + j]);
+        return out;
+    }
+
     // Index trait (mod.rs:54-71)
     size_t len() const { return granne_hip_index_len(h_.get()); }
     size_t num_layers() const { return granne_hip_index_num_layers(h_.get()); }

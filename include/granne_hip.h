@@ -245,6 +245,9 @@ int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, co
  * dimensions, int8 rows of up to 128. queries: dense [nq][dim], prepared like the elements. Asynchronous on `stream`. */
 int granne_hip_brute_force_device(const granne_hip_index* index, const void* d_queries, uint32_t nq, uint32_t k,
                                   uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, void* stream);
+/* the same with host buffers in and out (synchronous) */
+int granne_hip_brute_force(const granne_hip_index* index, const void* queries, uint32_t nq, uint32_t k,
+                           uint64_t* out_ids, float* out_dists, uint32_t* out_counts);
 
 /* The per-shard top-k of one batch as ONE buffer -- what a rank contributes to the single exchange
  * step of the partitioned mode (one all-gather, or one peer copy):

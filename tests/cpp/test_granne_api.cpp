@@ -61,6 +61,17 @@ int main(int argc, char** argv) {
         bool threw = false;
         try { index.search(index.get_element(0), 0, 1); } catch (const std::runtime_error&) { threw = true; }
         REQUIRE(threw);
+        // the exact scan (ElementContainer::dists over every index + a sort): a member finds itself first, and the walk's
+        // best hit at a generous max_search is never better than the scan's
+        {
+            auto e7 = index.get_element(7);
+            auto exact = index.brute_force(&e7, 1, 5);
+            REQUIRE(exact.size() == 1 && exact[0].size() == 5);
+            REQUIRE(exact[0][0].first == 7);
+            for (size_t i = 1; i < exact[0].size(); ++i) REQUIRE(exact[0][i - 1].second <= exact[0][i].second);
+            auto walk = index.search(e7, 200, 5);
+            REQUIRE(exact[0][0].second <= walk[0].second);
+        }
         // write_and_load
         index.write_index(tmp + "/cpp_index.granne");
         index.write_elements(tmp + "/cpp_elements.bin");
