@@ -1,55 +1,48 @@
 #!/usr/bin/env python
-"""Would an exact visited table of 16-bit entries hold a max_search-200 walk in the 16 KB the front table has today?
+"""How many ids does the two-choice bucket table of the register walkers (VisitedSetB, granne_amd/csrc/wave_prims.h) hold
+before the first id finds BOTH of its buckets full and goes to the global overflow table?
 
-Today (wave_prims.h): 4096 slots x 32 bits, double hashing, frozen at 5/8 load; everything after that goes to an overflow
-table in global memory (one or more atomicCAS round trips per expansion, queued behind the row loads): 47 % of an
-expansion at max_search 200 with four waves per SIMD (profiles/r2b_phase_i8_ef200_nq4096.txt).
-Candidate: 8192 slots x 16 bits, linear probing; entry = (remainder of a bijective hash, displacement from the home slot),
-home slot = high bits of the hash, so (slot, entry) identifies the id exactly as long as id_bits <= 13 + remainder bits.
-This script replays walks' insert streams (expansions of ~27 new ids, as the walker sees them) and reports, per expansion,
-what the wave would wait for: the slowest lane's number of 8-slot reads (one ds_read_b128 covers 8 consecutive 16-bit
-slots) and the largest displacement (must fit the entry's displacement bits).   Design-space model, not product code."""
-import random
-import statistics
+Placement as in the kernel: an id's two buckets are independent of each other, it goes to the emptier one (ties: the
+first), buckets hold 8 entries (16-bit entries) or 6 (20-bit entries) and never lose one.  Printed per table size: the
+number of ids inserted when the first one spilled (min / 1 % / 10 % / median over the trials) and the load that is.
+A max_search-50 walk on 10M uniform points visits 1,990 +- 240 ids, a max_search-200 walk ~7,000.
+
+Round 2's model of a 16-bit table with linear probing (home slot + remainder + displacement) is in the git history:
+its displacements outgrow four bits at the loads a walk reaches, which is why the table has buckets and two choices.
+Design-space model, not product code."""
 import sys
 
+import numpy as np
 
-def replay(n_ids, slots, per_exp, rnd, id_bits=24):
-    tab = [None] * slots
-    reads_hist, disp_max, fails = [], 0, 0
-    inserted = 0
-    while inserted < n_ids:
-        ids = [rnd.getrandbits(id_bits) for _ in range(per_exp)]
-        worst = 0
-        for i in ids:
-            h = (i * 0x9E3779B1) & 0xFFFFFFFF
-            home = (h * slots) >> 32
-            d = 0
-            while tab[(home + d) % slots] is not None and tab[(home + d) % slots] != i:
-                d += 1
-            tab[(home + d) % slots] = i
-            disp_max = max(disp_max, d)
-            first, last = home // 8, (home + d) // 8  # 8-slot groups touched by the probe sequence
-            worst = max(worst, last - first + 1)
-        inserted += per_exp
-        reads_hist.append((inserted / slots, worst))
-    return reads_hist, disp_max
+
+def first_spill(nb, per_bucket, trials, rng):
+    out = []
+    n = nb * per_bucket
+    for _ in range(trials):
+        cnt = np.zeros(nb, np.int32)
+        b1 = rng.integers(0, nb, n)
+        b2 = b1 ^ rng.integers(1, nb, n)  # never the same bucket (the kernel xors an odd function of the tag)
+        f = n
+        for i in range(n):
+            a, b = b1[i], b2[i]
+            c = a if cnt[a] <= cnt[b] else b
+            if cnt[c] >= per_bucket:
+                f = i
+                break
+            cnt[c] += 1
+        out.append(f)
+    return np.array(out)
 
 
 def main():
-    rnd = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-    for n_ids, slots in ((2100, 4096), (2100, 8192), (6500, 8192), (6500, 12288), (8000, 8192)):
-        worst_all, disp_all = [], []
-        late = []
-        for _ in range(200):
-            hist, disp = replay(n_ids, slots, 27, rnd)
-            worst_all += [w for _, w in hist]
-            late += [w for load, w in hist if load > 0.9 * n_ids / slots]
-            disp_all.append(disp)
-        print("%5d ids into %5d 16-bit slots (%4.1f KB, final load %.2f): 8-slot reads of the slowest lane per expansion "
-              "mean %.2f, at the end of the walk %.2f, max %d | largest displacement: median %d, max %d"
-              % (n_ids, slots, slots * 2 / 1024, n_ids / slots, statistics.mean(worst_all), statistics.mean(late),
-                 max(worst_all), statistics.median(disp_all), max(disp_all)))
+    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    for bits, per in ((16, 8), (20, 6)):
+        for lg in (6, 9, 10, 11):
+            nb = 1 << lg
+            fa = first_spill(nb, per, 100 if lg >= 10 else 300, rng)
+            print("%d-bit entries, %4d buckets x %d (%4.1f KB): first spill after min %5d, 1 %% %5d, 10 %% %5d, median %5d ids "
+                  "(load %.2f)" % (bits, nb, per, nb * 16 / 1024, fa.min(), np.percentile(fa, 1), np.percentile(fa, 10),
+                                  np.median(fa), np.median(fa) / (nb * per)))
 
 
 if __name__ == "__main__":
