@@ -19,7 +19,7 @@ per-shard top-k (RCCL), then the merge kernel; a step = one batch through search
 
 Rank 0 prints ONE JSON line. Besides the contract fields it carries
   roofline      HBM roofline of the dominant kernel: algorithmic bytes per launch (SURVEY.md 8d:
-                n_dist*d*s + 4*n_adj + d*s + 8*k per query, from the kernel's own exact counters) /
+                n_dist*d*s + 4*n_adj + d*s + 8*k per query, n_dist = the reference's count of distinct nodes) /
                 mean launch duration from HIP events recorded around the kernel on its stream
   cpu_baseline  the CPU oracle (restatement of the reference's search, OpenMP over queries = the
                 caller-side rayon par_iter) timed on this box's host cores on a bounded sample of
@@ -328,7 +328,34 @@ class Bench:
             glib.granne_hip_event_destroy(a)
             glib.granne_hip_event_destroy(b)
 
-        st = stats[warmup:].sum(dim=(0, 1)).cpu().numpy().astype(np.float64)  # n_dist, n_expand, n_adj
+        # The algorithmic bytes are the REFERENCE algorithm's: its search evaluates every distinct node once (HashSet,
+        # mod.rs:1026). The timed walkers keep no visited set and evaluate a revisited neighbor again (~3 % more rows
+        # on this data; wave_prims.h VisitedNone) -- so the counters come from one more, untimed pass over the same K
+        # batches with the exact bucket tables switched on, whose results must be the timed pass's, bit for bit.
+        evaluated = float(stats[warmup:, :, 0].sum().item())
+        ids_x = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        dists_x = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        counts_x = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        stats_x = torch.zeros((steps, nq, 3), dtype=torch.int64, device="cuda")
+        mode = index.get_option(_glib.OPT_VISITED16)
+        index.set_option(_glib.OPT_VISITED16, 3)
+        same = True
+        try:
+            for i in range(steps):
+                b = warmup + i
+                index.search_batch_device(queries[b * nq:(b + 1) * nq].data_ptr(), nq, ef, k, ids_x.data_ptr(),
+                                          dists_x.data_ptr(), counts_x.data_ptr(), stats_x[i].data_ptr(),
+                                          status.data_ptr(), self.stream)
+                torch.cuda.synchronize()
+                same = same and bool((ids_x == ids[b]).all().item()) and bool((counts_x == counts[b]).all().item()) \
+                    and bool((dists_x.view(torch.int32) == dists[b].view(torch.int32)).all().item())
+        finally:
+            index.set_option(_glib.OPT_VISITED16, mode)
+        if not same:
+            raise RuntimeError("the walk without a visited set and the walk with the exact tables returned different results")
+        if not bool((stats_x[:, :, 1:] == stats[warmup:, :, 1:]).all().item()):
+            raise RuntimeError("expansion / adjacency counters differ between the two forms of the walk")
+        st = stats_x.sum(dim=(0, 1)).cpu().numpy().astype(np.float64)  # n_dist, n_expand, n_adj (the reference's counts)
         alg_total = st[0] * dim * esize + st[2] * 4 + steps * nq * (dim * esize + k * 8)
         alg_per_launch = alg_total / steps
         mean_ms = float(np.mean(step_ms))
@@ -340,7 +367,8 @@ class Bench:
             "alg_per_launch": alg_per_launch, "achieved": achieved, "launch_ms_mean": mean_ms,
             "launch_ms_min": float(np.min(step_ms)), "call_ms_mean": float(np.mean(call_ms)),
             "per_query": {"n_dist": round(st[0] / (steps * nq), 1), "n_expand": round(st[1] / (steps * nq), 1),
-                          "n_adj": round(st[2] / (steps * nq), 1)},
+                          "n_adj": round(st[2] / (steps * nq), 1), "rows_evaluated": round(evaluated / (steps * nq), 1)},
+            "same_as_exact_set_walk": {"queries": steps * nq, "ids_dists_counts_bit_exact": True},
         }
 
     def roofline(self, m, traffic_key, value_per_gpu, nq):
@@ -362,7 +390,7 @@ class Bench:
             "aggregate_frac_with_inflight": round(m["alg_per_launch"] * (value_per_gpu / nq) / 1e9 / HBM_PEAK_GBPS, 4),
             "alg_bytes_per_launch": int(m["alg_per_launch"]), "launch_ms_mean": round(m["launch_ms_mean"], 4),
             "launch_ms_min": round(m["launch_ms_min"], 4), "call_ms_mean": round(m["call_ms_mean"], 4),
-            "per_query": m["per_query"],
+            "per_query": m["per_query"], "same_as_exact_set_walk": m["same_as_exact_set_walk"],
         }
         if note:
             r["traffic_note"] = note

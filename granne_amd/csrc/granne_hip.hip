@@ -467,7 +467,7 @@ extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uin
         ix->opt_overflow_slots = value;
         return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_VISITED16:
-        if (value > 2) return fail(GRANNE_HIP_ERR_INVALID, "visited16 must be 0 (auto), 1 (off) or 2 (20-bit entries whatever the ids)");
+        if (value > 4) return fail(GRANNE_HIP_ERR_INVALID, "visited16 must be 0 (auto), 1 (32-bit table), 2 (20-bit entries), 3 (16- or 20-bit entries by the ids) or 4 (none)");
         ix->opt_visited16 = value;
         return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_VISITED16_LG:
@@ -543,7 +543,7 @@ typedef void (*search_fn)(const SlowParams);
 
 // experiment knobs, read once per process
 struct EnvKnobs {
-    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, v16 = 1, v16_lg = 0, tail_blocks = -1;
+    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, v16_lg = 0, tail_blocks = -1;
     EnvKnobs() {
         auto geti = [](const char* name, int dflt) {
             const char* e = getenv(name);
@@ -553,7 +553,7 @@ struct EnvKnobs {
         front_eighths = geti("GRANNE_HIP_FRONT_EIGHTHS", 0);
         maxc = geti("GRANNE_HIP_MAXC", 0);
         lds_pad = geti("GRANNE_HIP_LDS_PAD", 0);
-        v16 = geti("GRANNE_HIP_V16", 1);       // 0: always the 32-bit visited table
+        visited = geti("GRANNE_HIP_VISITED", 0); // GRANNE_HIP_OPT_VISITED16's values, where the option says auto
         v16_lg = geti("GRANNE_HIP_V16_LG", 0); // log2(buckets) of the 16-bit table
     }
 };
@@ -584,17 +584,26 @@ static search_fn pick_kernel(int dtype, uint32_t ef) {
 // end hands the walk over -- with spare places that takes a run of ties.
 constexpr uint32_t FAST_MAX_SEARCH = 1024;
 static uint32_t fast_list_slots(uint32_t ef) { return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : 17u; }
+// v16: the form of the visited set (FastWalker's V16): 0 = 32-bit table, 1 = 16-bit entries, 2 = 20-bit entries, 3 = none
+template <int DT, int DIM, int S>
+static search_fn pick_fast_v(int v16) {
+    if (v16 == 3) return fast_kernel<DT, DIM, S, false, 3>;
+    if constexpr (!(DT == DT_I8 && DIM >= 256)) { // (wide int8 rows: no 20-bit instantiation)
+        if (v16 == 2) return fast_kernel<DT, DIM, S, false, 2>;
+    }
+    return v16 ? fast_kernel<DT, DIM, S, false, 1> : fast_kernel<DT, DIM, S>;
+}
 template <int DT, int DIM>
-static search_fn pick_fast_s(uint32_t S, bool trail, int v16 /* 0: 32-bit table, 1: 16-bit entries, 2: 20-bit entries */) {
+static search_fn pick_fast_s(uint32_t S, bool trail, int v16) {
     if (trail) return fast_kernel<DT, DIM, 1, true>;
     switch (S) {
-    case 1: return v16 == 2 ? fast_kernel<DT, DIM, 1, false, 2> : v16 ? fast_kernel<DT, DIM, 1, false, 1> : fast_kernel<DT, DIM, 1>;
-    case 2: return v16 == 2 ? fast_kernel<DT, DIM, 2, false, 2> : v16 ? fast_kernel<DT, DIM, 2, false, 1> : fast_kernel<DT, DIM, 2>;
-    case 4: return v16 == 2 ? fast_kernel<DT, DIM, 4, false, 2> : v16 ? fast_kernel<DT, DIM, 4, false, 1> : fast_kernel<DT, DIM, 4>;
-    case 8: return fast_kernel<DT, DIM, 8>;
+    case 1: return pick_fast_v<DT, DIM, 1>(v16);
+    case 2: return pick_fast_v<DT, DIM, 2>(v16);
+    case 4: return pick_fast_v<DT, DIM, 4>(v16);
+    case 8: return v16 == 3 ? fast_kernel<DT, DIM, 8, false, 3> : fast_kernel<DT, DIM, 8>;
     default:
         if constexpr (DT == DT_F32 && DIM == 0) return fast_kernel<DT, DIM, 8>; // not reached: max_search <= 508 there
-        else return fast_kernel<DT, DIM, 17>;
+        else return v16 == 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
     }
 }
 static bool fast_shape(const SearchTarget* ix) {
@@ -610,12 +619,12 @@ static uint32_t fast_max_search(const SearchTarget* ix) {
 }
 // int8 rows of 256 / 512 bytes (dims 129..512, e.g. the 200- and 300-d rows of benches/distance_computation.rs:29-39)
 template <int ROWB>
-static search_fn pick_fast_i8_wide(uint32_t S, bool trail, int v16) { // (16-bit entries or the 32-bit table)
+static search_fn pick_fast_i8_wide(uint32_t S, bool trail, int v16) {
     if (trail) return fast_kernel<DT_I8, ROWB, 1, true>;
     switch (S) {
-    case 1: return v16 ? fast_kernel<DT_I8, ROWB, 1, false, 1> : fast_kernel<DT_I8, ROWB, 1>;
-    case 2: return v16 ? fast_kernel<DT_I8, ROWB, 2, false, 1> : fast_kernel<DT_I8, ROWB, 2>;
-    default: return v16 ? fast_kernel<DT_I8, ROWB, 4, false, 1> : fast_kernel<DT_I8, ROWB, 4>;
+    case 1: return pick_fast_v<DT_I8, ROWB, 1>(v16);
+    case 2: return pick_fast_v<DT_I8, ROWB, 2>(v16);
+    default: return pick_fast_v<DT_I8, ROWB, 4>(v16);
     }
 }
 static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail, int v16) {
@@ -646,7 +655,26 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
     // 8 KB at max_search 50 (the 32-bit table: 16 KB), so twice the walkers fit a CU's LDS.
     // Id spaces beyond the 16-bit entries' tags (32767 ids per bucket: 125M ids would need 64 KB) take 20-bit entries
     // (524286 ids per bucket, six entries per bucket instead of eight); wide int8 rows have no 20-bit instantiation.
-    if (fastS >= 1 && fastS <= 4 && !trail && knobs().v16 && !ix->opt_visited_slots && ix->opt_visited16 != 1) {
+    // Lists of up to 256 keys walk without a visited set (VisitedNone, wave_prims.h: the list itself is searched for a
+    // candidate's id): no table in LDS, only the query's staging area and what a tail block needs.
+    // Measured against the exact tables below (10M x 100-d): equal to 5 % faster per launch at max_search
+    // 50, 3-4 % slower at 100, 17-31 % faster at 200 with 4096 queries, 30-40 % faster at 400-800; with batches in
+    // flight never slower and up to twice as fast -- no LDS bounds the walkers per CU, nothing spills.
+    const int vmode = ix->opt_visited16 ? ix->opt_visited16 : knobs().visited;
+    const bool none = vmode == 4 || vmode == 0;
+    if (fastS >= 1 && !trail && none && !ix->opt_visited_slots && ix->n_elements < WALK_MAX_ELEMENTS) {
+        P.v16 = 3;
+        P.visited_slots = P.upper_slots = 0;
+        P.maxc = 0;
+        P.lrow_bytes = 16;
+        P.stage_bytes = 0;
+        P.adjspec_bytes = 0;
+        P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, 0u);
+        const uint32_t least = lds_query_bytes(ix->row_bytes) + 64u * 8u; // int8 query staging; a tail block (slow_kernel.h)
+        if (P.lds_bytes < least) P.lds_bytes = least;
+        return P;
+    }
+    if (fastS >= 1 && fastS <= 4 && !trail && vmode != 1 && !ix->opt_visited_slots) {
         uint32_t lg = V16_MIN_LG;
         while ((1u << lg) < ef * 8u) ++lg;
         // big launches keep more walkers resident with a smaller table and let the largest walks spill
@@ -658,7 +686,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         const bool wide_i8 = ix->dtype == GRANNE_HIP_I8 && ix->row_bytes != 128;
         int kind = 0;
         uint32_t lg_ids = v16_lg_for_ids(ix->n_elements, V16_TAG_MAX);
-        if (lg_ids <= lg && ix->opt_visited16 != 2) {
+        if (lg_ids <= lg && vmode != 2) {
             kind = 1;
         } else if (!wide_i8) {
             lg_ids = v16_lg_for_ids(ix->n_elements, V20_TAG_MAX);
@@ -798,7 +826,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     // visited-set overflow pool: one table per walker that can be resident at once (bounded by
     // LDS: 160 KiB per CU, and by 32 waves per CU), at most one per query
     uint32_t ovf_slots = 0, ovf_regions = 0;
-    if (!all_slow && ix->opt_overflow_slots != 1) {
+    if (!all_slow && ix->opt_overflow_slots != 1 && plan.v16 != 3) { // (no visited set, no overflow)
         ovf_slots = ix->opt_overflow_slots ? next_pow2((uint32_t)ix->opt_overflow_slots) : next_pow2(ef_walk * 64u);
         if (!ix->opt_overflow_slots && ovf_slots < 4096) ovf_slots = 4096;
         if (ovf_slots < 512) ovf_slots = 512;

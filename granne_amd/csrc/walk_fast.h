@@ -136,6 +136,13 @@ struct WalkList : SortedList<S> {
         return lost;
     }
 
+    // is node `id` (wave-uniform) in the list, at any of its CAP places? (an unused place reads 0x7FFFFFFF: no node's id)
+    __device__ __forceinline__ bool holds(uint32_t id) const {
+        bool hit = false;
+#pragma unroll
+        for (int s = 0; s < S; ++s) hit = hit || (((uint32_t)key[s]) >> 1) == id;
+        return wave_ballot(hit) != 0;
+    }
     // position of the first entry whose expanded flag is clear (KEY_INF has it set)
     __device__ __forceinline__ bool first_unexpanded(uint32_t& pos) const {
 #pragma unroll
@@ -286,7 +293,10 @@ struct FastWalker {
     uint4 qi8[F32 ? 1 : 4 * NBI]; // i8: bytes 64h..64h+63 of every 128-byte block of the query
     float sy;               // i8: sqrt(sum of squares of the query) as f32
     uint32_t g_nbk, g_ngroups, g_tu; // GEN: full chunks, groups of them, 16-byte units of the (zero padded) tail
-    typename std::conditional<V16 == 0, VisitedSet, typename std::conditional<V16 == 1, VisitedSet16, VisitedSet20>::type>::type vis;
+    static constexpr bool NOVIS = V16 == 3; // no visited set: the list is searched for a candidate's id (VisitedNone, wave_prims.h)
+    typename std::conditional<V16 == 0, VisitedSet,
+        typename std::conditional<V16 == 1, VisitedSet16,
+            typename std::conditional<V16 == 2, VisitedSet20, VisitedNone>::type>::type>::type vis;
     WalkList<S> L;
     WalkStats st;
     bool bail;
@@ -571,6 +581,18 @@ struct FastWalker {
         return pass;
     }
 
+    // Without a visited set, lists merged in bulk: of the candidates that passed the filter, drop the ones whose id the
+    // list holds -- all CAP entries, expanded or not -- and the second of two lanes with one id (a row that names a
+    // neighbor twice). (Short lists look a candidate up right before inserting it: insert(), and the next-node decision.)
+    __device__ __forceinline__ uint64_t drop_known(uint64_t pm, bool pass, uint32_t nb) const {
+        for (uint64_t it = pm; it; it &= it - 1) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(it);
+            const uint32_t id = readlane32(nb, j);
+            if (L.holds(id) || wave_ballot(pass && nb == id && lane < j)) pm &= ~(1ull << j);
+        }
+        return pm;
+    }
+
     // pq.push (mod.rs:1030) of the lanes in pm. Short lists take the candidates one at a time (insert_sorted:
     // a dozen vector operations each, nothing scalar in the chain); lists that keep an LDS mirror are merged
     // in bulk. An entry pushed off the end is dead unless its distance ties with the entry that is number
@@ -587,6 +609,9 @@ struct FastWalker {
         uint32_t lost = 0xFFFFFFFFu;
         for (uint64_t it = pm; it; it &= it - 1) {
             const uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(it));
+            if constexpr (NOVIS) { // in the list already (a revisit, or the row names the node twice): not a candidate
+                if (L.holds(wkey_id(K))) continue;
+            }
             const uint32_t l = L.insert_sorted(K, lane);
             lost = l < lost ? l : lost;
         }
@@ -612,7 +637,8 @@ struct FastWalker {
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
                                                  bool d0_known = false, float d0_value = 0.0f) {
         PT_RESET();
-        if constexpr (V16 != 0) { // `slots` is log2(buckets) here (the host sizes it for the ids' tags: SearchParams)
+        if constexpr (NOVIS) {
+        } else if constexpr (V16 != 0) { // `slots` is log2(buckets) here (the host sizes it for the ids' tags: SearchParams)
             vis.reset(vis_tab, slots, lane);
         } else {
             vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
@@ -627,7 +653,8 @@ struct FastWalker {
         // to the same query was evaluated there: the same operations on the same inputs give the same bits, so
         // the value is reused (the evaluation still counts) and the layer starts one memory round trip earlier.
         pre_nb = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
-        if constexpr (V16 != 0) vis.insert(entrypoint, R == 0u, h, p.ovf, lane, bail);
+        if constexpr (NOVIS) {}
+        else if constexpr (V16 != 0) vis.insert(entrypoint, R == 0u, h, p.ovf, lane, bail);
         else vis.insert(entrypoint, lane == 0, p.ovf);
         vis.count = 1;
         st.n_dist += 1;
@@ -680,7 +707,8 @@ struct FastWalker {
 
             // visited set under the loads, then the distances (mod.rs:1026-1027)
             bool fresh;
-            if constexpr (V16 != 0) fresh = vis.insert(nb, R < nvalid, h, p.ovf, lane, bail) && h == 0u;
+            if constexpr (NOVIS) fresh = h == 0u && R < nvalid; // every neighbor is evaluated
+            else if constexpr (V16 != 0) fresh = vis.insert(nb, R < nvalid, h, p.ovf, lane, bail) && h == 0u;
             else fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
             PT_MARK(2); // visited set (under the loads)
             PT_WAIT_VM();
@@ -693,22 +721,37 @@ struct FastWalker {
             PT_PIN(d);
             PT_MARK(4); // distances
             const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
-            const bool pass = filter(cand, d, ef);
+            bool pass = filter(cand, d, ef);
             const uint64_t ck = wkey(d, nb);
-            const uint64_t pm = wave_ballot(pass);
+            uint64_t pm = wave_ballot(pass);
+            if constexpr (NOVIS && WalkList<S>::MIRROR) { // bulk merge: the candidates the list holds already leave first
+                pm = drop_known(pm, pass, nb);
+                pass = (pm >> lane) & 1ull;
+            }
             // a candidate that sorts before y is expanded next (the smallest such): request its adjacency row now
             // (not with 800-byte rows: the walk is bandwidth-bound there and the kernel sits at its 168-register limit)
             uint64_t beat = (F32 && DIM > 128) ? 0ull : wave_ballot(pass && ck < ykey); // ykey = KEY_INF without y: every passing candidate
             [[maybe_unused]] const bool beat0 = beat != 0;
-            if (beat) {
+            while (beat) {
                 uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
                 for (;;) { // usually one or two rounds
                     beat = wave_ballot(pass && ck < K);
                     if (!beat) break;
                     K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
                 }
+                if constexpr (NOVIS && !WalkList<S>::MIRROR) {
+                    // a revisited node that is in the list (an expanded one sorts before y, always) is no candidate:
+                    // out it goes, the next smallest is looked at
+                    if (L.holds(wkey_id(K))) {
+                        pass = pass && ck != K;
+                        pm = wave_ballot(pass);
+                        beat = wave_ballot(pass && ck < ykey);
+                        continue;
+                    }
+                }
                 pre_id = wkey_id(K);
                 pre_nb = adjg[(size_t)pre_id * 32u + R];
+                break;
             }
             PT_MARK(5); // filter, next-node decision, its adjacency request
             {

@@ -543,4 +543,22 @@ struct VisitedSetB {
 typedef VisitedSetB<16> VisitedSet16;
 typedef VisitedSetB<20> VisitedSet20;
 
+// No visited set at all (the register walkers with lists of up to 256 keys: FastWalker<.., V16 = 3>).
+// The reference's HashSet (mod.rs:1008,1016,1026) keeps a node from being evaluated twice; in a walk whose lanes
+// evaluate a whole adjacency row at once -- rows requested before anything is known about their ids -- a second
+// evaluation costs nothing that was not already spent, and what it must not do is enter the list twice. It cannot:
+//  * a node rejected by `distance < res.peek()` (mod.rs:1029) is rejected again, res.peek() only decreases;
+//  * a node that is in the list (expanded or not, including the entries past max_search) is found there by id;
+//  * a node that was pushed off the list's end has CAP keys below its own and the same key again: it falls off again.
+// So the results are the reference's, bit for bit, and the set's LDS, its instructions, its overflow tables and its
+// hand-overs are gone; WalkStats::n_dist counts evaluations (revisits included), no longer distinct nodes.
+struct VisitedNone {
+    uint32_t count = 0;
+    uint32_t pt_rounds = 0;
+    __device__ __forceinline__ void init_walker() {}
+    __device__ __forceinline__ void added(uint32_t) {}
+    __device__ __forceinline__ bool make_room(const OverflowPool&, uint32_t) { return true; }
+    __device__ __forceinline__ void release(const OverflowPool&, uint32_t) {}
+};
+
 } // namespace granne_hip

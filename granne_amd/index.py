@@ -222,6 +222,12 @@ class Granne:
     def set_option(self, option, value):
         check(lib().granne_hip_index_set_option(self._h, option, value))
 
+    def get_option(self, option):
+        import ctypes as C
+        v = C.c_uint64(0)
+        check(lib().granne_hip_index_get_option(self._h, option, C.byref(v)))
+        return int(v.value)
+
     def last_slow_count(self):
         return int(lib().granne_hip_index_last_slow_count(self._h))
 

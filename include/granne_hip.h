@@ -361,11 +361,15 @@ enum {
                                          as a whole (max_search beyond the register lists) runs up to 32x as many */
     GRANNE_HIP_OPT_OVERFLOW_SLOTS = 5,/* global overflow slots per walk for a full LDS visited table:
                                          0 = auto, 1 = off (such walks go to the slow path), else pow2 */
-    GRANNE_HIP_OPT_VISITED16 = 6,     /* the register walkers' two-choice bucket visited table (exact by its tags): 0 = auto
-                                         (used for max_search <= 252 unless VISITED_SLOTS is set: 16-bit entries -- half
-                                         the LDS of the 32-bit table -- when the index's ids fit their tags, 32767 ids
-                                         per bucket; else 20-bit entries, 524286 ids per bucket), 1 = off, 2 = 20-bit
-                                         entries whatever the ids (tests) */
+    GRANNE_HIP_OPT_VISITED16 = 6,     /* the visited set of the register walkers (unless VISITED_SLOTS is set):
+                                         0 = auto = 4 = NONE -- every neighbor is evaluated and the list itself is
+                                         searched for a candidate's id; the results are the reference's, the n_dist
+                                         counter counts evaluations instead of distinct nodes
+                                         (granne_amd/csrc/wave_prims.h, VisitedNone). The exact sets, with which n_dist
+                                         is the reference's count: 1 = the 32-bit table; 3 = for max_search <= 252
+                                         two-choice buckets of 16-bit entries when the index's ids fit their tags
+                                         (32767 ids per bucket), else of 20-bit entries (524286 ids per bucket), the
+                                         32-bit table beyond; 2 = the same with 20-bit entries whatever the ids */
     GRANNE_HIP_OPT_VISITED16_LG = 7   /* log2 of its bucket count (a bucket = 8 entries = 16 bytes): 0 = auto, else 6..12 */
 };
 int granne_hip_index_set_option(granne_hip_index* index, int option, uint64_t value);

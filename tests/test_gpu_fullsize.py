@@ -16,6 +16,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import assert_counters  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 N100 = int(os.environ.get("GRANNE_FULLSIZE_N", "10000000"))
@@ -126,7 +128,13 @@ def test_bit_exact_against_the_oracle_on_the_bench_graph(built, oracle):
         assert (cnt == oc).all()
         assert (ids == oi).all(), (ms, int((ids != oi).any(axis=1).sum()))
         assert ds.tobytes() == od.tobytes()
-        assert (st == octr).all()
+        assert_counters(st, octr, exact=False)  # the default walkers keep no visited set: n_dist counts evaluations
+        if ms == 50:  # the same walk with the exact bucket tables: every counter the reference's
+            ix.set_option(_lib.OPT_VISITED16, 3)
+            ids3, ds3, cnt3, st3 = ix.search_batch(queries[:nq], ms, k, stats=True)
+            ix.set_option(_lib.OPT_VISITED16, 0)
+            assert (ids3 == oi).all() and ds3.tobytes() == od.tobytes()
+            assert_counters(st3, octr, exact=True)
     assert ix.last_slow_count() == 0
 
 
