@@ -50,8 +50,9 @@ import time
 
 # Batches in flight run on HIP streams of their own; HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware
 # queues (default 4, one of them the null stream's), and two streams that share a queue run one after the other
-# (tools/inflight_probe.py: four streams on the default setting run like two). Must be set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (tools/inflight_probe.py: four streams on the default setting run like two; n streams on n queues fall back too --
+# one queue is shared -- so there are more queues than streams). Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 # the CPU baseline's OpenMP team: one thread per core, spread over both sockets (read when libgomp loads)
 if int(os.environ.get("WORLD_SIZE", "1")) <= 1:  # (several ranks on one host would all bind to the same cores)
     os.environ.setdefault("OMP_PROC_BIND", "spread")
@@ -123,8 +124,18 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def auto_inflight(args, dtype):
-    return max(1, args.inflight) if args.inflight else (4 if dtype == "f32" else 6)
+def auto_inflight(args, dtype, steps):
+    """Batches in flight (step i goes to stream i % inflight). Where more stop paying (profiles/r3_inflight_novis.txt):
+    f32 walks fill the memory system with six (6.2-6.3 M queries/s from six to twelve), int8 walks -- a quarter of the
+    bytes, eight waves per SIMD -- with twelve. The K timed steps are few (the driver times 20): a count that divides K
+    keeps the last round as full as the others, so the nearest divisor of K not below three quarters of that is taken."""
+    if args.inflight:
+        return max(1, args.inflight)
+    best = 6 if dtype == "f32" else 12
+    for d in range(best, (3 * best + 3) // 4 - 1, -1):
+        if steps % d == 0:
+            return d
+    return best
 
 
 def workload_label(n, dim, dtype, data, nq, ef, k):
@@ -171,7 +182,7 @@ class Bench:
         self.sp = C.c_void_p(self.stream)
         # the in-flight streams, created ONCE: HIP assigns hardware queues at stream creation, so every measurement of
         # a run sees the same stream-to-queue mapping
-        self.streams = [torch.cuda.Stream() for _ in range(8)]
+        self.streams = [torch.cuda.Stream() for _ in range(16)]
 
     # ---- synthetic rows, generated and prepared on the device ---------------------------------------
     def synth_raw(self, seed, row0, rows, dim):
@@ -332,6 +343,7 @@ class Bench:
         # mod.rs:1026). The timed walkers keep no visited set and evaluate a revisited neighbor again (~3 % more rows
         # on this data; wave_prims.h VisitedNone) -- so the counters come from one more, untimed pass over the same K
         # batches with the exact bucket tables switched on, whose results must be the timed pass's, bit for bit.
+        slow_n, spill_n = int(status[1].item()), int(status[2].item())  # (of the timed forms of the walk, not of the counting pass)
         evaluated = float(stats[warmup:, :, 0].sum().item())
         ids_x = torch.empty((nq, k), dtype=torch.int64, device="cuda")
         dists_x = torch.empty((nq, k), dtype=torch.float32, device="cuda")
@@ -363,7 +375,7 @@ class Bench:
         return {
             "elapsed": elapsed, "value_local": steps * nq / elapsed, "seq_elapsed": seq_elapsed, "steady": steady,
             "ids": ids, "dists": dists, "counts": counts, "status": status, "inflight": inflight,
-            "slow": int(status[1].item()), "spill": int(status[2].item()),
+            "slow": slow_n, "spill": spill_n,
             "alg_per_launch": alg_per_launch, "achieved": achieved, "launch_ms_mean": mean_ms,
             "launch_ms_min": float(np.min(step_ms)), "call_ms_mean": float(np.mean(call_ms)),
             "per_query": {"n_dist": round(st[0] / (steps * nq), 1), "n_expand": round(st[1] / (steps * nq), 1),
@@ -625,7 +637,7 @@ def run_replica(B, args):
     n, dim, nq, ef, k = args.n, args.dim, args.batch, args.ef, args.k
     esize = 4 if args.dtype == "f32" else 1
     n_batches = args.warmup + args.steps
-    inflight = auto_inflight(args, args.dtype)
+    inflight = auto_inflight(args, args.dtype, args.steps)
 
     t0 = time.time()
     elements = B.rows(args.data, SEED, 0, n, dim, args.dtype)
@@ -741,7 +753,7 @@ def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=
     bf = {}
     gt = B.ground_truth(index, queries[warmup * nq:warmup * nq + rq], k, dtype, timing=bf)
     gt_dists = B._gt_dists
-    inflight = auto_inflight(args, dtype)
+    inflight = auto_inflight(args, dtype, steps)
     layer_sizes = [builder.layer_len(l) for l in range(builder.num_layers())]
     rec = {"workload": workload_label(n, dim, dtype, data, nq, ef, k), "dtype": dtype, "data": "synthetic",
            "n_elements": n, "dim": dim, "layers": layer_sizes, "build_s": round(t_build, 1),

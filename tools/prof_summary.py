@@ -2,16 +2,26 @@
 import csv, glob, os, sys, collections, statistics
 root = sys.argv[1]; out = sys.argv[2]
 lines = []
+# bench.py also walks its timed batches once with the exact visited tables (the counting pass: fast_kernel<.., 1> / <.., 2>);
+# the launches summarised here are the timed form's (fast_kernel<.., 3>: no visited set) whenever the trace holds any
+TIMED = ", 3>("
+
+
+def timed_only(names):
+    return any(TIMED in n for n in names)
 # kernel trace
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
     agg = collections.defaultdict(list)
     bench = []
+    only3 = timed_only(r["Kernel_Name"] for r in rows)
     for r in rows:
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         agg[r["Kernel_Name"]].append(dur)
         # the benchmark's launches: 1024 walker blocks + the tail blocks (slow_kernel.h), 64 threads each
         if ("search_kernel" in r["Kernel_Name"] or "fast_kernel" in r["Kernel_Name"]) and 65536 <= int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0)) <= 65536 + 64 * 64:
+            if only3 and TIMED not in r["Kernel_Name"]:
+                continue
             bench.append(dur)
     tot = sum(sum(v) for v in agg.values())
     lines.append("# kernel trace: kernel, calls, total_ms, avg_us, min_us, max_us, pct")
@@ -25,6 +35,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         rows = list(csv.DictReader(open(f)))
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        only3 = timed_only(r["Kernel_Name"] for r in rows)
         for r in rows:
             if r["Kernel_Name"].startswith("void granne_hip::bf_") or "::bf_" in r["Kernel_Name"][:40]:
                 agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -33,6 +44,8 @@ for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
                 continue
             gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
             if not (65536 <= gs <= 65536 + 64 * 64):
+                continue
+            if only3 and TIMED not in r["Kernel_Name"]:
                 continue
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in agg.items():
