@@ -2,6 +2,7 @@
 
 * tools/model_unified.py: the walker's ONE sorted list with expanded flags and its once-per-expansion tie test
   (walk_fast.h, insert_sorted) against the reference's two heaps (src/index/mod.rs:999-1037) on tie-heavy graphs.
+  The same list WITHOUT a visited set (wave_prims.h VisitedNone: candidates are looked up in the list) against the same.
 * the builder's one-candidate form of add_and_limit_neighbors (builder_kernels.h, add_one_to_selected) against the
   full sort + select_neighbors pass (src/index/mod.rs:849-883, 923-959) over rows that fill, get limited, refill.
 """
@@ -36,6 +37,40 @@ def test_sorted_list_with_deferred_tie_test_equals_two_heaps():
         assert r0 == r1 and c0 == c1, (it, mode, n, deg, ef)
         equal += 1
     assert equal > 500 and bailed > 0  # both outcomes are exercised
+
+
+def test_walk_without_a_visited_set_equals_two_heaps():
+    """The register walkers keep no visited set (granne_amd/csrc/wave_prims.h, VisitedNone): every neighbor is evaluated, a
+    candidate that passed the filter is looked up in the list in the next-node decision and before its insert. Same
+    results as the reference's HashSet walk on tie-heavy graphs, rows that name a neighbor twice and self-references
+    included; expansions and adjacency entries equal, evaluations at least the reference's distinct nodes."""
+    spec = importlib.util.spec_from_file_location("model_unified", os.path.join(ROOT, "tools", "model_unified.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rnd = random.Random(23)
+    equal = bailed = revisits = 0
+    for it in range(900):
+        n = rnd.choice([5, 20, 80, 300])
+        deg = rnd.choice([2, 4, 8, 15, 30])
+        ef = rnd.choice([1, 2, 5, 10, 50, 60, 64])
+        adj = [rnd.sample(range(n), min(deg, n)) for _ in range(n)]
+        if it % 3 == 0:
+            for row in adj:
+                if len(row) >= 2 and rnd.random() < 0.3:
+                    row[-1] = row[0]
+        mode = rnd.choice(["float", "int_small", "int_tiny"])
+        dv = [rnd.random() if mode == "float" else rnd.randrange(50 if mode == "int_small" else 4) / 50.0 for _ in range(n)]
+        ep = rnd.randrange(n)
+        r0, c0 = m.reference(adj, dv.__getitem__, ep, ef)
+        r1, c1 = m.unified(adj, dv.__getitem__, ep, ef, 64, deferred=True, novis=True)
+        if r1 is None:
+            bailed += 1
+            continue
+        assert r0 == r1, (it, mode, n, deg, ef)
+        assert c0[1:] == c1[1:] and c0[0] <= c1[0] <= c0[2] + 1, (it, c0, c1)
+        revisits += c1[0] - c0[0]
+        equal += 1
+    assert equal > 600 and bailed > 0 and revisits > 1000
 
 
 def _dist(a, b):

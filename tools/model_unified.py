@@ -48,9 +48,12 @@ def reference(adj, dist, ep, ef):
     return sorted((-a, -b) for a, b in res), (n_dist, n_expand, n_adj)
 
 
-def unified(adj, dist, ep, ef, cap, deferred=True):
+def unified(adj, dist, ep, ef, cap, deferred=True, novis=False):
     """The list walker with walk_fast.h's control flow: the next node is decided (and its break test
-    taken) BEFORE the candidates of the current expansion are merged."""
+    taken) BEFORE the candidates of the current expansion are merged.
+    novis: the walker WITHOUT a visited set (VisitedNone, wave_prims.h) -- every neighbor is evaluated; a candidate that
+    passed the filter is looked up in the list (all `cap` places) in the next-node decision and right before its
+    insert, and dropped if it is there."""
     L = [[dist(ep), ep, True]]  # ascending by (dist, id); third field = expanded. The entry point is popped at once
     visited = {ep}
     n_dist, n_expand, n_adj = 1, 1, len(adj[ep])
@@ -62,7 +65,7 @@ def unified(adj, dist, ep, ef, cap, deferred=True):
         theta = L[ef - 1][0] if len(L) >= ef else None
         cands = []
         for n in adj[x]:
-            if n not in visited:
+            if novis or n not in visited:
                 visited.add(n)
                 dn = dist(n)
                 n_dist += 1
@@ -75,6 +78,11 @@ def unified(adj, dist, ep, ef, cap, deferred=True):
         ypos = next((i for i, e in enumerate(L) if not e[2]), None)
         ykey = (L[ypos][0], L[ypos][1]) if ypos is not None else (float("inf"), 1 << 62)
         beat = [c for c in cands if c < ykey]
+        if novis:  # the smallest candidate below y that the list does not hold (the held ones leave the candidates)
+            while beat and any(e[1] == min(beat)[1] for e in L):
+                known = min(beat)
+                cands = [c for c in cands if c != known]
+                beat = [c for c in cands if c < ykey]
         if beat:
             nxt = min(beat)[1]
         else:
@@ -85,6 +93,8 @@ def unified(adj, dist, ep, ef, cap, deferred=True):
             nxt = ykey[1]
         lost = None
         for dn, n in cands:
+            if novis and any(e[1] == n for e in L):
+                continue  # in the list already: a revisit, or the row names the node twice
             keys = [(e[0], e[1]) for e in L]
             L.insert(bisect.bisect_left(keys, (dn, n)), [dn, n, False])
             while len(L) > cap:
@@ -113,6 +123,10 @@ def main():
         ef = rnd.choice([1, 1, 2, 5, 10, 50, 60, 64])
         cap = 64
         adj = [rnd.sample(range(n), min(deg, n)) for _ in range(n)]
+        if it % 5 == 0:  # rows that name a neighbor twice
+            for row in adj:
+                if len(row) >= 2 and rnd.random() < 0.3:
+                    row[-1] = row[0]
         mode = rnd.choice(["float", "int_small", "int_tiny", "dup"])
         if mode == "float":
             dv = [rnd.random() for _ in range(n)]
@@ -127,14 +141,19 @@ def main():
         ep = rnd.randrange(n)
         r0, c0 = reference(adj, dist, ep, ef)
         deferred = bool(it & 1)
-        r1, c1 = unified(adj, dist, ep, ef, cap, deferred)
+        novis = bool(it & 2)
+        r1, c1 = unified(adj, dist, ep, ef, cap, deferred, novis)
         trials += 1
         if r1 is None:
             bails += 1
             continue
-        assert r0 == r1, (it, mode, deferred, n, deg, ef, r0[:5], r1[:5])
-        assert c0 == c1, (it, mode, deferred, n, deg, ef, c0, c1)
+        assert r0 == r1, (it, mode, deferred, novis, n, deg, ef, r0[:5], r1[:5])
+        if novis:  # expansions and adjacency entries are the reference's; n_dist counts evaluations
+            assert c0[1:] == c1[1:] and c0[0] <= c1[0] <= c0[2] + 1, (it, mode, deferred, n, deg, ef, c0, c1)
+        else:
+            assert c0 == c1, (it, mode, deferred, n, deg, ef, c0, c1)
     print("ok: %d walks equal, %d bailed (ties at the boundary)" % (trials - bails, bails))
+    return trials - bails, bails
 
 
 if __name__ == "__main__":
