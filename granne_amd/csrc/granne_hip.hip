@@ -543,7 +543,7 @@ typedef void (*search_fn)(const SlowParams);
 
 // experiment knobs, read once per process
 struct EnvKnobs {
-    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, v16_lg = 0, tail_blocks = -1;
+    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, v16_lg = 0, tail_blocks = -1, touch_max = -1;
     EnvKnobs() {
         auto geti = [](const char* name, int dflt) {
             const char* e = getenv(name);
@@ -555,6 +555,7 @@ struct EnvKnobs {
         lds_pad = geti("GRANNE_HIP_LDS_PAD", 0);
         visited = geti("GRANNE_HIP_VISITED", 0); // GRANNE_HIP_OPT_VISITED16's values, where the option says auto
         v16_lg = geti("GRANNE_HIP_V16_LG", 0); // log2(buckets) of the 16-bit table
+        touch_max = geti("GRANNE_HIP_TOUCH_MAX", -1); // launches of up to this many queries touch rows ahead (-1: default)
     }
 };
 static const EnvKnobs& knobs() {
@@ -587,7 +588,10 @@ static uint32_t fast_list_slots(uint32_t ef) { return ef <= 60 ? 1u : ef <= 124 
 // v16: the form of the visited set (FastWalker's V16): 0 = 32-bit table, 1 = 16-bit entries, 2 = 20-bit entries, 3 = none
 template <int DT, int DIM, int S>
 static search_fn pick_fast_v(int v16) {
-    if (v16 == 3) return fast_kernel<DT, DIM, S, false, 3>;
+    if constexpr (S == 1 && !(DT == DT_F32 && DIM == 0) && !(DT == DT_I8 && DIM >= 256)) {
+        if (v16 == 4) return fast_kernel<DT, DIM, S, false, 4>; // no visited set + rows touched ahead (few queries)
+    }
+    if (v16 >= 3) return fast_kernel<DT, DIM, S, false, 3>;
     if constexpr (!(DT == DT_I8 && DIM >= 256)) { // (wide int8 rows: no 20-bit instantiation)
         if (v16 == 2) return fast_kernel<DT, DIM, S, false, 2>;
     }
@@ -600,10 +604,10 @@ static search_fn pick_fast_s(uint32_t S, bool trail, int v16) {
     case 1: return pick_fast_v<DT, DIM, 1>(v16);
     case 2: return pick_fast_v<DT, DIM, 2>(v16);
     case 4: return pick_fast_v<DT, DIM, 4>(v16);
-    case 8: return v16 == 3 ? fast_kernel<DT, DIM, 8, false, 3> : fast_kernel<DT, DIM, 8>;
+    case 8: return v16 >= 3 ? fast_kernel<DT, DIM, 8, false, 3> : fast_kernel<DT, DIM, 8>;
     default:
         if constexpr (DT == DT_F32 && DIM == 0) return fast_kernel<DT, DIM, 8>; // not reached: max_search <= 508 there
-        else return v16 == 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
+        else return v16 >= 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
     }
 }
 static bool fast_shape(const SearchTarget* ix) {
@@ -663,7 +667,10 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
     const int vmode = ix->opt_visited16 ? ix->opt_visited16 : knobs().visited;
     const bool none = vmode == 4 || vmode == 0;
     if (fastS >= 1 && !trail && none && !ix->opt_visited_slots && ix->n_elements < WALK_MAX_ELEMENTS) {
-        P.v16 = 3;
+        // a launch of a few queries leaves the chip idle: its walkers touch the next node's rows ahead (walk_fast.h, TOUCH)
+        const uint32_t touch_max = knobs().touch_max >= 0 ? (uint32_t)knobs().touch_max : 64u;
+        const bool touch_shape = fastS == 1 && !fast_generic(ix) && !(ix->dtype == GRANNE_HIP_I8 && ix->row_bytes != 128);
+        P.v16 = (touch_shape && nq <= touch_max) ? 4 : 3;
         P.visited_slots = P.upper_slots = 0;
         P.maxc = 0;
         P.lrow_bytes = 16;
@@ -826,7 +833,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     // visited-set overflow pool: one table per walker that can be resident at once (bounded by
     // LDS: 160 KiB per CU, and by 32 waves per CU), at most one per query
     uint32_t ovf_slots = 0, ovf_regions = 0;
-    if (!all_slow && ix->opt_overflow_slots != 1 && plan.v16 != 3) { // (no visited set, no overflow)
+    if (!all_slow && ix->opt_overflow_slots != 1 && plan.v16 < 3) { // (no visited set, no overflow)
         ovf_slots = ix->opt_overflow_slots ? next_pow2((uint32_t)ix->opt_overflow_slots) : next_pow2(ef_walk * 64u);
         if (!ix->opt_overflow_slots && ovf_slots < 4096) ovf_slots = 4096;
         if (ovf_slots < 512) ovf_slots = 512;

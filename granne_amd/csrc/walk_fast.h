@@ -281,6 +281,7 @@ struct FastWalker {
     static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u * NBI;
     static_assert(F32 || DIM == 0 || DIM == 256 || DIM == 512, "fast int8 rows: 128, 256 or 512 bytes");
     static constexpr uint32_t CAP = 64u * S;
+    static constexpr int NT = ROWB ? (int)((ROWB + 255u) / 256u) : 1; // TOUCH: lines of a row per lane of its pair
     static_assert(!F32 || GEN || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
     const SearchParams& p;
@@ -293,7 +294,12 @@ struct FastWalker {
     uint4 qi8[F32 ? 1 : 4 * NBI]; // i8: bytes 64h..64h+63 of every 128-byte block of the query
     float sy;               // i8: sqrt(sum of squares of the query) as f32
     uint32_t g_nbk, g_ngroups, g_tu; // GEN: full chunks, groups of them, 16-byte units of the (zero padded) tail
-    static constexpr bool NOVIS = V16 == 3; // no visited set: the list is searched for a candidate's id (VisitedNone, wave_prims.h)
+    static constexpr bool NOVIS = V16 >= 3; // no visited set: the list is searched for a candidate's id (VisitedNone, wave_prims.h)
+    // V16 == 4, launches of a few queries on an otherwise idle chip (one query per call is the reference's own shape):
+    // the rows of the neighbors of the node that is first in line are touched one expansion early -- one load per
+    // 128-byte line, data dropped -- so that, when that node is expanded next (half of the time), its rows come from L2.
+    // With a thousand walks in a launch the same touches cost throughput and are not compiled in.
+    static constexpr bool TOUCH = V16 == 4;
     typename std::conditional<V16 == 0, VisitedSet,
         typename std::conditional<V16 == 1, VisitedSet16,
             typename std::conditional<V16 == 2, VisitedSet20, VisitedNone>::type>::type>::type vis;
@@ -669,6 +675,7 @@ struct FastWalker {
         theta = wkey_hi(L.at(ef - 1));
 
         RowRegs rr;
+        [[maybe_unused]] uint32_t touched[NT] = {};
         PT_WAIT_VM();
         PT_MARK(7); // layer setup: tables, entry point distance
         for (;;) {
@@ -714,6 +721,19 @@ struct FastWalker {
             PT_WAIT_VM();
             PT_MARK(3); // what is left of the wait for the rows
             const float d = finish_rows(rr);
+            if constexpr (TOUCH) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(touched[j])); // (arrived before the rows did)
+                // y's adjacency row came in right behind the rows; a pair past its end touches y's own row
+                const uint32_t tid = pre_nb != ID_EMPTY ? pre_nb : pre_id;
+                const uint8_t* tb = p.elements + (size_t)tid * ROWB;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const uint32_t off = h * 128u + (uint32_t)j * 256u;
+                    touched[j] = *reinterpret_cast<const uint32_t*>(tb + (off < ROWB ? off : ROWB - 4u));
+                }
+                asm volatile("" ::: "memory");
+            }
             const uint64_t fm = wave_ballot(fresh);
             const uint32_t mf = (uint32_t)__popcll(fm);
             vis.added(mf);
