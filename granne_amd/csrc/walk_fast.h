@@ -13,8 +13,10 @@
 //  i8:  v_dot4_i32_i8 partial sums of r and dx per half row, one quad_perm DPP exchange each, then
 //       the reference's float tail (angular_int.rs:52-58) once per lane; sqrt(dy) is the query's
 //       and is taken once per query (same operation on the same input: same bits).
-// All row loads of an expansion are issued from the neighbor ids alone before the exact visited
-// set (LDS front table + global overflow, wave_prims.h) is consulted under them.
+// All row loads of an expansion are issued from the neighbor ids alone. The walker keeps NO visited set by default
+// (V16 = 3; wave_prims.h VisitedNone says why the results stay the reference's): every neighbor is evaluated and a
+// candidate that passed the filter is looked up in the list before it is inserted. With an exact set switched on
+// (V16 = 0 / 1 / 2: LDS front table + global overflow) its look-ups run under the row loads.
 //
 // The reference's two heaps (`res`: the max_search best popped nodes, `pq`: the unbounded
 // candidate queue, mod.rs:1006-1007) are ONE ascending list of 64*S keys in registers, each key
@@ -245,10 +247,10 @@ struct WalkList : SortedList<S> {
 #define GRANNE_HIP_QUERY_IN_LDS 0 // experiments: 1 = the short list reads an f32 query from LDS too
 #endif
 // A query that lives in registers needs no LDS of its own: int8 rows (64 bytes per lane; staged once through the
-// start of the visited table, before that table's first reset) and, for the short list, f32 rows of the unrolled
+// start of the walker's LDS) and, for the short list, f32 rows of the unrolled
 // dims (this lane's pieces in VGPRs; longer lists need the registers and read the query from LDS, 13 ds_read_b128
-// per expansion at 100-d, issued under the row loads). At 4096 visited slots the walker's LDS is then the table
-// alone, 16 KB: ten walkers per CU.
+// per expansion at 100-d, issued under the row loads). Without a visited table the walker's LDS is that staging area
+// (and the mirror of lists of S >= 8): the registers bound the walkers per CU.
 __host__ __device__ constexpr bool fast_query_in_regs(bool i8, bool gen, uint32_t dim, uint32_t S) {
     if (i8) return true;
     if (gen || S != 1u || GRANNE_HIP_QUERY_IN_LDS) return false;
@@ -265,9 +267,10 @@ __host__ __device__ inline uint32_t fast_query_bytes(bool i8, bool gen, uint32_t
     return ngroups * GEN_GROUP * 128u + 128u;
 }
 
-// V16: the form of the visited set's front table. 0 = 32-bit open addressing (VisitedSet); 1 = 16-bit entries in
-// two-choice buckets (half the LDS; id spaces of up to 32767 ids per bucket); 2 = 20-bit entries (three eighths more
-// LDS per id than 16-bit ones, id spaces of up to 524286 ids per bucket). wave_prims.h; the host picks by the ids.
+// V16: the form of the visited set. 3 = none (the default; 4 = none + rows touched ahead, for launches of a few
+// queries); the exact sets: 0 = 32-bit open addressing (VisitedSet); 1 = 16-bit entries in two-choice buckets (half the
+// LDS; id spaces of up to 32767 ids per bucket); 2 = 20-bit entries (three eighths more LDS per id than 16-bit ones,
+// id spaces of up to 524286 ids per bucket). wave_prims.h; the host picks (plan_launch, granne_hip.hip).
 template <int DT, int DIM, int S, int V16 = 0>
 struct FastWalker {
     static constexpr bool F32 = (DT == DT_F32);
@@ -627,7 +630,7 @@ struct FastWalker {
 
     // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
     //
-    // One iteration = one expansion: pop, adjacency row, row loads, visited set under them, distances, filter,
+    // One iteration = one expansion: pop, adjacency row, row loads, (an exact visited set under them,) distances, filter,
     // merge. Two things run ahead of their use:
     //  * the adjacency row of the list's first unexpanded entry y is fetched during the expansion before it;
     //  * once the distances are in, the node expanded next is known BEFORE the merge -- the smallest of y and
@@ -890,7 +893,7 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
     }
 }
 
-// Block b walks query b (one wavefront). LDS: [query][S >= 8: the list's mirror, CAP keys][visited front table].
+// Block b walks query b (one wavefront). LDS: [query][S >= 8: the list's mirror, CAP keys][visited front table, if any].
 // waves per SIMD the register allocator is asked to keep possible (__launch_bounds__'s second argument is
 // per SIMD on AMD; 5 waves = 96 VGPRs, 4 = 128, 3 = 168, 2 = 256). Chosen from the unconstrained
 // allocation of each instantiation so that none spills (tools/isa_report.py prints both).
