@@ -94,7 +94,8 @@ def parse():
     ap.add_argument("--batch-max", type=int, default=65536)
     ap.add_argument("--inflight", type=int, default=0,
                     help="batches in flight: step i is enqueued on HIP stream i %% inflight (1 = strictly sequential; "
-                         "0 = per element type: f32 4, int8 6 -- int8 walks move a quarter of the bytes)")
+                         "0 = per element type: up to 6 for f32, 12 for int8 -- int8 walks move a quarter of the bytes -- "
+                         "the nearest count that divides --steps)")
     ap.add_argument("--cpu-batches", type=int, default=16, help="batches of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=2.0, help="wall seconds the CPU baseline is timed over (repeats its sample)")
     ap.add_argument("--c5-elements", type=int, default=125_000_000, help="elements of the c5_shard sub-record (0 = skip)")
