@@ -254,18 +254,26 @@ class Bench:
         stats = torch.zeros((n_batches, nq, 3), dtype=torch.int64, device="cuda")
         status = torch.zeros(4, dtype=torch.int32, device="cuda")
 
+        # raw pointers of every batch, taken once: a step is one library call (slicing five tensors per step costs more
+        # host time than the call, and the K timed steps start from idle queues)
+        q_ptr = [queries[b * nq:(b + 1) * nq].data_ptr() for b in range(n_batches)]
+        i_ptr = [ids[b].data_ptr() for b in range(n_batches)]
+        d_ptr = [dists[b].data_ptr() for b in range(n_batches)]
+        c_ptr = [counts[b].data_ptr() for b in range(n_batches)]
+        s_ptr = [stats[b].data_ptr() for b in range(n_batches)]
+        st_ptr = status.data_ptr()
+
         def step(b, on):
-            index.search_batch_device(queries[b * nq:(b + 1) * nq].data_ptr(), nq, ef, k, ids[b].data_ptr(),
-                                      dists[b].data_ptr(), counts[b].data_ptr(), stats[b].data_ptr(),
-                                      status.data_ptr(), on)
+            index.search_batch_device(q_ptr[b], nq, ef, k, i_ptr[b], d_ptr[b], c_ptr[b], s_ptr[b], st_ptr, on)
 
         # Step i is enqueued on stream i % inflight: a batch starts while the previous ones drain (one
         # batch of 1024 one-wave walkers fills one wave slot per SIMD). Every step is still one batch
         # of `nq` queries through one kernel launch; nothing is skipped or cached.
         inflight = min(inflight, len(self.streams))
         streams = self.streams[:inflight] if inflight > 1 else [torch.cuda.current_stream()]
+        on_ = [x.cuda_stream for x in streams]
         for b in range(max(warmup, inflight)):  # (every stream has searched once: its scratch block exists)
-            step(b % n_batches, streams[b % inflight].cuda_stream)
+            step(b % n_batches, on_[b % inflight])
         torch.cuda.synchronize()
         status.zero_()
         if contract:
@@ -274,7 +282,7 @@ class Bench:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(warmup + i, streams[i % inflight].cuda_stream)
+            step(warmup + i, on_[i % inflight])
         if contract:
             self.barrier()
         else:
@@ -296,7 +304,7 @@ class Bench:
             t2 = time.perf_counter()
             for r in range(rounds):
                 for i in range(steps):
-                    step(warmup + i, streams[(r * steps + i) % inflight].cuda_stream)
+                    step(warmup + i, on_[(r * steps + i) % inflight])
             torch.cuda.synchronize()
             dt = time.perf_counter() - t2
             steady = {"value": round(rounds * steps * nq / dt, 1), "unit": "queries/s", "steps": rounds * steps,
