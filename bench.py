@@ -48,11 +48,13 @@ import os
 import sys
 import time
 
-# Batches in flight run on HIP streams of their own; HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware
-# queues (default 4, one of them the null stream's), and two streams that share a queue run one after the other
-# (tools/inflight_probe.py: four streams on the default setting run like two; n streams on n queues fall back too --
-# one queue is shared -- so there are more queues than streams). Must be set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# The timed steps go out through granne_hip_search_batches_device: K batches of 1024 queries = ONE launch of K x 1024
+# walkers on ONE stream, default HIP settings (round 3 kept 5-10 batches in flight on as many streams and had to raise
+# GPU_MAX_HW_QUEUES for it). `--inflight N` (N > 1) still measures the stream form; it wants more hardware queues than
+# streams (HIP maps streams onto 4 by default and streams that share a queue run one after the other), which must be set
+# before HIP starts -- only then, never for the default line.
+if any(a.startswith("--inflight") for a in sys.argv[1:]):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 # the CPU baseline's OpenMP team: one thread per core, spread over both sockets (read when libgomp loads)
 if int(os.environ.get("WORLD_SIZE", "1")) <= 1:  # (several ranks on one host would all bind to the same cores)
     os.environ.setdefault("OMP_PROC_BIND", "spread")
@@ -92,10 +94,22 @@ def parse():
     ap.add_argument("--build-reinsert", type=int, default=1)
     ap.add_argument("--num-neighbors", type=int, default=30)
     ap.add_argument("--batch-max", type=int, default=65536)
-    ap.add_argument("--inflight", type=int, default=0,
-                    help="batches in flight: step i is enqueued on HIP stream i %% inflight (1 = strictly sequential; "
-                         "0 = per element type: up to 6 for f32, 12 for int8 -- int8 walks move a quarter of the bytes -- "
-                         "the nearest count that divides --steps)")
+    ap.add_argument("--batches-per-call", type=int, default=0,
+                    help="timed steps handed to the library per call (granne_hip_search_batches_device: one launch of that many "
+                         "batches); 0 = all K steps when K <= 32, else the largest divisor of K up to 32; 1 = one batch per call")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="> 1: the round-3 form instead -- step i enqueued alone on HIP stream i %% inflight "
+                         "(sets GPU_MAX_HW_QUEUES=24 unless the environment has it)")
+    ap.add_argument("--driver", default="cabi", choices=["cabi", "torch"],
+                    help="partitioned mode: whose pipelined rate is `value` -- cabi = granne_hip_sharded_begin/end_device (what a "
+                         "Rust host binds), torch = granne_amd/sharded.py (one process per GPU; the only one with WORLD_SIZE > 1). "
+                         "Both are measured when one process holds all shards")
+    ap.add_argument("--parity-all-shards", action="store_true",
+                    help="partitioned mode: every shard's first timed batch against the CPU oracle (host copy of each shard), "
+                         "and the merged result against the numpy merge of the ORACLE's per-shard results")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="only the warmup + timed + steady launches of the headline workload (for rocprofv3: every launch of "
+                         "the walker in the trace is then a timed-shape launch); prints a reduced line")
     ap.add_argument("--cpu-batches", type=int, default=16, help="batches of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=2.0, help="wall seconds the CPU baseline is timed over (repeats its sample)")
     ap.add_argument("--c5-elements", type=int, default=125_000_000, help="elements of the c5_shard sub-record (0 = skip)")
@@ -103,7 +117,7 @@ def parse():
     ap.add_argument("--no-partitioned", action="store_true", help="WORLD_SIZE > 1: skip the partitioned sub-record")
     ap.add_argument("--force-partitioned", action="store_true", help="take the partitioned sub-record with one rank too (tests)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--sweep-ef", default="50,100,200,400,800", help="ef values of ef_sweep ('' = skip)")
+    ap.add_argument("--sweep-ef", default="50,100,200,400,800,1600,3200", help="ef values of ef_sweep ('' = skip)")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the int8 / secondary / latency sub-records")
     ap.add_argument("--visited-slots", type=int, default=0,
@@ -125,18 +139,17 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def auto_inflight(args, dtype, steps):
-    """Batches in flight (step i goes to stream i % inflight). Where more stop paying (profiles/r3_inflight_novis.txt):
-    f32 walks fill the memory system with six (6.2-6.3 M queries/s from six to twelve), int8 walks -- a quarter of the
-    bytes, eight waves per SIMD -- with twelve. The K timed steps are few (the driver times 20): a count that divides K
-    keeps the last round as full as the others, so the nearest divisor of K not below three quarters of that is taken."""
-    if args.inflight:
-        return max(1, args.inflight)
-    best = 6 if dtype == "f32" else 12
-    for d in range(best, (3 * best + 3) // 4 - 1, -1):
+def auto_group(args, steps):
+    """Batches handed to the library per call (one launch each, up to 32 batches): all K timed steps when they fit one
+    launch, else the largest divisor of K that does -- every call of the timed region then has the same shape."""
+    if args.batches_per_call:
+        return max(1, min(args.batches_per_call, steps))
+    if steps <= 32:
+        return steps
+    for d in range(32, 0, -1):
         if steps % d == 0:
             return d
-    return best
+    return 1
 
 
 def workload_label(n, dim, dtype, data, nq, ef, k):
@@ -245,8 +258,15 @@ class Bench:
         self.torch.cuda.synchronize()
 
     # ---- one workload on one index: the timed K steps + per-launch events + counters ----------------
-    def measure(self, index, queries, dim, esize, nq, ef, k, steps, warmup, inflight, contract=False, steady_s=0.0):
+    def measure(self, index, queries, dim, esize, nq, ef, k, steps, warmup, group, inflight=1, contract=False, steady_s=0.0,
+                profile_only=False):
+        """The K timed steps (K batches of nq fresh queries) handed to the library `group` batches per call
+        (granne_hip_search_batches_device: one launch per call) on torch's current stream; or, inflight > 1, one batch per
+        call on stream i % inflight (round 3's form). Then, untimed: the grouped launches again between HIP events (the
+        dominant kernel's duration), the same steps one batch per call (`sequential`, with the library's own events
+        around every launch), and a counting pass with an exact visited set (the reference's n_dist)."""
         torch = self.torch
+        from granne_amd.index import pointer_array
         n_batches = warmup + steps
         ids = torch.empty((n_batches, nq, k), dtype=torch.int64, device="cuda")
         dists = torch.empty((n_batches, nq, k), dtype=torch.float32, device="cuda")
@@ -266,14 +286,25 @@ class Bench:
         def step(b, on):
             index.search_batch_device(q_ptr[b], nq, ef, k, i_ptr[b], d_ptr[b], c_ptr[b], s_ptr[b], st_ptr, on)
 
-        # Step i is enqueued on stream i % inflight: a batch starts while the previous ones drain (one
-        # batch of 1024 one-wave walkers fills one wave slot per SIMD). Every step is still one batch
-        # of `nq` queries through one kernel launch; nothing is skipped or cached.
-        inflight = min(inflight, len(self.streams))
+        def call_args(b0, nb):  # the pointer arrays of one grouped call, built outside the clock
+            sl = slice(b0, b0 + nb)
+            return tuple(pointer_array(v[sl]) for v in (q_ptr, i_ptr, d_ptr, c_ptr, s_ptr))
+
+        def grouped(a, on):
+            index.search_batches_device(a[0], nq, ef, k, a[1], a[2], a[3], a[4], st_ptr, on)
+
+        group = max(1, min(group, steps))
+        inflight = max(1, min(inflight, len(self.streams)))
         streams = self.streams[:inflight] if inflight > 1 else [torch.cuda.current_stream()]
         on_ = [x.cuda_stream for x in streams]
-        for b in range(max(warmup, inflight)):  # (every stream has searched once: its scratch block exists)
-            step(b % n_batches, on_[b % inflight])
+        timed_calls = [call_args(warmup + g0, min(group, steps - g0)) for g0 in range(0, steps, group)]
+        if inflight > 1:
+            for b in range(max(warmup, inflight)):  # (every stream has searched once: its scratch block exists)
+                step(b % n_batches, on_[b % inflight])
+        else:
+            for g0 in range(0, warmup, group):  # the W warmup steps, in calls of the timed shape
+                grouped(call_args(g0, min(group, warmup - g0)), self.stream)
+            grouped(timed_calls[0], self.stream)  # (the scratch block has the timed shape's size: no allocation under the clock)
         torch.cuda.synchronize()
         status.zero_()
         if contract:
@@ -281,8 +312,12 @@ class Bench:
         else:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            step(warmup + i, on_[i % inflight])
+        if inflight > 1:
+            for i in range(steps):
+                step(warmup + i, on_[i % inflight])
+        else:
+            for a in timed_calls:
+                grouped(a, self.stream)
         if contract:
             self.barrier()
         else:
@@ -296,25 +331,45 @@ class Bench:
             raise RuntimeError("exact-search scratch exhausted during the timed steps")
 
         # the same K steps again and again, back to back, until `steady_s` seconds have passed: the K-step window above
-        # is a few milliseconds, this one is long enough to trust (same batches, same streams, one synchronisation)
+        # is a few milliseconds, this one is long enough to trust (same batches, same calls, one synchronisation)
         steady = None
         if steady_s > 0:
             rounds = max(2, int(math.ceil(steady_s / max(elapsed, 1e-6))))
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             for r in range(rounds):
-                for i in range(steps):
-                    step(warmup + i, on_[(r * steps + i) % inflight])
+                if inflight > 1:
+                    for i in range(steps):
+                        step(warmup + i, on_[(r * steps + i) % inflight])
+                else:
+                    for a in timed_calls:
+                        grouped(a, self.stream)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t2
             steady = {"value": round(rounds * steps * nq / dt, 1), "unit": "queries/s", "steps": rounds * steps,
                       "seconds": round(dt, 3), "note": "the same K steps repeated back to back (rank-local)"}
 
-        # the same K steps strictly one after the other on ONE stream, twice: first bare (the wall clock of K back-to-back
-        # launches: what one batch at a time costs, launch gaps included), then with one pair of HIP events per step
-        # recorded inside the library immediately around the walker's dispatch = what rocprofv3 reports per kernel
-        # (a search is one kernel: walk_fast.h / slow_kernel.h). The events themselves are work on the stream, which is
-        # why the two loops are separate.
+        # the timed shape's launches between HIP events on the launch stream (a grouped call is ONE kernel and nothing else:
+        # walk_fast.h / slow_kernel.h), one pair per call, each call after the previous one has drained
+        grp_ms = []
+        if inflight == 1:
+            for rep in range(3):
+                for a in timed_calls:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    grouped(a, self.stream)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    grp_ms.append(e0.elapsed_time(e1))
+        slow_n, spill_n = int(status[1].item()), int(status[2].item())  # (of the timed forms of the walk, not of the counting pass)
+        if profile_only:
+            return {"elapsed": elapsed, "value_local": steps * nq / elapsed, "steady": steady, "group": group,
+                    "calls": len(timed_calls), "inflight": inflight, "group_launch_ms": grp_ms, "slow": slow_n, "spill": spill_n}
+
+        # the same K steps strictly one after the other, ONE batch per call, twice: first bare (the wall clock of K
+        # back-to-back launches: what one batch at a time costs, launch gaps included), then with one pair of HIP events
+        # per step recorded inside the library immediately around the walker's dispatch = what rocprofv3 reports per
+        # kernel. The events themselves are work on the stream, which is why the two loops are separate.
         glib, _glib = self.lib, self._lib
 
         def hip_event():
@@ -322,7 +377,7 @@ class Bench:
             _glib.check(glib.granne_hip_event_create(C.byref(e)))
             return e
 
-        step(0, self.stream)  # (the launch stream's scratch block exists)
+        step(0, self.stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(steps):
@@ -334,9 +389,8 @@ class Bench:
         for i in range(steps):
             b = warmup + i
             ev[i][0].record()
-            index.search_batch_device_timed(queries[b * nq:(b + 1) * nq].data_ptr(), nq, ef, k, ids[b].data_ptr(),
-                                            dists[b].data_ptr(), counts[b].data_ptr(), stats[b].data_ptr(),
-                                            status.data_ptr(), self.stream, kev[i][0].value, kev[i][1].value)
+            index.search_batch_device_timed(q_ptr[b], nq, ef, k, i_ptr[b], d_ptr[b], c_ptr[b], s_ptr[b], st_ptr, self.stream,
+                                            kev[i][0].value, kev[i][1].value)
             ev[i][1].record()
         torch.cuda.synchronize()
         call_ms = [a.elapsed_time(b) for a, b in ev]
@@ -352,7 +406,6 @@ class Bench:
         # mod.rs:1026). The timed walkers keep no visited set and evaluate a revisited neighbor again (~3 % more rows
         # on this data; wave_prims.h VisitedNone) -- so the counters come from one more, untimed pass over the same K
         # batches with the exact bucket tables switched on, whose results must be the timed pass's, bit for bit.
-        slow_n, spill_n = int(status[1].item()), int(status[2].item())  # (of the timed forms of the walk, not of the counting pass)
         evaluated = float(stats[warmup:, :, 0].sum().item())
         ids_x = torch.empty((nq, k), dtype=torch.int64, device="cuda")
         dists_x = torch.empty((nq, k), dtype=torch.float32, device="cuda")
@@ -364,9 +417,8 @@ class Bench:
         try:
             for i in range(steps):
                 b = warmup + i
-                index.search_batch_device(queries[b * nq:(b + 1) * nq].data_ptr(), nq, ef, k, ids_x.data_ptr(),
-                                          dists_x.data_ptr(), counts_x.data_ptr(), stats_x[i].data_ptr(),
-                                          status.data_ptr(), self.stream)
+                index.search_batch_device(q_ptr[b], nq, ef, k, ids_x.data_ptr(), dists_x.data_ptr(), counts_x.data_ptr(),
+                                          stats_x[i].data_ptr(), st_ptr, self.stream)
                 torch.cuda.synchronize()
                 same = same and bool((ids_x == ids[b]).all().item()) and bool((counts_x == counts[b]).all().item()) \
                     and bool((dists_x.view(torch.int32) == dists[b].view(torch.int32)).all().item())
@@ -378,25 +430,38 @@ class Bench:
             raise RuntimeError("expansion / adjacency counters differ between the two forms of the walk")
         st = stats_x.sum(dim=(0, 1)).cpu().numpy().astype(np.float64)  # n_dist, n_expand, n_adj (the reference's counts)
         alg_total = st[0] * dim * esize + st[2] * 4 + steps * nq * (dim * esize + k * 8)
-        alg_per_launch = alg_total / steps
+        alg_per_batch = alg_total / steps
         mean_ms = float(np.mean(step_ms))
-        achieved = alg_per_launch / (mean_ms * 1e-3) / 1e9
+        # the timed shape: a launch carries `group` batches (the last call of the region may carry fewer: weight by batches)
+        if grp_ms:
+            per_call_batches = [min(group, steps - g0) for g0 in range(0, steps, group)] * 3
+            grp_total_ms, grp_batches = float(np.sum(grp_ms)), float(np.sum(per_call_batches))
+            launch_ms = grp_total_ms / len(grp_ms)
+            alg_per_launch = alg_per_batch * grp_batches / len(grp_ms)
+        else:  # the stream form launches one batch at a time
+            launch_ms, alg_per_launch = mean_ms, alg_per_batch
         return {
             "elapsed": elapsed, "value_local": steps * nq / elapsed, "seq_elapsed": seq_elapsed, "steady": steady,
-            "ids": ids, "dists": dists, "counts": counts, "status": status, "inflight": inflight,
-            "slow": slow_n, "spill": spill_n,
-            "alg_per_launch": alg_per_launch, "achieved": achieved, "launch_ms_mean": mean_ms,
-            "launch_ms_min": float(np.min(step_ms)), "call_ms_mean": float(np.mean(call_ms)),
+            "ids": ids, "dists": dists, "counts": counts, "status": status, "inflight": inflight, "group": group,
+            "calls": len(timed_calls), "slow": slow_n, "spill": spill_n,
+            "alg_per_launch": alg_per_launch, "achieved": alg_per_launch / (launch_ms * 1e-3) / 1e9, "launch_ms_mean": launch_ms,
+            "launch_ms_min": float(np.min(grp_ms)) if grp_ms else float(np.min(step_ms)),
+            "one": {"alg_per_launch": alg_per_batch, "achieved": alg_per_batch / (mean_ms * 1e-3) / 1e9, "launch_ms_mean": mean_ms,
+                    "launch_ms_min": float(np.min(step_ms)), "call_ms_mean": float(np.mean(call_ms))},
             "per_query": {"n_dist": round(st[0] / (steps * nq), 1), "n_expand": round(st[1] / (steps * nq), 1),
                           "n_adj": round(st[2] / (steps * nq), 1), "rows_evaluated": round(evaluated / (steps * nq), 1)},
             "same_as_exact_set_walk": {"queries": steps * nq, "ids_dists_counts_bit_exact": True},
         }
 
     def roofline(self, m, traffic_key, value_per_gpu, nq):
+        """HBM roofline of the dominant kernel in the shape the timed region launches it: `group` batches per launch.
+        achieved = the reference algorithm's bytes for the launch's queries / the launch's mean duration (HIP events on the
+        launch stream). `one_batch_per_launch` is the same kernel launched with a single batch (round 3's headline shape)."""
         traffic, note = None, None
+        key = traffic_key + ("|g%d" % m["group"] if m["inflight"] == 1 else "")
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                ent = json.load(f).get(traffic_key)
+                ent = json.load(f).get(key)
             if ent:
                 if ent.get("csrc_sha") == csrc_sha():
                     traffic = ent.get("hbm_bytes_per_launch")
@@ -404,14 +469,22 @@ class Bench:
                     note = "PMC traffic in profiles/pmc_traffic.json was measured on other kernel sources (%s): not quoted" % ent.get("csrc_sha")
         except Exception:
             pass
+        one = m["one"]
         r = {
             "bound": "hbm", "kernel": "fast_kernel (walk_fast.h)", "achieved": round(m["achieved"], 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(m["achieved"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "aggregate_achieved_with_inflight": round(m["alg_per_launch"] * (value_per_gpu / nq) / 1e9, 1),
-            "aggregate_frac_with_inflight": round(m["alg_per_launch"] * (value_per_gpu / nq) / 1e9 / HBM_PEAK_GBPS, 4),
+            "launch": {"batches": m["group"] if m["inflight"] == 1 else 1,
+                       "queries": (m["group"] if m["inflight"] == 1 else 1) * nq, "ms_mean": round(m["launch_ms_mean"], 4),
+                       "ms_min": round(m["launch_ms_min"], 4), "alg_bytes": int(m["alg_per_launch"])},
             "alg_bytes_per_launch": int(m["alg_per_launch"]), "launch_ms_mean": round(m["launch_ms_mean"], 4),
-            "launch_ms_min": round(m["launch_ms_min"], 4), "call_ms_mean": round(m["call_ms_mean"], 4),
+            "whole_timed_region_achieved": round(one["alg_per_launch"] * (value_per_gpu / nq) / 1e9, 1),
+            "whole_timed_region_frac": round(one["alg_per_launch"] * (value_per_gpu / nq) / 1e9 / HBM_PEAK_GBPS, 4),
+            "one_batch_per_launch": {"achieved": round(one["achieved"], 1), "frac": round(one["achieved"] / HBM_PEAK_GBPS, 4),
+                                     "alg_bytes_per_launch": int(one["alg_per_launch"]),
+                                     "launch_ms_mean": round(one["launch_ms_mean"], 4), "launch_ms_min": round(one["launch_ms_min"], 4),
+                                     "call_ms_mean": round(one["call_ms_mean"], 4)},
             "per_query": m["per_query"], "same_as_exact_set_walk": m["same_as_exact_set_walk"],
+            "traffic_key": key,
         }
         if note:
             r["traffic_note"] = note
@@ -515,86 +588,141 @@ class Bench:
         torch.cuda.synchronize()
         return reps / (time.perf_counter() - t0), reps
 
-    def ef_sweep(self, index, queries, gt, nq, k, efs, steps, warmup, inflight, stop_at=None):
-        """recall@10 (first timed batch) and queries/sec over windows of >= 50 ms, one batch at a time and in flight."""
+    def ef_sweep(self, index, queries, gt, nq, k, efs, steps, warmup, group, stop_at=None):
+        """recall@10 (first timed batch) and queries/sec over windows of >= 50 ms: `group` batches per call (one stream),
+        and one batch per call."""
         torch = self.torch
+        from granne_amd.index import pointer_array
         out = []
         n_b = queries.shape[0] // nq
-        o = (torch.empty((nq, k), dtype=torch.int64, device="cuda"), torch.empty((nq, k), dtype=torch.float32, device="cuda"),
-             torch.empty((nq,), dtype=torch.int32, device="cuda"))
-        streams = self.streams[:inflight]
+        nd = n_b - warmup
+        g = max(1, min(group, nd))
+        o = (torch.empty((g, nq, k), dtype=torch.int64, device="cuda"), torch.empty((g, nq, k), dtype=torch.float32, device="cuda"),
+             torch.empty((g, nq), dtype=torch.int32, device="cuda"))
+        po = [pointer_array([o[j][b].data_ptr() for b in range(g)]) for j in range(3)]
+        starts = list(range(0, nd - g + 1, g)) or [0]
+        pq = [pointer_array([queries[(warmup + b0 + b) * nq:(warmup + b0 + b + 1) * nq].data_ptr() for b in range(g)]) for b0 in starts]
         for e_ in efs:
             def run(b, on):
-                index.search_batch_device(queries[b * nq:(b + 1) * nq].data_ptr(), nq, e_, k, o[0].data_ptr(), o[1].data_ptr(),
-                                          o[2].data_ptr(), 0, 0, on)
+                index.search_batch_device(queries[b * nq:(b + 1) * nq].data_ptr(), nq, e_, k, o[0][0].data_ptr(), o[1][0].data_ptr(),
+                                          o[2][0].data_ptr(), 0, 0, on)
             run(warmup, self.stream)
             torch.cuda.synchronize()
-            rec = self.recall(gt, o[0], k)
-            nd = n_b - warmup
+            rec = self.recall(gt, o[0][0], k)
+            slow0 = index.last_slow_count()
             r_seq, reps = self.timed_window(lambda j: run(warmup + j, self.stream), nd)
-            cnt = [0]
 
-            def infl(j):  # outputs overwrite each other: timing only
-                run(warmup + j, streams[cnt[0] % len(streams)].cuda_stream)
-                cnt[0] += 1
-            r_inf, reps_i = self.timed_window(infl, nd)
-            out.append({"ef": e_, "recall_at_10": round(rec, 4), "qps": round(r_inf * nq, 1),
-                        "qps_one_batch_at_a_time": round(r_seq * nq, 1), "batches_timed": reps_i})
+            def grp(j):  # outputs overwrite each other: timing only
+                index.search_batches_device(pq[j % len(pq)], nq, e_, k, po[0], po[1], po[2], None, 0, self.stream)
+            r_grp, reps_g = self.timed_window(grp, len(pq))
+            out.append({"ef": e_, "recall_at_10": round(rec, 4), "qps": round(r_grp * g * nq, 1),
+                        "qps_one_batch_at_a_time": round(r_seq * nq, 1), "batches_per_call": g, "calls_timed": reps_g})
+            del slow0
             if stop_at is not None and rec >= stop_at:
                 break
         return out
 
     # ---- the CPU oracle beside it ---------------------------------------------------------------------
+    def host_info(self):
+        """What bounds a CPU baseline on this box besides the cores' count: cgroup CPU quota, affinity mask, NUMA nodes,
+        transparent huge pages (granted or not is read off the mapping after it is filled: host_index)."""
+        def rd(path):
+            try:
+                with open(path) as f:
+                    return f.read().strip()
+            except Exception:
+                return None
+        info = {"logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                "cgroup_cpu_max": rd("/sys/fs/cgroup/cpu.max"), "thp_enabled": rd("/sys/kernel/mm/transparent_hugepage/enabled")}
+        if info["cgroup_cpu_max"] is None:
+            q, per = rd("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), rd("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+            info["cgroup_cpu_max"] = "%s %s (v1)" % (q, per) if q else None
+        try:
+            info["numa_nodes"] = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+        except Exception:
+            info["numa_nodes"] = None
+        try:
+            with open("/proc/cpuinfo") as f:
+                names = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")]
+            info["cpu_model"] = names[0] if names else None
+        except Exception:
+            info["cpu_model"] = None
+        quota = None
+        cm = info["cgroup_cpu_max"]
+        if cm and not cm.startswith("max") and not cm.startswith("-1"):
+            try:
+                a, b = cm.split()[:2]
+                quota = float(a) / float(b)
+            except Exception:
+                quota = None
+        info["cgroup_quota_cpus"] = quota
+        return info
+
     def host_index(self, elements, builder, order=None):
-        """the oracle's view of the index: host copies of the elements (parallel first touch: the pages end up spread
-        over the NUMA nodes of the threads that wrote them instead of all on one socket) and of the layers"""
-        from concurrent.futures import ThreadPoolExecutor
+        """the oracle's view of the index: host copies of the elements and of the layers. The element rows -- what the
+        walks gather at random -- live in a mapping that asks for transparent huge pages (4 GB in 4 KB pages is a TLB miss
+        per row) and are FIRST TOUCHED by the OpenMP team that will read them (gro_parallel_copy: static 2 MB chunks over
+        the team, so the pages spread over the NUMA nodes the team spans instead of sitting on the node of one copier)."""
         from oracle import oracle as orc
         orc.build()
         n = elements.shape[0]
         np_dt = np.float32 if elements.dtype == self.torch.float32 else np.int8
-        # the rows the walks gather at random live in transparent huge pages when the kernel grants them (4 GB in 4 KB
-        # pages is a TLB miss per row): the baseline should not lose to page walks what a tuned host would not
-        nbytes = int(np.prod(elements.shape)) * np.dtype(np_dt).itemsize
+        count = int(np.prod(elements.shape))
+        nbytes = count * np.dtype(np_dt).itemsize
         try:
             import mmap
             buf = mmap.mmap(-1, max(nbytes, 1))
             buf.madvise(mmap.MADV_HUGEPAGE)
-            h_el = np.frombuffer(buf, dtype=np_dt, count=int(np.prod(elements.shape))).reshape(tuple(elements.shape))
+            h_el = np.frombuffer(buf, dtype=np_dt, count=count).reshape(tuple(elements.shape))
             self._host_pages = "transparent huge pages requested (MADV_HUGEPAGE)"
         except Exception:
             h_el = np.empty(tuple(elements.shape), np_dt)
             self._host_pages = "default pages"
-        parts = 64
-        bounds = [n * i // parts for i in range(parts + 1)]
-
-        def cp(i):
-            h_el[bounds[i]:bounds[i + 1]] = elements[bounds[i]:bounds[i + 1]].cpu().numpy()
-        with ThreadPoolExecutor(8) as ex:
-            list(ex.map(cp, range(parts)))
+        rows_per = max(1, (1 << 30) // max(1, elements.shape[1] * np.dtype(np_dt).itemsize))
+        team = self.args.cpu_threads or 0
+        for r0 in range(0, n, rows_per):
+            r1 = min(n, r0 + rows_per)
+            tmp = np.ascontiguousarray(elements[r0:r1].cpu().numpy())
+            orc.lib().gro_parallel_copy(h_el[r0:r1].ctypes.data_as(C.c_void_p), tmp.ctypes.data_as(C.c_void_p), tmp.nbytes, team)
+        try:  # how much of the process's anonymous memory sits in huge pages now (the element mapping dominates it)
+            with open("/proc/self/smaps_rollup") as f:
+                kb = {l.split(":")[0]: int(l.split()[1]) for l in f if l.startswith(("AnonHugePages", "Anonymous"))}
+            self._host_pages += "; AnonHugePages %.1f GB of %.1f GB anonymous" % (kb.get("AnonHugePages", 0) / 1e6, kb.get("Anonymous", 0) / 1e6)
+        except Exception:
+            pass
         oix = orc.Index(h_el, builder.layers())
         if order is not None:
             oix = oix.reordered(order)
         return oix
 
-    def cpu_baseline(self, oix, h_q, ef, k, g_ids, g_d, single_thread_queries=256):
-        """the ONLY use of oracle/ in this file: the CPU baseline + parity check (the index view comes from host_index)."""
+    def cpu_baseline(self, oix, h_q, ef, k, g_ids, g_d, single_thread_queries=256, sweep=True):
+        """the ONLY use of oracle/ in this file: the CPU baseline + parity check (the index view comes from host_index).
+        sweep: thread counts {8, 16, ..., logical CPUs} each timed over cpu_seconds after an untimed pass; the best is the
+        baseline and the whole sweep is reported. Without: the count the last sweep chose and one thread per physical core."""
         from oracle import oracle as orc
         a = self.args
         nqs = h_q.shape[0]
-        # thread count: the best of {OpenMP default, all logical CPUs} unless given (a cgroup quota below
-        # the logical CPU count makes oversubscription much slower)
-        cands = [a.cpu_threads] if a.cpu_threads else sorted({orc.lib().gro_max_threads(), os.cpu_count() or 1})
-        best = None
+        logical = os.cpu_count() or 1
+        phys = max(1, logical // 2)
+        if a.cpu_threads:
+            cands = [a.cpu_threads]
+        elif sweep or not getattr(self, "_cpu_best_threads", None):
+            cands = sorted({t for t in (8, 16, 32, 64, 128, 256, phys, logical) if t <= logical})
+        else:
+            cands = sorted({self._cpu_best_threads, phys})
+        best, tried = None, []
         for th in cands:
             # one untimed pass inside the same parallel region, then as many timed passes as fill cpu_seconds
             probe, _, _, _ = oix.search_batch_timed(h_q, ef, k, n_threads=th, repeats=1)
             reps = max(1, int(math.ceil(a.cpu_seconds / max(probe, 1e-6))))
             sec, o_ids, o_d, o_c = oix.search_batch_timed(h_q, ef, k, n_threads=th, repeats=reps)
             rate = reps * nqs / sec
+            tried.append({"threads": th, "value": round(rate, 1), "passes": reps, "seconds": round(sec, 2)})
             if best is None or rate > best[0]:
                 best = (rate, th, sec, reps, o_ids, o_d)
         rate, threads, cpu_s, reps, o_ids, o_d = best
+        if sweep:
+            self._cpu_best_threads = threads
         # one thread, on queries it has not just walked (a repeated pass over a few hundred queries runs out of L3)
         m1 = min(single_thread_queries, max(1, nqs // 2))
         oix.search_batch(h_q[:8], ef, k, n_threads=1)
@@ -603,18 +731,25 @@ class Bench:
         single = m1 / (time.perf_counter() - t1)
         ids_ok = bool((g_ids == o_ids).all())
         d_ok = g_d.tobytes() == o_d.tobytes()
-        phys = (os.cpu_count() or 2) // 2
+        host = self.host_info()
+        usable = min(threads, phys)
+        if host.get("cgroup_quota_cpus"):
+            usable = min(usable, host["cgroup_quota_cpus"])
+        if host.get("affinity_cpus"):
+            usable = min(usable, max(1, host["affinity_cpus"] // 2) if host["affinity_cpus"] == logical else host["affinity_cpus"])
         return {
             "value": round(rate, 1), "unit": "queries/s", "cores": threads, "kind": "port",
             "single_thread": {"value": round(single, 1), "unit": "queries/s", "queries": int(m1)},
-            "parallel_efficiency": round(rate / (min(threads, phys) * single), 3),
+            "parallel_efficiency": round(rate / (usable * single), 3),
+            "thread_sweep": tried, "host": host,
             "sample": "%d queries of the timed workload, same index, %d passes = %.2f s wall after one untimed pass "
                       "(gro_search_batch_timed: one OpenMP region, dynamic schedule over queries, threads and their scratch kept "
                       "between passes; OMP_PROC_BIND=%s OMP_PLACES=%s); oracle/granne_oracle.c (C restatement of the reference's "
-                      "search; Rust toolchain absent); thread counts tried %s, best reported; elements first-touched by 8 threads, %s; "
-                      "parallel_efficiency = value / (min(threads, %d physical cores) x single_thread)"
+                      "search; Rust toolchain absent); thread counts tried %s, best reported; elements first-touched by the OpenMP "
+                      "team (gro_parallel_copy), %s; parallel_efficiency = value / (usable cores x single_thread), usable = "
+                      "min(threads, %d physical cores, cgroup quota, affinity) = %.1f"
                       % (nqs, reps, cpu_s, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), cands,
-                         getattr(self, "_host_pages", "default pages"), phys),
+                         getattr(self, "_host_pages", "default pages"), phys, usable),
             "gpu_matches_oracle": {"ids_bit_exact": ids_ok, "dists_bit_exact": bool(d_ok), "queries_checked": int(nqs)},
         }
 
@@ -646,7 +781,7 @@ def run_replica(B, args):
     n, dim, nq, ef, k = args.n, args.dim, args.batch, args.ef, args.k
     esize = 4 if args.dtype == "f32" else 1
     n_batches = args.warmup + args.steps
-    inflight = auto_inflight(args, args.dtype, args.steps)
+    group = auto_group(args, args.steps)
 
     t0 = time.time()
     elements = B.rows(args.data, SEED, 0, n, dim, args.dtype)
@@ -666,8 +801,15 @@ def run_replica(B, args):
     if rank == 0:
         log("gen %.1fs, gpu build %.1fs, layers %s, index %.2f GB HBM" % (t_gen, t_build, layer_sizes, index.hbm_bytes() / 1e9))
 
-    m = B.measure(index, queries, dim, esize, nq, ef, k, args.steps, args.warmup, inflight, contract=True, steady_s=0.5)
+    m = B.measure(index, queries, dim, esize, nq, ef, k, args.steps, args.warmup, group, inflight=args.inflight, contract=True,
+                  steady_s=0.5, profile_only=args.profile_run)
     value = world * args.steps * nq / m["elapsed"]
+    if args.profile_run:  # rocprofv3 runs: the trace holds launches of the timed shape only
+        return {"metric": "queries/sec (profile run: timed launches only)", "value": round(value, 1), "unit": "queries/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 4),
+                "batches_per_call": m["group"], "calls": m["calls"], "inflight_streams": m["inflight"], "steady": m["steady"],
+                "launch_ms_hip_events": [round(x, 4) for x in m["group_launch_ms"]], "kernel_sources_sha": csrc_sha(),
+                "config": {"workload": workload_label(n, dim, args.dtype, args.data, nq, ef, k)}}
     wl_key = "%d|%d|%s|%s|nq%d|ef%d|k%d|nn%d|ms%d|re%d" % (n, dim, args.dtype, args.data, nq, ef, k, args.num_neighbors,
                                                         args.build_max_search, args.build_reinsert)
     if args.reorder:
@@ -676,10 +818,11 @@ def run_replica(B, args):
         "metric": "queries/sec (recall@10 alongside), 10M x 100-d angular, batch=1024",
         "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "inflight_batches": m["inflight"], "slow_path_queries": m["slow"], "visited_spill_walks": m["spill"],
+        "inflight_batches": m["inflight"], "batches_per_call": m["group"] if m["inflight"] == 1 else 1, "library_calls": m["calls"],
+        "slow_path_queries": m["slow"], "visited_spill_walks": m["spill"],
         "sequential": {"value": round(args.steps * nq / m["seq_elapsed"], 1),
                        "ms_per_step": round(m["seq_elapsed"] / args.steps * 1e3, 4),
-                       "note": "same K steps, one stream, one batch at a time (rank-local)"},
+                       "note": "same K steps, one stream, one batch PER CALL (rank-local)"},
         "steady": m["steady"],
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
@@ -689,8 +832,12 @@ def run_replica(B, args):
                       "max_search": args.build_max_search, "reinsert": bool(args.build_reinsert),
                       "layer_multiplier": 15.0, "batch_max": args.batch_max, "build_s": round(t_build, 1),
                       "reordered": bool(args.reorder), "reorder_s": round(t_reorder, 2)},
-            "parallelism": "replica x%d (one process per GPU, no data-path collective); %d batches in flight per GPU, "
-                           "GPU_MAX_HW_QUEUES=%s" % (world, m["inflight"], os.environ.get("GPU_MAX_HW_QUEUES")),
+            "parallelism": ("replica x%d (one process per GPU, no data-path collective); the K timed steps in %d call(s) of "
+                            "granne_hip_search_batches_device (%d batches = one launch each) on ONE stream, GPU_MAX_HW_QUEUES=%s"
+                            % (world, m["calls"], m["group"], os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default)")))
+            if m["inflight"] == 1 else
+                           ("replica x%d; one batch per call, %d batches in flight on HIP streams of the caller, "
+                            "GPU_MAX_HW_QUEUES=%s" % (world, m["inflight"], os.environ.get("GPU_MAX_HW_QUEUES"))),
         },
         "roofline": B.roofline(m, wl_key, value / world, nq),
         "kernel_sources_sha": csrc_sha(),
@@ -715,7 +862,7 @@ def run_replica(B, args):
             out["recall_at_10"] = round(B.recall(gt, got, k), 4)
             efs = [int(x) for x in args.sweep_ef.split(",") if x]
             if efs and order is None:
-                out["ef_sweep"] = B.ef_sweep(index, queries, gt, nq, k, efs, args.steps, args.warmup, inflight, stop_at=0.95)
+                out["ef_sweep"] = B.ef_sweep(index, queries, gt, nq, k, efs, args.steps, args.warmup, group, stop_at=0.95)
         if world == 1 and args.cpu_batches > 0:
             nb = min(args.cpu_batches, args.steps)
             h_q = queries[b0 * nq:(b0 + nb) * nq].cpu().numpy()
@@ -735,6 +882,7 @@ def run_replica(B, args):
         if world == 1 and not args.no_extras and args.dtype == "f32" and args.data == "uniform" and order is None:
             del index, builder, elements, queries
             torch.cuda.empty_cache()
+            out["c1"] = c1_record(B, args)
             out["int8"] = sub_record(B, args, "i8", "uniform", n, dim, nq, args.ef, args.steps, args.warmup,
                                      cpu_batches=args.cpu_batches, scaling=True)
             out["secondary"] = sub_record(B, args, "f32", "latent", n, dim, nq, args.ef, args.steps, args.warmup,
@@ -746,6 +894,64 @@ def run_replica(B, args):
                 out["c5_shard"] = sub_record(B, args, "i8", "uniform", args.c5_elements, 100, 4096, 200, 10, 2, cpu_batches=1,
                                              recall_queries=1024)
     return out
+
+
+def c1_record(B, args):
+    """BASELINE.json configs[0] = examples/glove.rs:46-60: ~400k x 100-d f32 angular vectors, index built with
+    BuildConfig::default().max_search(10), then `index.search(&index.get_element(i), 200, 10)` for i in 0, 134, 5555,
+    37000 -- member queries, one per call. GloVe itself is not in this image (no network): 400k rows of BASELINE's
+    synthetic generator stand in. The four searches go through granne_hip_search (host pointers, the reference's call
+    shape) and are compared with the CPU oracle on the same graph, bit for bit; a member's nearest neighbor must be itself
+    at distance max(0, 1 - x.x). Beside it: 1024 member queries in one call against the oracle's rate."""
+    torch = B.torch
+    n, dim, ef, k = 400_000, 100, 200, 10
+    t0 = time.time()
+    el = B.rows("uniform", SEED + 50, 0, n, dim, "f32")
+    builder = B.ga.GranneBuilder.from_device("angular", el.data_ptr(), n, dim, device=B.dev, stream=B.stream, num_neighbors=30,
+                                             max_search=10, reinsert_elements=True, batch_max=args.batch_max, show_progress=False)
+    builder.build()
+    index = builder.get_index()
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    members = [0, 134, 5555, 37000]
+    oix = B.host_index(el, builder)
+    singles, ok, self_first = [], True, True
+    for i in members:
+        x = index.get_element(i)
+        t1 = time.perf_counter()
+        res = index.search(x, ef, k)
+        dt = time.perf_counter() - t1
+        oi, od, oc, _ = oix.search_batch(x[None], ef, k, n_threads=1)
+        want = [(int(oi[0, j]), float(od[0, j])) for j in range(int(oc[0]))]
+        ok = ok and [r[0] for r in res] == [w[0] for w in want] and \
+            np.array([r[1] for r in res], np.float32).tobytes() == np.array([w[1] for w in want], np.float32).tobytes()
+        self_first = self_first and res[0][0] == i and res[0][1] <= 1e-6
+        singles.append({"member": i, "first": [res[0][0], res[0][1]], "call_us": round(dt * 1e6, 1)})
+    # 1024 members, one call (device-resident), against the oracle on all threads
+    mem = torch.arange(0, n, n // 1024, device="cuda")[:1024]
+    q = el[mem].contiguous()
+    ids = torch.empty((1024, k), dtype=torch.int64, device="cuda")
+    ds = torch.empty((1024, k), dtype=torch.float32, device="cuda")
+    cnt = torch.empty(1024, dtype=torch.int32, device="cuda")
+
+    def run(_j):
+        index.search_batch_device(q.data_ptr(), 1024, ef, k, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), 0, 0, B.stream)
+    rate, reps = B.timed_window(run, 1)
+    h_q = q.cpu().numpy()
+    cb = B.cpu_baseline(oix, h_q, ef, k, ids.cpu().numpy().astype(np.uint64), ds.cpu().numpy(), single_thread_queries=128, sweep=False)
+    batch_self = bool((ids[:, 0] == mem).all().item())
+    rec = {"workload": "C1 (BASELINE.json configs[0], examples/glove.rs:46-60): %d x %d-d f32 angular (synthetic stand-in for GloVe-100), "
+                       "build max_search 10, member queries at (max_search %d, k %d)" % (n, dim, ef, k),
+           "layers": [builder.layer_len(l) for l in range(builder.num_layers())], "build_s": round(t_build, 2),
+           "four_searches": singles, "four_searches_equal_oracle_bit_for_bit": bool(ok),
+           "self_is_nearest_at_distance_0": bool(self_first and batch_self),
+           "members_1024": {"value": round(rate * 1024, 1), "unit": "queries/s", "calls_timed": reps,
+                            "cpu_baseline": cb, "speedup_vs_cpu": round(rate * 1024 / cb["value"], 1)}}
+    if not (ok and self_first and batch_self and cb["gpu_matches_oracle"]["ids_bit_exact"] and cb["gpu_matches_oracle"]["dists_bit_exact"]):
+        raise RuntimeError("C1 parity failed: %s" % json.dumps(rec)[:600])
+    del oix, index, builder, el
+    torch.cuda.empty_cache()
+    return rec
 
 
 def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=1, scaling=False, find_ef=False,
@@ -762,25 +968,26 @@ def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=
     bf = {}
     gt = B.ground_truth(index, queries[warmup * nq:warmup * nq + rq], k, dtype, timing=bf)
     gt_dists = B._gt_dists
-    inflight = auto_inflight(args, dtype, steps)
+    group = auto_group(args, steps)
     layer_sizes = [builder.layer_len(l) for l in range(builder.num_layers())]
     rec = {"workload": workload_label(n, dim, dtype, data, nq, ef, k), "dtype": dtype, "data": "synthetic",
            "n_elements": n, "dim": dim, "layers": layer_sizes, "build_s": round(t_build, 1),
            "index_hbm_gb": round(index.hbm_bytes() / 1e9, 2), "brute_force": bf}
     if find_ef:
         sweep = B.ef_sweep(index, queries, gt, nq, k, [20, 30, 50, 70, 100, 140, 200, 300, 400, 600, 800], steps, warmup,
-                           inflight, stop_at=0.95)
+                           group, stop_at=0.95)
         rec["ef_sweep"] = sweep
         ok = [s for s in sweep if s["recall_at_10"] >= 0.95]
         ef = ok[0]["ef"] if ok else sweep[-1]["ef"]
         rec["smallest_ef_with_recall_0.95"] = ef if ok else None
         rec["workload"] = workload_label(n, dim, dtype, data, nq, ef, k)
-    m = B.measure(index, queries, dim, esize, nq, ef, k, steps, warmup, inflight, steady_s=0.3)
+    m = B.measure(index, queries, dim, esize, nq, ef, k, steps, warmup, group, inflight=args.inflight, steady_s=0.3)
     wl_key = "%d|%d|%s|%s|nq%d|ef%d|k%d|nn%d|ms%d|re%d" % (n, dim, dtype, data, nq, ef, k, args.num_neighbors,
                                                         args.build_max_search, args.build_reinsert)
     rec.update({
         "value": round(m["value_local"], 1), "unit": "queries/s", "ef_search": ef, "batch": nq, "k": k, "steps": steps,
-        "inflight_batches": m["inflight"], "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
+        "inflight_batches": m["inflight"], "batches_per_call": m["group"] if m["inflight"] == 1 else 1,
+        "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
         "sequential": {"value": round(steps * nq / m["seq_elapsed"], 1), "ms_per_step": round(m["seq_elapsed"] / steps * 1e3, 4)},
         "steady": m["steady"],
         "slow_path_queries": m["slow"], "visited_spill_walks": m["spill"],
@@ -795,7 +1002,7 @@ def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=
         g_ids = m["ids"][warmup:warmup + nb].reshape(-1, k).cpu().numpy().astype(np.uint64)
         g_d = m["dists"][warmup:warmup + nb].reshape(-1, k).cpu().numpy()
         oix = B.host_index(elements, builder)
-        rec["cpu_baseline"] = B.cpu_baseline(oix, h_q, ef, k, g_ids, g_d, single_thread_queries=128)
+        rec["cpu_baseline"] = B.cpu_baseline(oix, h_q, ef, k, g_ids, g_d, single_thread_queries=128, sweep=False)
         rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 2)
         if n <= 20_000_000:  # (the oracle's scan of 125M rows is not worth its minute)
             B._gt_dists = gt_dists
@@ -807,13 +1014,27 @@ def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=
     return rec
 
 
+def _merge_rows_numpy(dists, ids, k):
+    """[nq, m] distances and global ids -> the k smallest by (distance, id) per row (ground truth over all shards)."""
+    order = np.lexsort((ids, dists), axis=1)[:, :k]
+    return np.take_along_axis(ids, order, 1), np.take_along_axis(dists, order, 1)
+
+
 def partitioned_record(B, args, n, dim, dtype, nq, ef, k, steps, warmup, spg, seed_base, depth=2, with_cpu=True):
     """The element set split into world * spg id ranges, one independent index per range
-    (src/elements/embeddings/parsing.rs:63-100). A step = one batch through every shard's search + ONE all-gather of the
-    packed per-shard top-k + the merge kernel; steps are pipelined `depth` deep (granne_amd/sharded.py). Collective:
-    every rank calls this with the same arguments. Returns the record (the same on every rank up to rank-local timings)."""
+    (src/elements/embeddings/parsing.rs:63-100). A step = one batch through every shard's search + the ONE exchange step
+    of the packed per-shard top-k + the merge kernel; steps are pipelined `depth` deep. Two drivers over the same kernels:
+      torch  granne_amd/sharded.py: one process per GPU, torch streams, all_gather_into_tensor (RCCL) between ranks;
+      cabi   granne_hip_sharded_begin_device / _end_device: ONE host process holds every shard (what a Rust host binds),
+             peer copies or an in-library ncclAllGather as the exchange -- measured when world == 1.
+    Shards are built one after the other and only the searchable index is kept (elements and builder of a shard are
+    released before the next is generated): 8 x 12.5M x 200-d f32 or 4 x 125M x 100-d int8 fit one MI355X that way.
+    Collective: every rank calls this with the same arguments. Returns the record (rank-local timings aside, the same
+    on every rank)."""
     torch, dist = B.torch, B.dist
+    from granne_amd import _lib as glib
     from granne_amd import sharded
+    from oracle.merge import merge_topk_numpy, unpack_topk  # the checker, as in replica mode
     world, rank = B.world, B.rank
     G = world * spg
     esize = 4 if dtype == "f32" else 1
@@ -821,24 +1042,51 @@ def partitioned_record(B, args, n, dim, dtype, nq, ef, k, steps, warmup, spg, se
     bounds = sharded.shard_bounds(n, G)
     offsets = [b[0] for b in bounds]
     mine = list(range(rank * spg, (rank + 1) * spg))
-    t0 = time.time()
-    # per-shard seed, clear of the query stream's (SEED + 1): shard g is rows 0.. of stream seed_base + g
-    elements = [B.rows(args.data, seed_base + g, 0, bounds[g][1] - bounds[g][0], dim, dtype) for g in mine]
+    b0 = warmup  # the batch parity and recall are taken on
     queries = B.rows(args.data, SEED + 1, 0, n_batches * nq, dim, dtype)  # the SAME batches on every rank
-    torch.cuda.synchronize()
-    t_gen = time.time() - t0
-    builders, indexes, t_build = [], [], 0.0
-    for e in elements:
-        b, ix, tb = B.build_index(e, dtype)
-        builders.append(b)
-        indexes.append(ix)
+    q1 = queries[b0 * nq:(b0 + 1) * nq]
+    h_q1 = q1.cpu().numpy()
+    want_cpu = with_cpu and args.cpu_batches > 0
+    indexes, layer_sizes, t_gen, t_build = [], None, 0.0, 0.0
+    oracle_parts, cb, gt_parts = {}, None, []
+    for j, g in enumerate(mine):
+        t0 = time.time()
+        # per-shard seed, clear of the query stream's (SEED + 1): shard g is rows 0.. of stream seed_base + g
+        el = B.rows(args.data, seed_base + g, 0, bounds[g][1] - bounds[g][0], dim, dtype)
+        torch.cuda.synchronize()
+        t_gen += time.time() - t0
+        builder, ix, tb = B.build_index(el, dtype)
         t_build += tb
-    layer_sizes = [builders[0].layer_len(l) for l in range(builders[0].num_layers())]
-    if rank == 0:
-        log("partitioned: gen %.1fs, gpu build %.1fs (%d local shards), shard layers %s" % (t_gen, t_build, spg, layer_sizes))
-    sg = sharded.ShardedGranne(indexes, offsets)
+        if layer_sizes is None:
+            layer_sizes = [builder.layer_len(l) for l in range(builder.num_layers())]
+        if not args.no_recall:  # exact k nearest of this shard (the scan on the matrix cores), global ids
+            gi = B.ground_truth(ix, q1[:min(nq, 1024)], k, dtype)
+            gt_parts.append((gi.astype(np.int64) + offsets[g], B._gt_dists.copy()))
+        if want_cpu and (j == 0 or args.parity_all_shards):
+            oix = B.host_index(el, builder)
+            if j == 0:  # the CPU baseline: this rank's first shard, timed (the others are searched once, for parity)
+                saved = (args.cpu_threads, args.cpu_seconds)
+                if world > 1:  # every rank runs this on the same host: share the cores, keep it short
+                    args.cpu_threads = max(1, (os.cpu_count() or 2) // (2 * world))
+                    args.cpu_seconds = min(args.cpu_seconds, 0.5)
+                o_ids, o_d, o_c, _ = oix.search_batch(h_q1, ef, k, n_threads=args.cpu_threads or 0)
+                cb = B.cpu_baseline(oix, h_q1, ef, k, o_ids, o_d, single_thread_queries=64, sweep=(world == 1 and spg == 1))
+                args.cpu_threads, args.cpu_seconds = saved
+            else:
+                o_ids, o_d, o_c, _ = oix.search_batch(h_q1, ef, k, n_threads=0)
+            oracle_parts[g] = (o_ids, o_d, o_c)
+            del oix
+        del builder, el
+        torch.cuda.empty_cache()
+        indexes.append(ix)
+        if rank == 0:
+            log("partitioned: shard %d/%d built (%.1fs so far), %.1f GB of HBM in indexes"
+                % (j + 1, spg, t_build, sum(i.hbm_bytes() for i in indexes) / 1e9))
     batches = [queries[b * nq:(b + 1) * nq] for b in range(n_batches)]
+    drivers = {}
 
+    # ---- driver "torch": granne_amd/sharded.py -----------------------------------------------------------------------
+    sg = sharded.ShardedGranne(indexes, offsets)
     sg.search_batches(batches[:max(warmup, depth)], ef, k, depth=depth)
     B.barrier()
     t0 = time.perf_counter()
@@ -851,10 +1099,8 @@ def partitioned_record(B, args, n, dim, dtype, nq, ef, k, steps, warmup, spg, se
         elapsed = float(t.item())
     if bool(sg.status_of_last_batch(0)[:, 0].any().item()):
         raise RuntimeError("exact-search scratch exhausted during the timed steps")
-    value = steps * nq / elapsed  # every rank answers the same queries: the job's rate, not a sum over ranks
-    out_ids = torch.stack([r[0] for r in res])
-    out_d = torch.stack([r[1] for r in res])
-
+    t_ids = torch.stack([r[0] for r in res])
+    t_d = torch.stack([r[1] for r in res])
     # the same steps strictly one batch at a time, and its phases (HIP events; synchronised, so not the pipelined rate)
     B.barrier()
     t0 = time.perf_counter()
@@ -868,100 +1114,171 @@ def partitioned_record(B, args, n, dim, dtype, nq, ef, k, steps, warmup, spg, se
         for key in ph:
             ph[key].append(sg.timings[key])
     phases = {key: round(float(np.mean(v)), 4) for key, v in ph.items()}
+    drivers["torch"] = {"value": round(steps * nq / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+                        "sequential": {"value": round(steps * nq / seq_elapsed, 1), "ms_per_step": round(seq_elapsed / steps * 1e3, 4)},
+                        "phases_ms": phases, "exchange": "all_gather_into_tensor (RCCL)" if world > 1 else "none (one rank: shards write the gather buffer)",
+                        "what": "granne_amd/sharded.py: torch streams, %d batches pipelined" % depth}
+    # this batch's per-shard results as the ranks exchanged them (slot 0 holds the gathered buffers of the last search_batch)
+    sg.search_batch(q1, ef, k)
+    torch.cuda.synchronize()
+    gathered = sg._slots[0].gathered.view(G, -1).cpu().numpy()
+    parts = [unpack_topk(gathered[g], nq, k) for g in range(G)]
+    del sg
+
+    # ---- driver "cabi": the one-process handle of include/granne_hip.h ---------------------------------------------------
+    c_ids = c_d = None
+    if world == 1:
+        o_ids = torch.empty((n_batches, nq, k), dtype=torch.int64, device="cuda")
+        o_d = torch.empty((n_batches, nq, k), dtype=torch.float32, device="cuda")
+        o_c = torch.empty((n_batches, nq), dtype=torch.int32, device="cuda")
+        status = torch.zeros(4, dtype=torch.int32, device="cuda")
+        s_ = B.stream
+        qp = [batches[b].data_ptr() for b in range(n_batches)]
+        ip, dp, cp = [o_ids[b].data_ptr() for b in range(n_batches)], [o_d[b].data_ptr() for b in range(n_batches)], \
+            [o_c[b].data_ptr() for b in range(n_batches)]
+        for name, exch in (("cabi", glib.SHARDED_EXCHANGE_PEER), ("cabi_rccl", glib.SHARDED_EXCHANGE_RCCL)):
+            sh = sharded.ShardedHost(indexes, offsets, depth=depth)
+            try:
+                if exch != glib.SHARDED_EXCHANGE_PEER:
+                    sh.set_option(glib.SHARDED_OPT_EXCHANGE, exch)
+            except glib.GranneHipError as e:  # no librccl to load: say so, measure the rest
+                drivers[name] = {"skipped": str(e)}
+                sh.close()
+                continue
+
+            def pipelined(first, count):
+                tickets = []
+                for i in range(count):
+                    b = first + i
+                    tickets.append(sh.begin_device(qp[b], nq, ef, k, ip[b], dp[b], cp[b], status.data_ptr(), s_))
+                    if i >= depth - 1:
+                        sh.end_device(tickets[i - depth + 1], s_)
+                for tk in tickets[max(0, count - depth + 1):]:
+                    sh.end_device(tk, s_)
+
+            pipelined(0, max(warmup, depth))
+            torch.cuda.synchronize()
+            status.zero_()
+            t0 = time.perf_counter()
+            pipelined(warmup, steps)
+            torch.cuda.synchronize()
+            el_c = time.perf_counter() - t0
+            if int(status[0].item()):
+                raise RuntimeError("exact-search scratch exhausted during the timed steps (cabi)")
+            t0 = time.perf_counter()
+            for b in range(warmup, n_batches):  # one batch at a time: stream-ordered, nothing overlaps, no host synchronisation
+                sh.search_batch_device(qp[b], nq, ef, k, ip[b], dp[b], cp[b], 0, s_)
+            torch.cuda.synchronize()
+            seq_c = time.perf_counter() - t0
+            # host buffers in and out (pinned staging + PCIe inside the clock), pipelined inside the library
+            h_q = queries[warmup * nq:].cpu().numpy().reshape(steps, nq, dim)
+            sh.search_batches(h_q[:depth], ef, k)
+            t0 = time.perf_counter()
+            h_res = sh.search_batches(h_q, ef, k)
+            host_c = time.perf_counter() - t0
+            drivers[name] = {"value": round(steps * nq / el_c, 1), "ms_per_step": round(el_c / steps * 1e3, 4),
+                             "sequential": {"value": round(steps * nq / seq_c, 1), "ms_per_step": round(seq_c / steps * 1e3, 4)},
+                             "host_pointers": {"value": round(steps * nq / host_c, 1), "ms_per_step": round(host_c / steps * 1e3, 4),
+                                               "note": "granne_hip_sharded_search_batches: queries from and results to host memory, PCIe inside the clock"},
+                             "exchange": "shards write the merge device's gather buffer; peer copies for remote shards" if exch == glib.SHARDED_EXCHANGE_PEER
+                                         else "one in-place ncclAllGather (librccl by dlopen) over %d device(s)" % 1,
+                             "what": "granne_hip_sharded_begin_device / _end_device on one stream, %d batches in flight" % depth}
+            same = bool((o_ids[warmup:] == t_ids).all().item()) and bool((o_d[warmup:].view(torch.int32) == t_d.view(torch.int32)).all().item()) \
+                and bool((torch.from_numpy(h_res[0].astype(np.int64)).cuda() == t_ids).all().item())
+            drivers[name]["same_results_as_torch_driver"] = same
+            if not same:
+                raise RuntimeError("the %s driver and the torch driver returned different results" % name)
+            if name == "cabi":
+                c_ids, c_d = o_ids[warmup:].clone(), o_d[warmup:].clone()
+            sh.close()
+
+    pick = args.driver if (args.driver in drivers and "value" in drivers[args.driver]) else "torch"
+    value, ms_step = drivers[pick]["value"], drivers[pick]["ms_per_step"]  # every rank answers the same queries: the job's rate, not a sum over ranks
+    out_ids, out_d = (c_ids, c_d) if (pick == "cabi" and c_ids is not None) else (t_ids, t_d)
 
     # roofline of the dominant kernel: shard 0 of this rank, one launch at a time
     m = B.measure(indexes[0], queries, dim, esize, nq, ef, k, steps, warmup, 1)
     out = {
         "metric": "queries/sec, partitioned index (every rank searches every batch), batch=%d" % nq,
-        "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "partitioned",
-        "scaling_note": "the element set is split over the ranks and every rank answers the SAME queries: value is the job's "
+        "value": value, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "partitioned",
+        "scaling_note": "the element set is split over the shards and every shard answers the SAME queries: value is the job's "
                         "rate (not a sum over ranks), per-GPU work shrinks as ranks are added",
-        "pipeline_depth": depth,
-        "sequential": {"value": round(steps * nq / seq_elapsed, 1), "ms_per_step": round(seq_elapsed / steps * 1e3, 4),
-                       "note": "one batch at a time: search, all-gather, merge, then the next batch"},
+        "driver": pick, "drivers": drivers, "pipeline_depth": depth,
+        "sequential": drivers[pick]["sequential"],
         "dtype": dtype, "data": "synthetic",
         "config": {
             "workload": "%d x %d-d %s angular in %d shards of %d, batch=%d, ef_search=%d, k=%d"
                         % (n, dim, dtype, G, bounds[0][1] - bounds[0][0], nq, ef, k),
             "n_elements": n, "shards": G, "shards_per_gpu": spg, "shard_elements": bounds[0][1] - bounds[0][0], "dim": dim,
             "batch": nq, "ef_search": ef, "k": k, "shard_layers": layer_sizes,
+            "index_hbm_gb": round(sum(i.hbm_bytes() for i in indexes) / 1e9, 2),
             "graph": {"builder": "gpu-batched", "num_neighbors": args.num_neighbors, "max_search": args.build_max_search,
                       "reinsert": bool(args.build_reinsert), "layer_multiplier": 15.0, "batch_max": args.batch_max,
-                      "build_s": round(t_build, 1)},
-            "parallelism": "partitioned x%d (%d ranks x %d shards; one all-gather of the packed per-shard top-k + status words "
-                           "per batch, then merge_topk_kernel; %d batches pipelined)" % (G, world, spg, depth),
+                      "build_s": round(t_build, 1), "gen_s": round(t_gen, 1)},
+            "parallelism": "partitioned x%d (%d ranks x %d shards; the packed per-shard top-k + status words exchanged once per batch, "
+                           "then merge_topk_kernel; %d batches pipelined)" % (G, world, spg, depth),
         },
-        "exchange": {"collective": "all_gather_into_tensor (RCCL)" if world > 1 else "none (one rank)",
-                     "collectives_per_batch": 1 if world > 1 else 0,
-                     "bytes_per_rank_per_batch": sg.exchange_bytes_per_rank(nq, k), "ranks": world},
+        "exchange": {"collectives_per_batch": 1 if world > 1 else 0,
+                     "bytes_per_shard_per_batch": int(sharded.packed_bytes(nq, k) + sharded.STATUS_BYTES), "ranks": world},
         "phases_ms": phases,
         "roofline": B.roofline(m, "partitioned|%d|%d|%s|nq%d|ef%d" % (bounds[0][1] - bounds[0][0], dim, dtype, nq, ef),
                                m["value_local"], nq),
     }
-    out["roofline"]["note"] = "search kernel of ONE shard (this rank's first), one launch at a time"
+    out["roofline"]["note"] = "search kernel of ONE shard (this rank's first), one batch per launch"
 
-    # ---- recall against exact brute force over ALL shards --------------------------------------------
-    b0 = warmup
+    # ---- recall against the exact scan over ALL shards ----------------------------------------------------------------
     if not args.no_recall:
-        q0 = queries[b0 * nq:(b0 + 1) * nq]
-        loc_v, loc_i = [], []
-        for j, g in enumerate(mine):
-            gt = torch.from_numpy(B.ground_truth(indexes[j], q0, k, dtype)).cuda()
-            e = elements[j].float()
-            if dtype == "i8":
-                e = e / e.norm(dim=1, keepdim=True).clamp_min(1e-30)
-            sims = (q0.float()[:, None, :] * e[gt]).sum(-1)
-            loc_v.append(sims)
-            loc_i.append(gt + offsets[g])
-        lv, li = torch.cat(loc_v, 1), torch.cat(loc_i, 1)
+        li = torch.from_numpy(np.concatenate([p_[0] for p_ in gt_parts], 1)).cuda()
+        lv = torch.from_numpy(np.concatenate([p_[1] for p_ in gt_parts], 1)).cuda()
         if world > 1:
             av = [torch.empty_like(lv) for _ in range(world)]
             ai = [torch.empty_like(li) for _ in range(world)]
             dist.all_gather(av, lv)
             dist.all_gather(ai, li)
             lv, li = torch.cat(av, 1), torch.cat(ai, 1)
-        top = lv.topk(k, dim=1).indices
-        gt_all = li.gather(1, top).cpu().numpy()
-        out["recall_at_10"] = round(B.recall(gt_all, out_ids[0], k), 4)
+        gt_all, _ = _merge_rows_numpy(lv.cpu().numpy(), li.cpu().numpy(), k)
+        rq = gt_all.shape[0]
+        out["recall_at_10"] = round(B.recall(gt_all, out_ids[0][:rq], k), 4)
 
-    # ---- parity: this rank's first shard against the CPU oracle; the merge against the numpy merge ----
-    if with_cpu and args.cpu_batches > 0:
-        from oracle.merge import merge_topk_numpy, unpack_topk  # the checker, as in replica mode
-        q1 = queries[b0 * nq:(b0 + 1) * nq]
-        sg.search_batch(q1, ef, k)  # slot 0 now holds this batch's gathered per-shard results
-        torch.cuda.synchronize()
-        gathered = sg._slots[0].gathered.view(G, -1).cpu().numpy()
-        parts = [unpack_topk(gathered[g], nq, k) for g in range(G)]
+    # ---- parity: shard results against the CPU oracle; the merged result against the numpy merge -----------------------
+    if want_cpu:
         w_ids, w_d, w_c = merge_topk_numpy(np.stack([p_[0] for p_ in parts]), np.stack([p_[1] for p_ in parts]),
                                            np.stack([p_[2] for p_ in parts]), offsets, k)
         merge_ok = bool((out_ids[0].cpu().numpy().astype(np.uint64) == w_ids).all()
                         and out_d[0].cpu().numpy().tobytes() == w_d.tobytes())
-        oix = B.host_index(elements[0], builders[0])
-        mi, md, mc = parts[mine[0]]
-        saved = (args.cpu_threads, args.cpu_seconds)
-        if world > 1:  # every rank runs this on the same host: share the cores, keep it short
-            args.cpu_threads = max(1, (os.cpu_count() or 2) // (2 * world))
-            args.cpu_seconds = min(args.cpu_seconds, 0.5)
-        cb = B.cpu_baseline(oix, q1.cpu().numpy(), ef, k, mi, md, single_thread_queries=64)
-        args.cpu_threads, args.cpu_seconds = saved
-        shard_ok = bool(cb["gpu_matches_oracle"]["ids_bit_exact"] and cb["gpu_matches_oracle"]["dists_bit_exact"])
+        shard_ok, checked = True, 0
+        for g, (oi, od, oc) in oracle_parts.items():
+            gi, gd, gc = parts[g]
+            shard_ok = shard_ok and bool((gi == oi).all()) and gd.tobytes() == od.tobytes() and bool((gc == oc).all())
+            checked += 1
+        oracle_merge_ok = None
+        if world == 1 and len(oracle_parts) == G:  # every shard came from the oracle: the whole job against the CPU restatement
+            x_ids, x_d, x_c = merge_topk_numpy(np.stack([oracle_parts[g][0] for g in range(G)]), np.stack([oracle_parts[g][1] for g in range(G)]),
+                                               np.stack([oracle_parts[g][2] for g in range(G)]), offsets, k)
+            oracle_merge_ok = bool((out_ids[0].cpu().numpy().astype(np.uint64) == x_ids).all()
+                                   and out_d[0].cpu().numpy().tobytes() == x_d.tobytes())
         ok = torch.tensor([int(merge_ok), int(shard_ok)], dtype=torch.int32, device="cuda")
         if B.use_dist:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         shard_rate = cb["value"]
         out["cpu_baseline"] = {
             "value": round(shard_rate / max(1, G), 1), "unit": "queries/s", "cores": cb["cores"], "kind": "port",
-            "one_shard": {"value": shard_rate, "single_thread": cb["single_thread"], "parallel_efficiency": cb["parallel_efficiency"]},
+            "one_shard": {"value": shard_rate, "single_thread": cb["single_thread"], "parallel_efficiency": cb["parallel_efficiency"],
+                          "thread_sweep": cb.get("thread_sweep")},
+            "host": cb.get("host"),
             "sample": "search only (the host index view is built outside the clock): " + cb["sample"] + "; measured on ONE shard of "
                       "%d -- a CPU host answering the partitioned index searches all %d shards per query, so the job rate is that "
                       "shard rate / %d" % (bounds[0][1] - bounds[0][0], G, G),
-            "gpu_matches_oracle": {"every_rank_first_shard_bit_exact": bool(int(ok[1].item())),
+            "gpu_matches_oracle": {"shards_checked_against_oracle_per_rank": checked, "those_shards_bit_exact_on_every_rank": bool(int(ok[1].item())),
                                    "merged_equals_numpy_merge_of_shard_results": bool(int(ok[0].item())),
+                                   "merged_equals_numpy_merge_of_ORACLE_shard_results": oracle_merge_ok,
                                    "queries_checked": int(nq)},
         }
-        del oix
-    del m, sg, indexes, builders, elements, queries
+        out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        if not (merge_ok and shard_ok and oracle_merge_ok is not False):
+            raise RuntimeError("partitioned parity failed: %s" % out["cpu_baseline"]["gpu_matches_oracle"])
+    del m, indexes, queries
     torch.cuda.empty_cache()
     return out
 

@@ -15,6 +15,8 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OVERFLOW, ERR_IO = -1, -2, -3, -4, -5
 
 OPT_VISITED_SLOTS, OPT_FORCE_SLOW, OPT_SLOW_SLOTS, OPT_SLOW_BLOCKS, OPT_OVERFLOW_SLOTS = 1, 2, 3, 4, 5
 OPT_VISITED16, OPT_VISITED16_LG = 6, 7
+SHARDED_OPT_DEPTH, SHARDED_OPT_EXCHANGE = 1, 2
+SHARDED_EXCHANGE_PEER, SHARDED_EXCHANGE_RCCL = 0, 1
 
 
 class GranneHipError(RuntimeError):
@@ -61,6 +63,7 @@ SIGNATURES = {
     "granne_hip_index_get_element": (i32, [vp, u64, vp]),
     "granne_hip_search_batch": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
     "granne_hip_search_batch_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]),
+    "granne_hip_search_batches_device": (i32, [vp, u32, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]),
     "granne_hip_event_create": (i32, [vp]),
     "granne_hip_event_destroy": (None, [vp]),
     "granne_hip_event_elapsed_ms": (i32, [vp, vp, vp]),
@@ -94,6 +97,13 @@ SIGNATURES = {
     "granne_hip_sharded_destroy": (None, [vp]),
     "granne_hip_sharded_num_shards": (u32, [vp]),
     "granne_hip_sharded_len": (u64, [vp]),
+    "granne_hip_sharded_device": (i32, [vp]),
+    "granne_hip_sharded_set_option": (i32, [vp, i32, u64]),
+    "granne_hip_sharded_get_option": (i32, [vp, i32, C.POINTER(u64)]),
+    "granne_hip_sharded_search_batch_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp]),
+    "granne_hip_sharded_begin_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, C.POINTER(u64)]),
+    "granne_hip_sharded_end_device": (i32, [vp, u64, vp]),
+    "granne_hip_sharded_search_batches": (i32, [vp, vp, u32, u32, u32, u32, vp, vp, vp]),
     "granne_hip_sharded_search_batch": (i32, [vp, vp, u32, u32, u32, vp, vp, vp]),
     "granne_hip_sharded_search": (i32, [vp, vp, u32, u32, vp, vp, C.POINTER(u32)]),
     "granne_hip_build_config_default": (None, [vp]),

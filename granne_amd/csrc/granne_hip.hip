@@ -772,24 +772,35 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
 // walker's containers) is kept per (index, stream) for the life of the index: launches on one stream run in
 // order, so they can share a block, and the kernels leave its control words and region states zeroed -- no
 // allocator call and no memset per search.
+constexpr size_t SLOW_SCRATCH_BUDGET = (size_t)1 << 30;               // bytes of exact-walker containers per scratch block
 constexpr uint32_t SCRATCH_MAX_REGIONS = 16384;                       // 256 CUs x 32 waves x 2
 constexpr size_t SCRATCH_STATE_OFF = CTL_WORDS * 4;                   // region states follow the control words
 constexpr size_t SCRATCH_FIXED = SCRATCH_STATE_OFF + (size_t)SCRATCH_MAX_REGIONS * 4; // zero between launches
 
-static int scratch_for(ScratchCache* cache, hipStream_t s, size_t total, uint8_t** out) {
-    // (the caller holds cache->mu for the whole enqueue)
+constexpr size_t SCRATCH_CACHE_STREAMS = 64;      // streams that keep a block for the life of the index
+constexpr size_t SCRATCH_SHRINK_ABOVE = 256u << 20; // a cached block this large is let go when a launch needs < 1/4 of it
+
+// `*transient` is set when the block was taken from the stream-ordered allocator for this launch alone (the cache is
+// full: a caller with more live streams than SCRATCH_CACHE_STREAMS): the caller frees it with hipFreeAsync after its
+// last use on `s`. No device-wide synchronisation anywhere.
+static int scratch_for(ScratchCache* cache, hipStream_t s, size_t total, uint8_t** out, bool* transient) {
+    // (the caller holds cache->mu for the enqueue)
+    *transient = false;
     ScratchCache::Block* b = nullptr;
     for (auto& x : cache->blocks)
         if (x.stream == s) b = &x;
     if (!b) {
-        if (cache->blocks.size() >= 64) { // a caller that keeps inventing streams: start over
-            HIP_TRY(hipDeviceSynchronize());
-            cache->free_all();
+        if (cache->blocks.size() >= SCRATCH_CACHE_STREAMS) {
+            HIP_TRY(hipMallocAsync((void**)out, total, s));
+            HIP_TRY(hipMemsetAsync(*out, 0, SCRATCH_FIXED, s));
+            *transient = true;
+            return GRANNE_HIP_OK;
         }
         cache->blocks.push_back({s, nullptr, 0});
         b = &cache->blocks.back();
     }
-    if (b->cap < total) {
+    const bool oversized = b->cap > SCRATCH_SHRINK_ABOVE && total < b->cap / 4; // e.g. after one exact-walker batch
+    if (b->cap < total || oversized) {
         if (b->p) {
             HIP_TRY(hipStreamSynchronize(s)); // earlier launches on this stream still use the old block
             (void)hipFree(b->p);
@@ -810,11 +821,30 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
                          uint32_t* d_status, hipStream_t s, uint32_t* h_slow_count /* optional, syncs */,
                          uint32_t* d_trail = nullptr /* [nq][8]: trail mode, no search outputs */,
                          uint32_t trail_layers = 0, hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr,
-                         uint32_t* host_status = nullptr /* u32[2], host-mapped: hand-over count and exhaustion flag, plain stores */) {
+                         uint32_t* host_status = nullptr /* u32[2], host-mapped: hand-over count and exhaustion flag, plain stores */,
+                         const BatchIO* batches = nullptr, uint32_t n_batches = 0 /* > 0: `nq` queries in EACH of these, one launch */) {
     if (ef == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
     if (nq == 0) return GRANNE_HIP_OK;
+    if (n_batches > MAX_LAUNCH_BATCHES) return fail(GRANNE_HIP_ERR_INVALID, "at most %u batches per launch", MAX_LAUNCH_BATCHES);
+    if (n_batches && (uint64_t)n_batches * nq > 0x7FFFFFFFull) return fail(GRANNE_HIP_ERR_INVALID, "too many queries in one launch");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+    const uint32_t batch_nq = nq;
+    if (n_batches) {
+        for (uint32_t b = 0; b < n_batches; ++b)
+            if (!batches[b].queries || !batches[b].out_counts || (k && (!batches[b].out_ids || !batches[b].out_dists)))
+                return fail(GRANNE_HIP_ERR_INVALID, "null buffer (batch %u)", b);
+        if (k == 0) {
+            for (uint32_t b = 0; b < n_batches; ++b) HIP_TRY(hipMemsetAsync(batches[b].out_counts, 0, (size_t)nq * 4, s));
+            return GRANNE_HIP_OK;
+        }
+        d_queries = batches[0].queries;
+        d_ids = batches[0].out_ids;
+        d_dists = batches[0].out_dists;
+        d_counts = batches[0].out_counts;
+        d_stats = batches[0].out_stats;
+        nq *= n_batches; // walkers of the launch
+    }
     if (k == 0 && !d_trail) { // .take(0): every result is empty (src/index/mod.rs:974-977)
         if (!d_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
         HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)nq * 4, s));
@@ -850,13 +880,19 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     // The exact walker's blocks: a few as the tail of a register-walker launch (hand-overs are rare), many when the whole
     // batch is its to walk (max_search beyond the register lists, GRANNE_HIP_OPT_FORCE_SLOW): one block per query up to
     // 32x the option (512 at its default of 16) -- each block owns 12 bytes x slow_slots of global scratch.
+    // Every block owns 12 bytes x slow_slots + 8 x max_search of global scratch (3 MB at the default 2^18 slots), and the
+    // scratch block is kept per (index, stream): the many-block form is bounded by SLOW_SCRATCH_BUDGET bytes (never below
+    // the option itself), so that a handful of streams searching beyond the register lists hold a few GB, not tens.
     uint32_t slow_blocks = (uint32_t)ix->opt_slow_blocks;
+    const uint32_t slots = (uint32_t)ix->opt_slow_slots;
     if (all_slow) {
-        const uint32_t most = slow_blocks * 32u;
+        uint32_t most = slow_blocks * 32u;
+        const size_t per_block = (size_t)slots * 12 + (size_t)ef * 8;
+        const size_t fit = SLOW_SCRATCH_BUDGET / per_block;
+        if (most > fit) most = fit > slow_blocks ? (uint32_t)fit : slow_blocks;
         slow_blocks = nq < most ? (nq > slow_blocks ? nq : slow_blocks) : most;
     }
     const uint32_t n_tail = all_slow ? 0u : (slow_blocks < nq ? slow_blocks : nq);
-    const uint32_t slots = (uint32_t)ix->opt_slow_slots;
     const size_t list_bytes = ((size_t)nq * 4 + 15) & ~(size_t)15;
     size_t off_list = SCRATCH_FIXED;
     size_t off_ovf = off_list + list_bytes;
@@ -865,12 +901,23 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     size_t off_pq = off_vis + (size_t)slow_blocks * slots * 4;
     size_t off_res = off_pq + (size_t)slow_blocks * slots * 8;
     size_t total = off_res + (size_t)slow_blocks * ef * 8;
-    std::lock_guard<std::mutex> cache_lock(ix->scratch->mu);
+    // The cache's mutex covers finding (or growing) this stream's block and the enqueue -- host work of microseconds.
+    // Whatever waits for the GPU (the synchronisation behind h_slow_count) happens after it is released: host threads
+    // searching one index on streams of their own do not queue behind each other's kernels.
+    std::unique_lock<std::mutex> cache_lock(ix->scratch->mu);
     uint8_t* scratch = nullptr;
+    bool transient = false;
     {
-        int r = scratch_for(ix->scratch, s, total, &scratch);
+        int r = scratch_for(ix->scratch, s, total, &scratch, &transient);
         if (r) return r;
     }
+    struct FreeTransient { // a block of the stream-ordered allocator goes back after the launch's last use of it
+        uint8_t* p;
+        hipStream_t s;
+        ~FreeTransient() {
+            if (p) (void)hipFreeAsync(p, s);
+        }
+    } free_transient{transient ? scratch : nullptr, s};
     uint32_t* ctl = (uint32_t*)scratch;
 
     SlowParams sp;
@@ -914,6 +961,9 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.ovf.spilled = d_status ? d_status + 2 : ctl + CTL_SPILLED;
     p.trail_out = d_trail;
     p.trail_layers = trail_layers;
+    p.n_batches = n_batches;
+    p.batch_nq = batch_nq;
+    for (uint32_t b = 0; b < n_batches; ++b) p.batch[b] = batches[b];
     sp.ctl = ctl;
     sp.vis = (uint32_t*)(scratch + off_vis);
     sp.pq = (uint64_t*)(scratch + off_pq);
@@ -948,8 +998,9 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
 
     if (h_slow_count) {
         uint32_t hs[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(hs, ctl + CTL_LAST_SLOW, 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpyAsync(hs, ctl + CTL_LAST_SLOW, 8, hipMemcpyDeviceToHost, s)); // enqueued under the lock, ...
+        cache_lock.unlock();
+        HIP_TRY(hipStreamSynchronize(s));                                               // ... waited for outside it
         h_slow_count[0] = hs[0]; // queries served by the global-memory walker
         h_slow_count[1] = hs[1]; // its containers ran out
     }
@@ -975,6 +1026,42 @@ extern "C" int granne_hip_search_batch_device_timed(const granne_hip_index* ix, 
     return search_launch(&T, d_queries, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
                          d_out_ids, d_out_dists, d_out_counts, d_out_stats, d_status, (hipStream_t)stream, nullptr,
                          nullptr, 0, (hipEvent_t)ev_before, (hipEvent_t)ev_after);
+}
+
+// Several batches of `nq` queries in ONE launch: a grid of n_batches x nq walkers, which the dispatcher refills from as
+// walks finish -- the in-flight depth a host otherwise has to provide with streams of its own (a launch of 1024 walks is
+// one wave per SIMD and lasts as long as its slowest walk). More than MAX_LAUNCH_BATCHES batches go out as several
+// launches on the same stream.
+extern "C" int granne_hip_search_batches_device(const granne_hip_index* ix, uint32_t n_batches, const void* const* d_queries,
+                                                uint32_t nq, uint32_t max_search, uint32_t num_neighbors,
+                                                uint64_t* const* d_out_ids, float* const* d_out_dists,
+                                                uint32_t* const* d_out_counts, uint64_t* const* d_out_stats,
+                                                uint32_t* d_status, void* stream) {
+    if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (max_search == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
+    if (n_batches == 0 || nq == 0) return GRANNE_HIP_OK;
+    if (!d_queries || !d_out_counts || (num_neighbors && (!d_out_ids || !d_out_dists)))
+        return fail(GRANNE_HIP_ERR_INVALID, "null pointer array");
+    SearchTarget T = target_of(ix);
+    // as many batches per launch as keep the launch's walker count within 31 bits (and the kernel argument table)
+    uint32_t per = MAX_LAUNCH_BATCHES;
+    while (per > 1 && (uint64_t)per * nq > 0x7FFFFFFFull) per >>= 1;
+    for (uint32_t b0 = 0; b0 < n_batches; b0 += per) {
+        const uint32_t nb = n_batches - b0 < per ? n_batches - b0 : per;
+        BatchIO io[MAX_LAUNCH_BATCHES];
+        for (uint32_t b = 0; b < nb; ++b) {
+            io[b].queries = (const uint8_t*)d_queries[b0 + b];
+            io[b].out_ids = num_neighbors ? d_out_ids[b0 + b] : nullptr;
+            io[b].out_dists = num_neighbors ? d_out_dists[b0 + b] : nullptr;
+            io[b].out_counts = d_out_counts[b0 + b];
+            io[b].out_stats = d_out_stats ? d_out_stats[b0 + b] : nullptr;
+        }
+        int rc = search_launch(&T, nullptr, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors, nullptr,
+                               nullptr, nullptr, nullptr, d_status, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, nullptr,
+                               nullptr, io, nb);
+        if (rc) return rc;
+    }
+    return GRANNE_HIP_OK;
 }
 
 #if GRANNE_HIP_PHASE_TIMERS

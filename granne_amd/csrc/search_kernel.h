@@ -37,6 +37,16 @@ struct LayerDev {
     uint32_t pad_;
 };
 
+// one batch of a launch that serves several (SearchParams::batch)
+constexpr uint32_t MAX_LAUNCH_BATCHES = 32;
+struct BatchIO {
+    const uint8_t* queries;
+    uint64_t* out_ids;
+    float* out_dists;
+    uint32_t* out_counts;
+    uint64_t* out_stats; // or null
+};
+
 struct SearchParams {
     const uint8_t* elements; // device layout: [n][row_bytes], zero padded
     uint64_t n_elements;
@@ -69,8 +79,47 @@ struct SearchParams {
     // 0..trail_layers-1 with max_search 1, each from node 0, and record the ids found
     uint32_t* trail_out;     // [nq][8] or null
     uint32_t trail_layers;
+    // Several batches in ONE launch (granne_hip_search_batches_device): walker w serves query w % batch_nq of batch
+    // w / batch_nq, whose buffers are batch[w / batch_nq]; `nq` is then the number of walkers of the launch and the
+    // plain pointers above are unused. n_batches == 0: one batch, the plain pointers.
+    uint32_t n_batches;
+    uint32_t batch_nq;
+    BatchIO batch[MAX_LAUNCH_BATCHES];
 };
 constexpr uint32_t TRAIL_WIDTH = 8; // NUM_LAYERS, reorder.rs:177
+
+// where walker qi of a launch reads its query and writes its result
+struct QueryIO {
+    const uint8_t* q;
+    uint64_t* ids;   // [k]
+    float* dists;    // [k]
+    uint32_t* count;
+    uint64_t* stats; // [3] or null
+};
+__device__ __forceinline__ QueryIO query_io(const SearchParams& p, uint32_t qi) {
+    const uint8_t* q = p.queries;
+    uint64_t* ids = p.out_ids;
+    float* dists = p.out_dists;
+    uint32_t* counts = p.out_counts;
+    uint64_t* stats = p.out_stats;
+    uint32_t i = qi;
+    if (p.n_batches) {
+        const uint32_t b = qi / p.batch_nq;
+        i = qi - b * p.batch_nq;
+        q = p.batch[b].queries;
+        ids = p.batch[b].out_ids;
+        dists = p.batch[b].out_dists;
+        counts = p.batch[b].out_counts;
+        stats = p.batch[b].out_stats;
+    }
+    QueryIO io;
+    io.q = q + (int64_t)i * p.q_stride;
+    io.ids = ids + (size_t)i * p.k;
+    io.dists = dists + (size_t)i * p.k;
+    io.count = counts + i;
+    io.stats = stats ? stats + (size_t)i * 3 : nullptr;
+    return io;
+}
 
 struct WalkStats {
     uint64_t n_dist, n_expand, n_adj;
@@ -136,11 +185,11 @@ struct Walker {
     // stage the query in LDS, zero padded to row_bytes
     __device__ __forceinline__ void load_query(uint32_t qi) {
         if (DT == DT_F32) {
-            const float* q = reinterpret_cast<const float*>(p.queries + (int64_t)qi * p.q_stride);
+            const float* q = reinterpret_cast<const float*>(query_io(p, qi).q);
             float* l = reinterpret_cast<float*>(lds_q);
             for (uint32_t i = lane; i < p.row_bytes / 4; i += 64) l[i] = (i < p.dim) ? q[i] : 0.0f;
         } else {
-            const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
+            const int8_t* q = reinterpret_cast<const int8_t*>(query_io(p, qi).q);
             int8_t* l = reinterpret_cast<int8_t*>(lds_q);
             int part = 0;
             for (uint32_t i = lane; i < p.row_bytes; i += 64) {
@@ -506,25 +555,26 @@ __device__ __forceinline__ void walk_one(const SearchParams& p, const uint32_t q
         for (int s = 0; s < S; ++s) count += (uint32_t)__popcll(wave_ballot(w.res.key[s] != KEY_INF));
         count = min(count, p.k);
     }
+    const QueryIO io = query_io(p, qi);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         uint32_t e = (uint32_t)s * 64u + lane;
         if (e < p.k) {
             bool ok = e < count;
-            p.out_ids[(size_t)qi * p.k + e] = ok ? (uint64_t)key_id(w.res.key[s]) : ~0ull;
-            p.out_dists[(size_t)qi * p.k + e] = ok ? key_dist(w.res.key[s]) : __builtin_inff();
+            io.ids[e] = ok ? (uint64_t)key_id(w.res.key[s]) : ~0ull;
+            io.dists[e] = ok ? key_dist(w.res.key[s]) : __builtin_inff();
         }
     }
     for (uint32_t e = 64u * S + lane; e < p.k; e += 64) { // k beyond the list capacity: padding
-        p.out_ids[(size_t)qi * p.k + e] = ~0ull;
-        p.out_dists[(size_t)qi * p.k + e] = __builtin_inff();
+        io.ids[e] = ~0ull;
+        io.dists[e] = __builtin_inff();
     }
     if (lane == 0) {
-        p.out_counts[qi] = count;
-        if (p.out_stats) {
-            p.out_stats[(size_t)qi * 3 + 0] = w.st.n_dist;
-            p.out_stats[(size_t)qi * 3 + 1] = w.st.n_expand;
-            p.out_stats[(size_t)qi * 3 + 2] = w.st.n_adj;
+        *io.count = count;
+        if (io.stats) {
+            io.stats[0] = w.st.n_dist;
+            io.stats[1] = w.st.n_expand;
+            io.stats[2] = w.st.n_adj;
         }
     }
     } // !TRAIL

@@ -4,53 +4,221 @@
 // (/root/reference/src/elements/embeddings/parsing.rs:63-100: shards of consecutive elements); a search
 // asks every shard and keeps the best num_neighbors by (dist, global id), global id = shard offset +
 // the shard's local id. Here shard s is a granne_hip_index of its own, on whatever device it was created
-// on: every shard searches the same batch on its own stream (concurrently across devices), its packed
-// top-k (granne_hip_packed_topk_bytes) is copied to the merge device (peer copy over xGMI when the
-// shard lives elsewhere), and merge_topk_kernel ranks the n_shards*k candidates of each query.
-// One process per GPU with a collective instead of peer copies is granne_amd/sharded.py; both use the
-// same search and merge entry points and return the same bits.
+// on. One batch:
+//   * every shard searches the batch on a stream of its own (concurrently across and within devices) and
+//     writes its packed top-k + four status words (granne_hip_packed_topk_bytes + 16) straight into its
+//     place of the merge device's gather buffer when it lives there -- no copy at all -- else into a buffer
+//     on its own device;
+//   * the exchange step: peer copies over xGMI into the gather buffer (default), or ONE grouped
+//     ncclAllGather over a communicator of the shard devices (RCCL, loaded with dlopen when the option asks
+//     for it: the collective BASELINE.json's north star names; this library does not link librccl);
+//   * merge_topk_kernel ranks the n_shards*k candidates of each query, fold_status_kernel folds the
+//     shards' status words into the caller's -- nothing is read back shard by shard.
+// Everything is stream-ordered: `begin` orders the batch after what the caller's stream holds and returns
+// at once, `end` makes the caller's stream wait for the merged result; between the two the caller may
+// begin further batches (up to the handle's depth, two by default), so batch b+1 is searched while batch
+// b is exchanged and merged. The host-pointer calls stage through pinned memory and pipeline the same way.
+// One process per GPU with torch.distributed's collective is granne_amd/sharded.py; both use the same
+// search and merge entry points and return the same bits.
 #pragma once
+
+#include <dlfcn.h>
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why; // when it could not be loaded
+};
+constexpr int RCCL_UINT8 = 1; // ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1)
+
+static RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // A process has ONE HIP runtime; an RCCL built against another copy of it would see no devices. So: a librccl
+        // the process has loaded already (PyTorch-ROCm brings its own) is taken first, then GRANNE_HIP_RCCL_LIB, then
+        // the system's.
+        const char* env = getenv("GRANNE_HIP_RCCL_LIB");
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names)
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (!api.handle && env && *env) api.handle = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+        for (const char* n : names)
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!api.handle) {
+            const char* e = dlerror();
+            api.why = e ? e : "librccl.so not found";
+            return;
+        }
+        auto sym = [&](const char* name) -> void* {
+            void* p = dlsym(api.handle, name);
+            if (!p && api.why.empty()) api.why = std::string("librccl lacks ") + name;
+            return p;
+        };
+        api.CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
+        api.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))sym("ncclAllGather");
+        api.GroupStart = (int (*)())sym("ncclGroupStart");
+        api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    });
+    return &api;
+}
+
+#define RCCL_TRY(api, expr)                                                                                         \
+    do {                                                                                                            \
+        int r_ = (expr);                                                                                            \
+        if (r_ != 0)                                                                                                \
+            return fail(GRANNE_HIP_ERR_HIP, "%s failed: %s", #expr, (api)->GetErrorString ? (api)->GetErrorString(r_) : "?"); \
+    } while (0)
+
+// ---- the handle ---------------------------------------------------------------------------------------------
+constexpr uint32_t SHARDED_MAX_DEPTH = 8;
+constexpr size_t SHARD_STATUS_BYTES = 16;
 
 struct granne_hip_sharded {
     struct Shard {
         granne_hip_index* ix = nullptr;
         uint64_t offset = 0;
         hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;
-        uint8_t* d_queries = nullptr; // on the shard's device
-        uint8_t* d_packed = nullptr;  // on the shard's device
-        uint32_t* d_status = nullptr; // u32[4] on the shard's device
-        size_t q_cap = 0, p_cap = 0;
+        uint32_t dev = 0;   // index into `devices`
+        uint32_t local = 0; // index among the shards of its device
+    };
+    struct Device {
+        int id = 0;
+        uint32_t n_local = 0;
+        hipStream_t xstream = nullptr; // the exchange (RCCL) on this device; the merge device's is merge_stream
+        void* comm = nullptr;          // ncclComm_t
+    };
+    // One batch in flight: every buffer a batch touches belongs to its slot.
+    struct Slot {
+        uint32_t nq = 0, k = 0;
+        size_t stride = 0;
+        bool busy = false;    // begun, not ended
+        bool used = false;    // `merged` (and `xdone`) have been recorded at least once
+        uint64_t seq = 0;     // the ticket's upper half: an `end` must name the begin it belongs to
+        std::vector<uint8_t*> d_recv;   // per device: [G][stride]; the merge device's is the gather buffer
+        std::vector<size_t> recv_cap;
+        std::vector<uint8_t*> d_q;      // per device other than the merge device: the batch's queries
+        std::vector<size_t> q_cap;
+        hipEvent_t ready = nullptr;     // caller's stream: queries (and the previous use of the outputs) are in order
+        hipEvent_t merged = nullptr;    // merge stream: the merged result is written
+        std::vector<hipEvent_t> searched; // per shard
+        std::vector<hipEvent_t> q_there;  // per device: the queries have arrived
+        std::vector<hipEvent_t> xdone;    // per device: its part of the exchange is over (buffers reusable)
+        // host-pointer calls: [queries | ids | dists | counts | status] in pinned memory and on the merge device
+        uint8_t* h_pin = nullptr;
+        uint8_t* d_io = nullptr;
+        size_t h_cap = 0, io_cap = 0;
+        hipEvent_t h_done = nullptr;
     };
     std::vector<Shard> shards;
+    std::vector<Device> devices;
+    std::vector<Slot> slots;
+    uint32_t depth = 2;
+    uint32_t next_slot = 0;
+    uint64_t next_seq = 1;
+    int exchange = GRANNE_HIP_SHARDED_EXCHANGE_PEER;
+    bool uniform = false; // shards in device-major order, the same number on every device (what one all-gather needs)
     int merge_device = 0;
     hipStream_t merge_stream = nullptr;
-    uint8_t* d_gather = nullptr; // [n_shards][packed] on the merge device
-    uint8_t* d_out = nullptr;    // merged ids | dists | counts
-    size_t g_cap = 0, o_cap = 0;
+    hipStream_t io_stream = nullptr; // the host-pointer calls' copies
     uint32_t dim = 0;
     int dtype = 0;
-    std::mutex mu; // one search at a time per handle (the buffers above are the handle's)
+    std::mutex mu;      // slot bookkeeping + the enqueue of one begin / end (host work only; nothing waits for a GPU under it)
+    std::mutex host_mu; // the host-pointer calls of a handle run one at a time (they are synchronous anyway)
 };
+
+static void sharded_free_slot(granne_hip_sharded* sh, granne_hip_sharded::Slot& L) {
+    for (size_t d = 0; d < sh->devices.size(); ++d) {
+        DeviceGuard g(sh->devices[d].id);
+        if (d < L.d_recv.size() && L.d_recv[d]) (void)hipFree(L.d_recv[d]);
+        if (d < L.d_q.size() && L.d_q[d]) (void)hipFree(L.d_q[d]);
+        if (d < L.q_there.size() && L.q_there[d]) (void)hipEventDestroy(L.q_there[d]);
+        if (d < L.xdone.size() && L.xdone[d]) (void)hipEventDestroy(L.xdone[d]);
+    }
+    for (size_t s = 0; s < L.searched.size(); ++s) {
+        DeviceGuard g(sh->shards[s].ix->device);
+        if (L.searched[s]) (void)hipEventDestroy(L.searched[s]);
+    }
+    DeviceGuard g(sh->merge_device);
+    if (L.ready) (void)hipEventDestroy(L.ready);
+    if (L.merged) (void)hipEventDestroy(L.merged);
+    if (L.h_done) (void)hipEventDestroy(L.h_done);
+    if (L.h_pin) (void)hipHostFree(L.h_pin);
+    if (L.d_io) (void)hipFree(L.d_io);
+    L = granne_hip_sharded::Slot();
+}
+
+static void sharded_quiesce(granne_hip_sharded* sh) {
+    for (auto& S : sh->shards) {
+        if (!S.ix || !S.stream) continue;
+        DeviceGuard g(S.ix->device);
+        (void)hipStreamSynchronize(S.stream);
+    }
+    for (auto& D : sh->devices) {
+        if (!D.xstream) continue;
+        DeviceGuard g(D.id);
+        (void)hipStreamSynchronize(D.xstream);
+    }
+    DeviceGuard g(sh->merge_device);
+    if (sh->merge_stream) (void)hipStreamSynchronize(sh->merge_stream);
+    if (sh->io_stream) (void)hipStreamSynchronize(sh->io_stream);
+}
 
 static void sharded_free(granne_hip_sharded* sh) {
     if (!sh) return;
+    sharded_quiesce(sh);
+    for (auto& L : sh->slots) sharded_free_slot(sh, L);
+    RcclApi* api = rccl_api();
+    for (auto& D : sh->devices) {
+        DeviceGuard g(D.id);
+        if (D.comm && api->CommDestroy) (void)api->CommDestroy(D.comm);
+        if (D.xstream && D.xstream != sh->merge_stream) (void)hipStreamDestroy(D.xstream);
+    }
     for (auto& S : sh->shards) {
         if (!S.ix) continue;
         DeviceGuard g(S.ix->device);
         if (S.stream) (void)hipStreamDestroy(S.stream);
-        if (S.done) (void)hipEventDestroy(S.done);
-        if (S.d_queries) (void)hipFree(S.d_queries);
-        if (S.d_packed) (void)hipFree(S.d_packed);
-        if (S.d_status) (void)hipFree(S.d_status);
     }
     {
         DeviceGuard g(sh->merge_device);
         if (sh->merge_stream) (void)hipStreamDestroy(sh->merge_stream);
-        if (sh->d_gather) (void)hipFree(sh->d_gather);
-        if (sh->d_out) (void)hipFree(sh->d_out);
+        if (sh->io_stream) (void)hipStreamDestroy(sh->io_stream);
     }
     delete sh;
+}
+
+static int sharded_init_slot(granne_hip_sharded* sh, granne_hip_sharded::Slot& L) {
+    const size_t nd = sh->devices.size(), G = sh->shards.size();
+    L.d_recv.assign(nd, nullptr);
+    L.recv_cap.assign(nd, 0);
+    L.d_q.assign(nd, nullptr);
+    L.q_cap.assign(nd, 0);
+    L.q_there.assign(nd, nullptr);
+    L.xdone.assign(nd, nullptr);
+    L.searched.assign(G, nullptr);
+    for (size_t d = 0; d < nd; ++d) {
+        DeviceGuard g(sh->devices[d].id);
+        if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", sh->devices[d].id);
+        HIP_TRY(hipEventCreateWithFlags(&L.q_there[d], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.xdone[d], hipEventDisableTiming));
+    }
+    for (size_t s = 0; s < G; ++s) {
+        DeviceGuard g(sh->shards[s].ix->device);
+        HIP_TRY(hipEventCreateWithFlags(&L.searched[s], hipEventDisableTiming));
+    }
+    DeviceGuard g(sh->merge_device);
+    HIP_TRY(hipEventCreateWithFlags(&L.ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&L.merged, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&L.h_done, hipEventDisableTiming));
+    return GRANNE_HIP_OK;
 }
 
 extern "C" int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_index* const* shards,
@@ -74,19 +242,40 @@ extern "C" int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_in
             auto& S = sh->shards[s];
             S.ix = shards[s];
             S.offset = id_offsets[s];
+            uint32_t d = 0;
+            while (d < sh->devices.size() && sh->devices[d].id != S.ix->device) ++d;
+            if (d == sh->devices.size()) {
+                sh->devices.emplace_back();
+                sh->devices.back().id = S.ix->device;
+            }
+            S.dev = d;
+            S.local = sh->devices[d].n_local++;
             DeviceGuard g(S.ix->device);
             if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", S.ix->device);
             HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
-            HIP_TRY(hipMalloc((void**)&S.d_status, 16));
-            if (S.ix->device != sh->merge_device) {
+            if (S.ix->device != sh->merge_device) { // peer copies in both directions (queries out, results back)
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, S.ix->device, sh->merge_device) == hipSuccess && can)
                     (void)hipDeviceEnablePeerAccess(sh->merge_device, 0); // already enabled is fine
             }
         }
+        // one all-gather needs equal contributions in rank order: shard s on device s / n_local
+        sh->uniform = true;
+        for (uint32_t s = 0; s < n_shards; ++s) {
+            const auto& S = sh->shards[s];
+            const uint32_t per = sh->devices[0].n_local;
+            if (sh->devices[S.dev].n_local != per || S.dev != s / per || S.local != s % per) sh->uniform = false;
+        }
+        (void)hipGetLastError(); // (a "peer access already enabled" above is not an error of ours)
         DeviceGuard g(sh->merge_device);
         HIP_TRY(hipStreamCreateWithFlags(&sh->merge_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&sh->io_stream, hipStreamNonBlocking));
+        sh->devices[0].xstream = sh->merge_stream; // (device 0 of the list is shard 0's = the merge device)
+        sh->slots.resize(sh->depth);
+        for (auto& L : sh->slots) {
+            int rc = sharded_init_slot(sh, L);
+            if (rc) return rc;
+        }
         return GRANNE_HIP_OK;
     };
     int rc = body();
@@ -106,14 +295,347 @@ extern "C" uint64_t granne_hip_sharded_len(const granne_hip_sharded* sh) {
         for (auto& S : sh->shards) n += granne_hip_index_len(S.ix);
     return n;
 }
+extern "C" int granne_hip_sharded_device(const granne_hip_sharded* sh) { return sh ? sh->merge_device : -1; }
 
-static int grow(uint8_t** p, size_t* cap, size_t want) {
+extern "C" int granne_hip_sharded_set_option(granne_hip_sharded* sh, int option, uint64_t value) {
+    if (!sh) return fail(GRANNE_HIP_ERR_INVALID, "sharded index is null");
+    std::lock_guard<std::mutex> hk(sh->host_mu);
+    std::lock_guard<std::mutex> lk(sh->mu);
+    for (auto& L : sh->slots)
+        if (L.busy) return fail(GRANNE_HIP_ERR_INVALID, "options cannot change while a batch is in flight");
+    switch (option) {
+    case GRANNE_HIP_SHARDED_OPT_DEPTH: {
+        if (value < 1 || value > SHARDED_MAX_DEPTH) return fail(GRANNE_HIP_ERR_INVALID, "depth must be in [1, %u]", SHARDED_MAX_DEPTH);
+        sharded_quiesce(sh);
+        for (auto& L : sh->slots) sharded_free_slot(sh, L);
+        sh->depth = (uint32_t)value;
+        sh->slots.assign(sh->depth, granne_hip_sharded::Slot());
+        sh->next_slot = 0;
+        for (auto& L : sh->slots) {
+            int rc = sharded_init_slot(sh, L);
+            if (rc) return rc;
+        }
+        return GRANNE_HIP_OK;
+    }
+    case GRANNE_HIP_SHARDED_OPT_EXCHANGE: {
+        if (value != GRANNE_HIP_SHARDED_EXCHANGE_PEER && value != GRANNE_HIP_SHARDED_EXCHANGE_RCCL)
+            return fail(GRANNE_HIP_ERR_INVALID, "exchange must be 0 (peer copies) or 1 (RCCL all-gather)");
+        if (value == GRANNE_HIP_SHARDED_EXCHANGE_RCCL) {
+            if (!sh->uniform)
+                return fail(GRANNE_HIP_ERR_INVALID, "the all-gather needs the shards in device order, the same number on every device");
+            RcclApi* api = rccl_api();
+            if (!api->handle || !api->why.empty())
+                return fail(GRANNE_HIP_ERR_HIP, "RCCL is not available: %s", api->why.c_str());
+            if (!sh->devices[0].comm) {
+                const int nd = (int)sh->devices.size();
+                std::vector<int> devs(nd);
+                std::vector<void*> comms(nd, nullptr);
+                for (int d = 0; d < nd; ++d) devs[d] = sh->devices[d].id;
+                RCCL_TRY(api, api->CommInitAll(comms.data(), nd, devs.data()));
+                for (int d = 0; d < nd; ++d) {
+                    sh->devices[d].comm = comms[d];
+                    if (!sh->devices[d].xstream) {
+                        DeviceGuard g(sh->devices[d].id);
+                        HIP_TRY(hipStreamCreateWithFlags(&sh->devices[d].xstream, hipStreamNonBlocking));
+                    }
+                }
+            }
+        }
+        sharded_quiesce(sh);
+        sh->exchange = (int)value;
+        return GRANNE_HIP_OK;
+    }
+    default:
+        return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+extern "C" int granne_hip_sharded_get_option(const granne_hip_sharded* sh, int option, uint64_t* value) {
+    if (!sh || !value) return fail(GRANNE_HIP_ERR_INVALID, "null argument");
+    switch (option) {
+    case GRANNE_HIP_SHARDED_OPT_DEPTH: *value = sh->depth; return GRANNE_HIP_OK;
+    case GRANNE_HIP_SHARDED_OPT_EXCHANGE: *value = (uint64_t)sh->exchange; return GRANNE_HIP_OK;
+    default: return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
+    }
+}
+
+// a buffer of a slot grows: nothing of the slot's previous batch may still be running
+static int slot_grow(uint8_t** p, size_t* cap, size_t want) {
     if (*cap >= want) return GRANNE_HIP_OK;
-    if (*p) (void)hipFree(*p);
+    if (*p) (void)hipFree(*p); // (hipFree waits for the device)
     *p = nullptr;
     *cap = 0;
-    HIP_TRY(hipMalloc((void**)p, want));
-    *cap = want;
+    HIP_TRY(hipMalloc((void**)p, want + (want >> 2)));
+    *cap = want + (want >> 2);
+    return GRANNE_HIP_OK;
+}
+
+// ---- one batch: begin (enqueue everything) / end (order the caller's stream after the merge) -------------------
+// The caller holds sh->mu.
+static int sharded_begin_locked(granne_hip_sharded* sh, const void* d_queries, uint32_t nq, uint32_t max_search,
+                                uint32_t num_neighbors, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                                uint32_t* d_status, hipStream_t stream, uint64_t* out_ticket) {
+    using Slot = granne_hip_sharded::Slot;
+    const uint32_t G = (uint32_t)sh->shards.size();
+    const uint32_t nd = (uint32_t)sh->devices.size();
+    const uint32_t si = sh->next_slot;
+    Slot& L = sh->slots[si];
+    if (L.busy)
+        return fail(GRANNE_HIP_ERR_INVALID, "%u batches are in flight already (GRANNE_HIP_SHARDED_OPT_DEPTH): end one first", sh->depth);
+    const size_t pb = (size_t)granne_hip_packed_topk_bytes(nq, num_neighbors);
+    const size_t stride = pb + SHARD_STATUS_BYTES;
+    const size_t qb = (size_t)nq * sh->dim * elem_size(sh->dtype);
+    const bool rccl = sh->exchange == GRANNE_HIP_SHARDED_EXCHANGE_RCCL;
+
+    // buffers (sized once per (nq, k); a change waits for the slot's previous batch: hipFree synchronises)
+    for (uint32_t d = 0; d < nd; ++d) {
+        DeviceGuard g(sh->devices[d].id);
+        if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", sh->devices[d].id);
+        // the merge device holds every shard's block; another device its own shards' (peer) or everybody's (all-gather)
+        const size_t blocks = (d == 0 || rccl) ? G : sh->devices[d].n_local;
+        int rc = slot_grow(&L.d_recv[d], &L.recv_cap[d], stride * blocks);
+        if (rc == 0 && d != 0) rc = slot_grow(&L.d_q[d], &L.q_cap[d], qb);
+        if (rc) return rc;
+    }
+    L.nq = nq;
+    L.k = num_neighbors;
+    L.stride = stride;
+
+    DeviceGuard gm(sh->merge_device);
+    HIP_TRY(hipEventRecord(L.ready, stream));
+    // where shard s writes: its place in the gather buffer of ITS device (the all-gather is in place: a device's
+    // contribution is the slice of its own receive buffer that the collective would put there anyway)
+    auto block_of = [&](uint32_t s) -> uint8_t* {
+        const auto& S = sh->shards[s];
+        if (S.dev == 0 || rccl) return L.d_recv[S.dev] + stride * s;
+        return L.d_recv[S.dev] + stride * S.local;
+    };
+    std::vector<char> q_sent(nd, 0);
+    for (uint32_t s = 0; s < G; ++s) {
+        auto& S = sh->shards[s];
+        DeviceGuard g(S.ix->device);
+        if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", S.ix->device);
+        HIP_TRY(hipStreamWaitEvent(S.stream, L.ready, 0));
+        if (L.used) { // the slot's previous batch has left these buffers
+            HIP_TRY(hipStreamWaitEvent(S.stream, L.merged, 0));
+            HIP_TRY(hipStreamWaitEvent(S.stream, L.xdone[S.dev], 0));
+        }
+        const void* q_here = d_queries;
+        if (S.dev != 0) {
+            if (!q_sent[S.dev]) { // the first shard of a device fetches the queries for all of them
+                HIP_TRY(hipMemcpyPeerAsync(L.d_q[S.dev], S.ix->device, d_queries, sh->merge_device, qb, S.stream));
+                HIP_TRY(hipEventRecord(L.q_there[S.dev], S.stream));
+                q_sent[S.dev] = 1;
+            } else {
+                HIP_TRY(hipStreamWaitEvent(S.stream, L.q_there[S.dev], 0));
+            }
+            q_here = L.d_q[S.dev];
+        }
+        uint8_t* blk = block_of(s);
+        HIP_TRY(hipMemsetAsync(blk + pb, 0, SHARD_STATUS_BYTES, S.stream));
+        int rc = granne_hip_search_batch_packed_device(S.ix, q_here, nq, max_search, num_neighbors, blk, (uint32_t*)(blk + pb), S.stream);
+        if (rc) return rc;
+        if (!rccl && S.dev != 0)
+            HIP_TRY(hipMemcpyPeerAsync(L.d_recv[0] + stride * s, sh->merge_device, blk, S.ix->device, stride, S.stream));
+        HIP_TRY(hipEventRecord(L.searched[s], S.stream));
+    }
+    if (rccl) {
+        RcclApi* api = rccl_api();
+        for (uint32_t s = 0; s < G; ++s) {
+            const auto& S = sh->shards[s];
+            DeviceGuard g(S.ix->device);
+            HIP_TRY(hipStreamWaitEvent(sh->devices[S.dev].xstream, L.searched[s], 0));
+        }
+        RCCL_TRY(api, api->GroupStart());
+        int bad = 0;
+        for (uint32_t d = 0; d < nd; ++d) {
+            DeviceGuard g(sh->devices[d].id);
+            const size_t part = stride * sh->devices[d].n_local;
+            const int r = api->AllGather(L.d_recv[d] + part * d, L.d_recv[d], part, RCCL_UINT8, sh->devices[d].comm, sh->devices[d].xstream);
+            if (r && !bad) bad = r;
+        }
+        const int ge = api->GroupEnd();
+        if (bad || ge) return fail(GRANNE_HIP_ERR_HIP, "ncclAllGather failed: %s", api->GetErrorString(bad ? bad : ge));
+        for (uint32_t d = 1; d < nd; ++d) {
+            DeviceGuard g(sh->devices[d].id);
+            HIP_TRY(hipEventRecord(L.xdone[d], sh->devices[d].xstream));
+        }
+    } else {
+        for (uint32_t s = 0; s < G; ++s) HIP_TRY(hipStreamWaitEvent(sh->merge_stream, L.searched[s], 0));
+    }
+    uint64_t offs[64];
+    for (uint32_t s = 0; s < G; ++s) offs[s] = sh->shards[s].offset;
+    int rc = granne_hip_merge_topk_packed_strided_device(L.d_recv[0], stride, offs, G, nq, num_neighbors, d_out_ids, d_out_dists,
+                                                         d_out_counts, sh->merge_device, sh->merge_stream);
+    if (rc) return rc;
+    if (d_status) {
+        hipLaunchKernelGGL(fold_status_kernel, dim3(1), dim3(64), 0, sh->merge_stream, (const uint8_t*)L.d_recv[0], (uint64_t)stride,
+                           (uint64_t)pb, G, d_status);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(L.merged, sh->merge_stream));
+    HIP_TRY(hipEventRecord(L.xdone[0], sh->merge_stream));
+    if (!rccl)
+        for (uint32_t d = 1; d < nd; ++d) { // peer mode: a device's buffers are free once its shards' copies are out
+            DeviceGuard g(sh->devices[d].id);
+            for (uint32_t s = 0; s < G; ++s)
+                if (sh->shards[s].dev == d && sh->shards[s].local + 1 == sh->devices[d].n_local)
+                    HIP_TRY(hipEventRecord(L.xdone[d], sh->shards[s].stream));
+        }
+    L.used = true;
+    L.busy = true;
+    L.seq = sh->next_seq++;
+    sh->next_slot = (si + 1) % sh->depth;
+    *out_ticket = (L.seq << 8) | si;
+    return GRANNE_HIP_OK;
+}
+
+static int sharded_check_args(granne_hip_sharded* sh, uint32_t max_search, uint32_t num_neighbors) {
+    if (!sh) return fail(GRANNE_HIP_ERR_INVALID, "sharded index is null");
+    if (max_search == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
+    if ((uint64_t)sh->shards.size() * num_neighbors > 4096) return fail(GRANNE_HIP_ERR_INVALID, "n_shards * num_neighbors must be <= 4096");
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_sharded_begin_device(granne_hip_sharded* sh, const void* d_queries, uint32_t nq, uint32_t max_search,
+                                               uint32_t num_neighbors, uint64_t* d_out_ids, float* d_out_dists,
+                                               uint32_t* d_out_counts, uint32_t* d_status, void* stream, uint64_t* out_ticket) {
+    int rc = sharded_check_args(sh, max_search, num_neighbors);
+    if (rc) return rc;
+    if (!out_ticket) return fail(GRANNE_HIP_ERR_INVALID, "out_ticket is null");
+    if (nq == 0 || num_neighbors == 0) return fail(GRANNE_HIP_ERR_INVALID, "nq and num_neighbors must be > 0 for a batch in flight");
+    if (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    std::lock_guard<std::mutex> lk(sh->mu);
+    rc = sharded_begin_locked(sh, d_queries, nq, max_search, num_neighbors, d_out_ids, d_out_dists, d_out_counts, d_status,
+                              (hipStream_t)stream, out_ticket);
+    if (rc) sharded_quiesce(sh); // an error return leaves nothing running on the caller's buffers
+    return rc;
+}
+
+extern "C" int granne_hip_sharded_end_device(granne_hip_sharded* sh, uint64_t ticket, void* stream) {
+    if (!sh) return fail(GRANNE_HIP_ERR_INVALID, "sharded index is null");
+    std::lock_guard<std::mutex> lk(sh->mu);
+    const uint32_t si = (uint32_t)(ticket & 0xFF);
+    if (si >= sh->slots.size() || !sh->slots[si].busy || sh->slots[si].seq != (ticket >> 8))
+        return fail(GRANNE_HIP_ERR_INVALID, "no batch in flight has this ticket");
+    auto& L = sh->slots[si];
+    DeviceGuard g(sh->merge_device);
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, L.merged, 0));
+    L.busy = false;
+    return GRANNE_HIP_OK;
+}
+
+// Granne::search on every shard + the merge, device buffers (on the merge device = shard 0's), stream-ordered.
+extern "C" int granne_hip_sharded_search_batch_device(granne_hip_sharded* sh, const void* d_queries, uint32_t nq,
+                                                      uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
+                                                      float* d_out_dists, uint32_t* d_out_counts, uint32_t* d_status,
+                                                      void* stream) {
+    int rc = sharded_check_args(sh, max_search, num_neighbors);
+    if (rc) return rc;
+    if (nq == 0) return GRANNE_HIP_OK;
+    if (num_neighbors == 0) { // .take(0), src/index/mod.rs:974-977
+        if (!d_out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+        DeviceGuard g(sh->merge_device);
+        HIP_TRY(hipMemsetAsync(d_out_counts, 0, (size_t)nq * 4, (hipStream_t)stream));
+        return GRANNE_HIP_OK;
+    }
+    uint64_t ticket = 0;
+    rc = granne_hip_sharded_begin_device(sh, d_queries, nq, max_search, num_neighbors, d_out_ids, d_out_dists, d_out_counts,
+                                         d_status, stream, &ticket);
+    if (rc) return rc;
+    return granne_hip_sharded_end_device(sh, ticket, stream);
+}
+
+// ---- host pointers: pinned staging, `depth` batches in flight --------------------------------------------------
+// queries: [n_batches][nq][dim] (dense, prepared like the elements); outputs [n_batches][nq][num_neighbors] / [n_batches][nq].
+extern "C" int granne_hip_sharded_search_batches(granne_hip_sharded* sh, const void* queries, uint32_t n_batches, uint32_t nq,
+                                                 uint32_t max_search, uint32_t num_neighbors, uint64_t* out_ids,
+                                                 float* out_dists, uint32_t* out_counts) {
+    int rc = sharded_check_args(sh, max_search, num_neighbors);
+    if (rc) return rc;
+    if (nq == 0 || n_batches == 0) return GRANNE_HIP_OK;
+    if (num_neighbors == 0) {
+        if (!out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+        memset(out_counts, 0, (size_t)n_batches * nq * 4);
+        return GRANNE_HIP_OK;
+    }
+    if (!queries || !out_ids || !out_dists || !out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    std::lock_guard<std::mutex> hk(sh->host_mu);
+    const size_t k = num_neighbors;
+    const size_t qb = (size_t)nq * sh->dim * elem_size(sh->dtype);
+    const size_t o_ids = (qb + 255) & ~(size_t)255;
+    const size_t o_d = o_ids + (size_t)nq * k * 8;
+    const size_t o_c = o_d + (size_t)nq * k * 4;
+    const size_t o_st = (o_c + (size_t)nq * 4 + 15) & ~(size_t)15;
+    const size_t total = o_st + 16;
+    struct Quiesce { // whatever way this call ends, nothing it enqueued is still running when it returns
+        granne_hip_sharded* sh;
+        bool armed = true;
+        ~Quiesce() {
+            if (!armed) return;
+            sharded_quiesce(sh);
+            std::lock_guard<std::mutex> lk(sh->mu);
+            for (auto& L : sh->slots) L.busy = false;
+        }
+    } quiesce{sh};
+    DeviceGuard g(sh->merge_device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", sh->merge_device);
+    struct Pending {
+        uint32_t batch;
+        uint32_t slot;
+        uint64_t ticket;
+    };
+    std::vector<Pending> pending;
+    auto finish = [&](const Pending& P) -> int {
+        auto& L = sh->slots[P.slot];
+        rc = granne_hip_sharded_end_device(sh, P.ticket, sh->io_stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(L.h_pin + o_ids, L.d_io + o_ids, total - o_ids, hipMemcpyDeviceToHost, sh->io_stream));
+        HIP_TRY(hipEventRecord(L.h_done, sh->io_stream));
+        HIP_TRY(hipEventSynchronize(L.h_done));
+        const uint32_t* st = (const uint32_t*)(L.h_pin + o_st);
+        if (st[0]) return fail(GRANNE_HIP_ERR_OVERFLOW, "a shard's exact-search scratch is exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)");
+        memcpy(out_ids + (size_t)P.batch * nq * k, L.h_pin + o_ids, (size_t)nq * k * 8);
+        memcpy(out_dists + (size_t)P.batch * nq * k, L.h_pin + o_d, (size_t)nq * k * 4);
+        memcpy(out_counts + (size_t)P.batch * nq, L.h_pin + o_c, (size_t)nq * 4);
+        return GRANNE_HIP_OK;
+    };
+    for (uint32_t b = 0; b < n_batches; ++b) {
+        uint32_t si;
+        {
+            std::lock_guard<std::mutex> lk(sh->mu);
+            si = sh->next_slot;
+        }
+        if (!pending.empty() && pending.front().slot == si) { // the slot's previous batch comes home first
+            rc = finish(pending.front());
+            if (rc) return rc;
+            pending.erase(pending.begin());
+        }
+        auto& L = sh->slots[si];
+        if (L.h_cap < total) {
+            if (L.h_pin) (void)hipHostFree(L.h_pin);
+            L.h_pin = nullptr;
+            L.h_cap = 0;
+            HIP_TRY(hipHostMalloc((void**)&L.h_pin, total + (total >> 2), hipHostMallocDefault));
+            L.h_cap = total + (total >> 2);
+        }
+        rc = slot_grow(&L.d_io, &L.io_cap, total);
+        if (rc) return rc;
+        memcpy(L.h_pin, (const uint8_t*)queries + (size_t)b * qb, qb);
+        HIP_TRY(hipMemcpyAsync(L.d_io, L.h_pin, qb, hipMemcpyHostToDevice, sh->io_stream));
+        HIP_TRY(hipMemsetAsync(L.d_io + o_st, 0, 16, sh->io_stream));
+        Pending P{b, si, 0};
+        rc = granne_hip_sharded_begin_device(sh, L.d_io, nq, max_search, num_neighbors, (uint64_t*)(L.d_io + o_ids),
+                                             (float*)(L.d_io + o_d), (uint32_t*)(L.d_io + o_c), (uint32_t*)(L.d_io + o_st),
+                                             sh->io_stream, &P.ticket);
+        if (rc) return rc;
+        pending.push_back(P);
+    }
+    for (const auto& P : pending) {
+        rc = finish(P);
+        if (rc) return rc;
+    }
+    quiesce.armed = false; // everything has been waited for
     return GRANNE_HIP_OK;
 }
 
@@ -121,84 +643,7 @@ static int grow(uint8_t** p, size_t* cap, size_t want) {
 extern "C" int granne_hip_sharded_search_batch(granne_hip_sharded* sh, const void* queries, uint32_t nq, uint32_t max_search,
                                                uint32_t num_neighbors, uint64_t* out_ids, float* out_dists,
                                                uint32_t* out_counts) {
-    if (!sh) return fail(GRANNE_HIP_ERR_INVALID, "sharded index is null");
-    if (max_search == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
-    if (nq == 0) return GRANNE_HIP_OK;
-    if (num_neighbors == 0) {
-        if (!out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
-        memset(out_counts, 0, (size_t)nq * 4);
-        return GRANNE_HIP_OK;
-    }
-    if (!queries || !out_ids || !out_dists || !out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
-    const uint32_t G = (uint32_t)sh->shards.size();
-    if ((uint64_t)G * num_neighbors > 4096) return fail(GRANNE_HIP_ERR_INVALID, "n_shards * num_neighbors must be <= 4096");
-    std::lock_guard<std::mutex> lk(sh->mu);
-    // Whatever way this call ends, nothing it enqueued may still be running when it returns: the shard streams read the
-    // caller's `queries` and write buffers the next call may regrow (grow() frees), the merge stream writes the caller's
-    // outputs. On success everything has been waited for already and this costs nothing.
-    struct Quiesce {
-        granne_hip_sharded* sh;
-        ~Quiesce() {
-            for (auto& S : sh->shards) {
-                DeviceGuard g(S.ix->device);
-                (void)hipStreamSynchronize(S.stream);
-            }
-            DeviceGuard g(sh->merge_device);
-            (void)hipStreamSynchronize(sh->merge_stream);
-        }
-    } quiesce{sh};
-    const size_t k = num_neighbors;
-    const size_t qb = (size_t)nq * sh->dim * elem_size(sh->dtype);
-    const size_t pb = (size_t)granne_hip_packed_topk_bytes(nq, num_neighbors);
-    const size_t ob = (size_t)nq * k * 12 + (size_t)nq * 4;
-    {
-        DeviceGuard g(sh->merge_device);
-        int rc = grow(&sh->d_gather, &sh->g_cap, pb * G);
-        if (rc == 0) rc = grow(&sh->d_out, &sh->o_cap, ob);
-        if (rc) return rc;
-    }
-    // every shard: upload the batch, search, send its packed top-k to the merge device
-    for (uint32_t s = 0; s < G; ++s) {
-        auto& S = sh->shards[s];
-        DeviceGuard g(S.ix->device);
-        if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", S.ix->device);
-        int rc = grow(&S.d_queries, &S.q_cap, qb);
-        if (rc == 0) rc = grow(&S.d_packed, &S.p_cap, pb);
-        if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(S.d_status, 0, 16, S.stream));
-        HIP_TRY(hipMemcpyAsync(S.d_queries, queries, qb, hipMemcpyHostToDevice, S.stream));
-        rc = granne_hip_search_batch_packed_device(S.ix, S.d_queries, nq, max_search, num_neighbors, S.d_packed, S.d_status,
-                                                   S.stream);
-        if (rc) return rc;
-        if (S.ix->device == sh->merge_device)
-            HIP_TRY(hipMemcpyAsync(sh->d_gather + pb * s, S.d_packed, pb, hipMemcpyDeviceToDevice, S.stream));
-        else
-            HIP_TRY(hipMemcpyPeerAsync(sh->d_gather + pb * s, sh->merge_device, S.d_packed, S.ix->device, pb, S.stream));
-        HIP_TRY(hipEventRecord(S.done, S.stream));
-    }
-    DeviceGuard g(sh->merge_device);
-    for (uint32_t s = 0; s < G; ++s) HIP_TRY(hipStreamWaitEvent(sh->merge_stream, sh->shards[s].done, 0));
-    uint64_t offs[64];
-    for (uint32_t s = 0; s < G; ++s) offs[s] = sh->shards[s].offset;
-    uint64_t* d_ids = (uint64_t*)sh->d_out;
-    float* d_d = (float*)(sh->d_out + (size_t)nq * k * 8);
-    uint32_t* d_c = (uint32_t*)(sh->d_out + (size_t)nq * k * 12);
-    int rc = granne_hip_merge_topk_packed_device(sh->d_gather, offs, G, nq, num_neighbors, d_ids, d_d, d_c, sh->merge_device,
-                                                 sh->merge_stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out_ids, d_ids, (size_t)nq * k * 8, hipMemcpyDeviceToHost, sh->merge_stream));
-    HIP_TRY(hipMemcpyAsync(out_dists, d_d, (size_t)nq * k * 4, hipMemcpyDeviceToHost, sh->merge_stream));
-    HIP_TRY(hipMemcpyAsync(out_counts, d_c, (size_t)nq * 4, hipMemcpyDeviceToHost, sh->merge_stream));
-    HIP_TRY(hipStreamSynchronize(sh->merge_stream));
-    // a shard whose exact-search scratch ran out wrote empty results for those queries: report, never merge silently
-    for (uint32_t s = 0; s < G; ++s) {
-        auto& S = sh->shards[s];
-        DeviceGuard gs(S.ix->device);
-        uint32_t st[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpy(st, S.d_status, 16, hipMemcpyDeviceToHost));
-        if (st[0]) return fail(GRANNE_HIP_ERR_OVERFLOW, "shard %u: exact-search scratch exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)", s);
-    }
-    return GRANNE_HIP_OK;
+    return granne_hip_sharded_search_batches(sh, queries, 1, nq, max_search, num_neighbors, out_ids, out_dists, out_counts);
 }
 
 // Granne::search on a partitioned index: one query

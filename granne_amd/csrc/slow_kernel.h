@@ -135,11 +135,11 @@ __device__ inline void slow_walk_list(const SlowParams& P, const uint32_t me, co
         // query to LDS
         int dy = 0;
         if (DT == DT_F32) {
-            const float* q = reinterpret_cast<const float*>(p.queries + (int64_t)qi * p.q_stride);
+            const float* q = reinterpret_cast<const float*>(query_io(p, qi).q);
             float* l = reinterpret_cast<float*>(lds_q);
             for (uint32_t i = lane; i < p.row_bytes / 4; i += 64) l[i] = (i < p.dim) ? q[i] : 0.0f;
         } else {
-            const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
+            const int8_t* q = reinterpret_cast<const int8_t*>(query_io(p, qi).q);
             int8_t* l = reinterpret_cast<int8_t*>(lds_q);
             int part = 0;
             for (uint32_t i = lane; i < p.row_bytes; i += 64) {
@@ -305,19 +305,18 @@ __device__ inline void slow_walk_list(const SlowParams& P, const uint32_t me, co
             count = min(n_res, p.k);
         }
         if (lane == 0) {
+            const QueryIO io = query_io(p, qi);
             for (uint32_t e = 0; e < p.k; ++e) {
                 bool ok = e < count;
                 uint64_t key = ok ? res[e] : KEY_INF;
-                p.out_ids[(size_t)qi * p.k + e] = ok ? (uint64_t)key_id(key) : ~0ull;
-                p.out_dists[(size_t)qi * p.k + e] = ok ? key_dist(key) : __builtin_inff();
+                io.ids[e] = ok ? (uint64_t)key_id(key) : ~0ull;
+                io.dists[e] = ok ? key_dist(key) : __builtin_inff();
             }
-        }
-        if (lane == 0) {
-            p.out_counts[qi] = count;
-            if (p.out_stats) {
-                p.out_stats[(size_t)qi * 3 + 0] = n_dist;
-                p.out_stats[(size_t)qi * 3 + 1] = n_expand;
-                p.out_stats[(size_t)qi * 3 + 2] = n_adj;
+            *io.count = count;
+            if (io.stats) {
+                io.stats[0] = n_dist;
+                io.stats[1] = n_expand;
+                io.stats[2] = n_adj;
             }
         }
         __syncthreads();

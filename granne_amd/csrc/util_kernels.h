@@ -308,4 +308,29 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const MergeParams P) {
     if (lane == 0) P.out_counts[q] = count;
 }
 
+// The status words of the G shards of a partitioned search (four u32 after each shard's packed top-k, stride bytes
+// apart) folded into the caller's four: [0] |= a shard's exact-search scratch ran out, [1] += hand-overs, [2] += walks
+// that borrowed an overflow table. One wave (G <= 64).
+__global__ __launch_bounds__(64) void fold_status_kernel(const uint8_t* gathered, uint64_t stride, uint64_t status_off,
+                                                         uint32_t n_shards, uint32_t* out) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t a = 0, b = 0, c = 0;
+    if (lane < n_shards) {
+        const uint32_t* st = reinterpret_cast<const uint32_t*>(gathered + (size_t)lane * stride + status_off);
+        a = st[0];
+        b = st[1];
+        c = st[2];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a |= __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+        c += __shfl_xor(c, o, 64);
+    }
+    if (lane == 0) {
+        if (a) atomicOr(out + 0, 1u);
+        if (b) atomicAdd(out + 1, b);
+        if (c) atomicAdd(out + 2, c);
+    }
+}
+
 } // namespace granne_hip

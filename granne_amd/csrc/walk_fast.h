@@ -335,7 +335,7 @@ struct FastWalker {
 
     __device__ __forceinline__ void load_query(uint32_t qi) {
         if constexpr (F32) {
-            const float* q = reinterpret_cast<const float*>(p.queries + (int64_t)qi * p.q_stride);
+            const float* q = reinterpret_cast<const float*>(query_io(p, qi).q);
             if constexpr (QREG) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
@@ -355,7 +355,7 @@ struct FastWalker {
                 __syncthreads();
             }
         } else {
-            const int8_t* q = reinterpret_cast<const int8_t*>(p.queries + (int64_t)qi * p.q_stride);
+            const int8_t* q = reinterpret_cast<const int8_t*>(query_io(p, qi).q);
             int8_t* l = reinterpret_cast<int8_t*>(lds_q);
             int part = 0;
             for (uint32_t i = lane; i < ROWB; i += 64) {
@@ -861,16 +861,17 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
             for (int s = 0; s < S; ++s) { flag[s] = false; rank[s] = 0; }
         }
         const uint32_t count = min(min(total, p.ef), p.k);
+        const QueryIO io = query_io(p, qi);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             if (flag[s] && rank[s] < count) {
-                p.out_ids[(size_t)qi * p.k + rank[s]] = (uint64_t)wkey_id(w.L.key[s]);
-                p.out_dists[(size_t)qi * p.k + rank[s]] = wkey_dist(w.L.key[s]);
+                io.ids[rank[s]] = (uint64_t)wkey_id(w.L.key[s]);
+                io.dists[rank[s]] = wkey_dist(w.L.key[s]);
             }
         }
         for (uint32_t e = count + lane; e < p.k; e += 64) {
-            p.out_ids[(size_t)qi * p.k + e] = ~0ull;
-            p.out_dists[(size_t)qi * p.k + e] = __builtin_inff();
+            io.ids[e] = ~0ull;
+            io.dists[e] = __builtin_inff();
         }
 #if GRANNE_HIP_PHASE_TIMERS
         if (lane == 0 && qi < PHASE_QUERIES) {
@@ -883,11 +884,11 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
         }
 #endif
         if (lane == 0) {
-            p.out_counts[qi] = count;
-            if (p.out_stats) {
-                p.out_stats[(size_t)qi * 3 + 0] = w.st.n_dist;
-                p.out_stats[(size_t)qi * 3 + 1] = w.st.n_expand;
-                p.out_stats[(size_t)qi * 3 + 2] = w.st.n_adj;
+            *io.count = count;
+            if (io.stats) {
+                io.stats[0] = w.st.n_dist;
+                io.stats[1] = w.st.n_expand;
+                io.stats[2] = w.st.n_adj;
             }
         }
     }

@@ -267,6 +267,18 @@ class Granne:
                                                    C.c_void_p(d_counts), C.c_void_p(d_stats), C.c_void_p(d_status),
                                                    C.c_void_p(stream)))
 
+    def search_batches_device(self, d_queries, nq, max_search, num_elements, d_ids, d_dists, d_counts, d_stats=None,
+                              d_status=0, stream=0):
+        """Several batches of nq queries through ONE launch (granne_hip_search_batches_device). d_queries, d_ids,
+        d_dists, d_counts (and d_stats, optional): sequences of raw device pointers (int), one per batch -- or ctypes
+        pointer arrays prepared once with `pointer_array`. Asynchronous on `stream`."""
+        n = len(d_queries)
+        arr = lambda v: v if isinstance(v, C.Array) else pointer_array(v)  # noqa: E731
+        check(lib().granne_hip_search_batches_device(self._h, n, arr(d_queries), int(nq), int(max_search), int(num_elements),
+                                                     arr(d_ids), arr(d_dists), arr(d_counts),
+                                                     arr(d_stats) if d_stats is not None else None, C.c_void_p(d_status),
+                                                     C.c_void_p(stream)))
+
     def search_batch_device_timed(self, d_queries, nq, max_search, num_elements, d_ids, d_dists, d_counts, d_stats,
                                   d_status, stream, ev_before, ev_after):
         """search_batch_device plus two raw hipEvent_t recorded around the search kernel's dispatch."""
@@ -281,13 +293,16 @@ class Granne:
         check(lib().granne_hip_brute_force_device(self._h, C.c_void_p(d_queries), int(nq), int(k), C.c_void_p(d_ids),
                                                   C.c_void_p(d_dists), C.c_void_p(d_counts), C.c_void_p(stream)))
 
-    def brute_force(self, queries, k):
+    def brute_force(self, queries, k, prepared=True):
         """Host convenience over brute_force_device (torch moves the buffers): ids [nq, k] u64, dists [nq, k] f32,
-        counts [nq] u32, ascending by (distance, id) -- the exact answer Granne::search approximates."""
+        counts [nq] u32, ascending by (distance, id) -- the exact answer Granne::search approximates.
+        prepared=False applies Vector::from to the queries first, as `search` does."""
         import torch
-        q = np.ascontiguousarray(queries, dtype=self.np_dtype)
+        q = self._prepare(queries, prepared)
         if q.ndim == 1:
             q = q[None]
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError("queries must be [nq, %d]" % self.dim)
         dev = torch.device("cuda", self.device)
         tq = torch.from_numpy(q.view(np.uint8).reshape(q.shape[0], -1)).to(dev)
         ids = torch.empty((q.shape[0], k), dtype=torch.int64, device=dev)
@@ -330,6 +345,11 @@ class Granne:
         out = np.empty(qi.size, np.float32)
         check(lib().granne_hip_dist_pairs(self._h, _p(q), q.shape[0], _p(qi), _p(ii), qi.size, _p(out)))
         return out
+
+
+def pointer_array(ptrs):
+    """A ctypes array of device pointers (ints) for the multi-batch calls; build it once when the buffers are fixed."""
+    return (C.c_void_p * len(ptrs))(*[int(x) for x in ptrs])
 
 
 def compute_distance(element_type, a, b, device=0):

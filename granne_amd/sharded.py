@@ -226,8 +226,12 @@ class ShardedGranne:
         if sl.busy:
             raise RuntimeError("search_batch while batches of search_batches are in flight")
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (timed and self._on_gpu) else None
-        self._start(sl, queries, max_search, k, ev)
-        out = self._finish(sl, check_status)
+        try:
+            self._start(sl, queries, max_search, k, ev)
+            out = self._finish(sl, check_status)
+        except BaseException:
+            self._drain()
+            raise
         if check_status:
             self._raise_if_exhausted()
         if ev:
@@ -243,19 +247,42 @@ class ShardedGranne:
         depth = max(1, int(depth))
         results = [None] * len(batches)
         pending = []  # (batch index, slot)
-        for b, q in enumerate(batches):
-            if b % depth < len(self._slots) and self._slots[b % depth].busy:  # the slot's previous batch first
+        try:
+            for b, q in enumerate(batches):
+                if b % depth < len(self._slots) and self._slots[b % depth].busy:  # the slot's previous batch first
+                    pb_, psl = pending.pop(0)
+                    assert psl is self._slots[b % depth]
+                    results[pb_] = self._finish(psl, check_status)
+                sl = self._slot(b % depth, int(q.shape[0]), k)
+                self._start(sl, q, max_search, k)
+                pending.append((b, sl))
+            while pending:
                 pb_, psl = pending.pop(0)
-                assert psl is self._slots[b % depth]
                 results[pb_] = self._finish(psl, check_status)
-            sl = self._slot(b % depth, int(q.shape[0]), k)
-            self._start(sl, q, max_search, k)
-            pending.append((b, sl))
-        for pb_, psl in pending:
-            results[pb_] = self._finish(psl, check_status)
+        except BaseException:
+            self._drain()  # a failed launch or collective: no slot stays marked in flight, the object stays usable
+            raise
         if check_status:
             self._raise_if_exhausted()  # once for the whole run of batches: every rank raises together
         return results
+
+    def _drain(self):
+        """After a failure inside the pipeline: wait for whatever the slots still have running (best effort) and
+        forget it -- the next call starts from free slots on every rank that got here."""
+        for sl in self._slots:
+            if not sl.busy:
+                continue
+            try:
+                if self._on_gpu:
+                    if sl.done is not None:
+                        sl.done.synchronize()
+                elif sl.done is not None:
+                    sl.done.wait()
+            except Exception:
+                pass
+            sl.busy = False
+            sl.done = None
+        self._exhausted = None
 
     def status_of_last_batch(self, slot=0):
         """[n_shards, 4] int32: the status words of every shard of the job for the last batch of that slot."""
@@ -266,6 +293,85 @@ class ShardedGranne:
 
     def exchange_bytes_per_rank(self, nq, k):
         return self.local * (packed_bytes(nq, k) + STATUS_BYTES)
+
+
+class ShardedHost:
+    """granne_hip_sharded_* (include/granne_hip.h): the partitioned index as ONE host process drives it -- what a Rust
+    host binds. `indexes`: granne_amd.Granne objects (local ids), any devices; `offsets`: the first
+    global id of each. Device calls take raw device pointers (int) on `self.device` (= the first shard's)."""
+
+    def __init__(self, indexes, offsets, depth=None, exchange=None):
+        from ._lib import SHARDED_OPT_DEPTH, SHARDED_OPT_EXCHANGE, check, lib
+        self._lib, self._check = lib(), check
+        self.indexes = list(indexes)  # borrowed by the handle: kept alive here
+        G = len(self.indexes)
+        handles = (C.c_void_p * G)(*[ix._h for ix in self.indexes])
+        offs = (C.c_uint64 * G)(*[int(o) for o in offsets])
+        self._h = C.c_void_p()
+        check(self._lib.granne_hip_sharded_create(C.byref(self._h), handles, offs, G))
+        self.device = int(self._lib.granne_hip_sharded_device(self._h))
+        self.dim, self.np_dtype = self.indexes[0].dim, self.indexes[0].np_dtype
+        if depth is not None:
+            self.set_option(SHARDED_OPT_DEPTH, depth)
+        if exchange is not None:
+            self.set_option(SHARDED_OPT_EXCHANGE, exchange)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.granne_hip_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._lib.granne_hip_sharded_len(self._h))
+
+    def set_option(self, option, value):
+        self._check(self._lib.granne_hip_sharded_set_option(self._h, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_uint64(0)
+        self._check(self._lib.granne_hip_sharded_get_option(self._h, int(option), C.byref(v)))
+        return int(v.value)
+
+    def search_batch_device(self, d_queries, nq, max_search, k, d_ids, d_dists, d_counts, d_status=0, stream=0):
+        self._check(self._lib.granne_hip_sharded_search_batch_device(
+            self._h, C.c_void_p(d_queries), int(nq), int(max_search), int(k), C.c_void_p(d_ids), C.c_void_p(d_dists),
+            C.c_void_p(d_counts), C.c_void_p(d_status), C.c_void_p(stream)))
+
+    def begin_device(self, d_queries, nq, max_search, k, d_ids, d_dists, d_counts, d_status=0, stream=0):
+        t = C.c_uint64(0)
+        self._check(self._lib.granne_hip_sharded_begin_device(
+            self._h, C.c_void_p(d_queries), int(nq), int(max_search), int(k), C.c_void_p(d_ids), C.c_void_p(d_dists),
+            C.c_void_p(d_counts), C.c_void_p(d_status), C.c_void_p(stream), C.byref(t)))
+        return int(t.value)
+
+    def end_device(self, ticket, stream=0):
+        self._check(self._lib.granne_hip_sharded_end_device(self._h, C.c_uint64(ticket), C.c_void_p(stream)))
+
+    def search_batches(self, queries, max_search, k):
+        """queries: host [n_batches, nq, dim] (prepared). Returns ids [n_batches, nq, k] u64, dists f32, counts
+        [n_batches, nq] u32 -- batches pipelined `depth` deep inside the library."""
+        q = np.ascontiguousarray(queries, dtype=self.np_dtype)
+        if q.ndim != 3 or q.shape[2] != self.dim:
+            raise ValueError("queries must be [n_batches, nq, %d]" % self.dim)
+        nb, nq = q.shape[0], q.shape[1]
+        ids = np.empty((nb, nq, max(k, 0)), np.uint64)
+        ds = np.empty((nb, nq, max(k, 0)), np.float32)
+        cnt = np.zeros((nb, nq), np.uint32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        self._check(self._lib.granne_hip_sharded_search_batches(self._h, p(q), nb, nq, int(max_search), int(k), p(ids), p(ds),
+                                                               p(cnt)))
+        return ids, ds, cnt
+
+    def search_batch(self, queries, max_search, k):
+        q = np.ascontiguousarray(queries, dtype=self.np_dtype)
+        ids, ds, cnt = self.search_batches(q[None], max_search, k)
+        return ids[0], ds[0], cnt[0]
 
 
 def replica_query_rows(rank, world_size, n_batches, batch):

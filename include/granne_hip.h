@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GRANNE_HIP_ABI_VERSION 2
+#define GRANNE_HIP_ABI_VERSION 3
 
 /* element scalar types: granne::angular::Vectors (f32, rows normalised) and
  * granne::angular_int::Vectors (i8, rows quantised) -- src/elements/angular.rs:53,
@@ -113,8 +113,14 @@ int granne_hip_index_get_element(const granne_hip_index* index, uint64_t idx, vo
  *   out_dists  f32          the distances; unused slots = +inf
  *   out_counts u32 [nq]     results per query = min(num_neighbors, max_search, #reachable)
  *   out_stats  u64 [nq][3]  (optional) per query: n_dist, n_expand, n_adj -- the counters the
- *                           roofline uses: dist_to_element calls, get_neighbors
- *                           calls, neighbor ids returned by those calls.
+ *                           roofline uses. [1] n_expand = get_neighbors calls
+ *                           (src/index/mod.rs:1025) and [2] n_adj = neighbor ids those calls returned
+ *                           are the reference's counts in every mode. [0] n_dist = element rows
+ *                           EVALUATED: by default the walkers keep no visited set and evaluate a
+ *                           neighbor they have seen before again (same result, ~3 % more rows on
+ *                           uniform data), so [0] >= the reference's dist_to_element calls
+ *                           (mod.rs:1012,1027); with an exact visited set switched on
+ *                           (GRANNE_HIP_OPT_VISITED16 = 1, 2 or 3) [0] IS the reference's count.
  * Thread-safe on a shared index.                                                              */
 int granne_hip_search_batch(const granne_hip_index* index, const void* queries, uint32_t nq,
                             uint32_t max_search, uint32_t num_neighbors, uint64_t* out_ids,
@@ -130,6 +136,21 @@ int granne_hip_search_batch_device(const granne_hip_index* index, const void* d_
                                    uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
                                    float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
                                    uint32_t* d_status, void* stream);
+
+/* n_batches batches of nq queries each through ONE kernel launch (a grid of n_batches x nq walkers): the
+ * caller-side loop / par_iter over Granne::search (src/index/mod.rs:140-150) for a host that has several
+ * batches ready. One launch of 1024 walks occupies one of a SIMD's wave slots and lasts as long as its
+ * slowest walk; here walks of later batches take the place of finished ones inside the same launch, so ONE
+ * stream and default HIP settings reach what otherwise takes 5-10 streams in flight.
+ * d_queries / d_out_*: HOST arrays of n_batches DEVICE pointers (batch b: [nq][dim] queries, [nq][k] ids
+ * and dists, [nq] counts, [nq][3] stats); d_out_stats may be NULL, and so may its entries. d_status as in
+ * granne_hip_search_batch_device (shared by all batches). Results are those of n_batches separate calls,
+ * bit for bit. More than 32 batches go out as several launches on `stream`. Asynchronous.              */
+int granne_hip_search_batches_device(const granne_hip_index* index, uint32_t n_batches,
+                                     const void* const* d_queries, uint32_t nq, uint32_t max_search,
+                                     uint32_t num_neighbors, uint64_t* const* d_out_ids,
+                                     float* const* d_out_dists, uint32_t* const* d_out_counts,
+                                     uint64_t* const* d_out_stats, uint32_t* d_status, void* stream);
 
 /* granne_hip_search_batch_device, and two optional hipEvent_t recorded on `stream` immediately
  * before and after the dispatch of the search kernel itself (the call also enqueues a small
@@ -272,19 +293,62 @@ int granne_hip_merge_topk_packed_strided_device(const void* d_packed, uint64_t s
 /* ---- a partitioned index driven by one host process ----------------------------------------------
  * SURVEY.md 8b's `device_ids / n_devices / partitioned`: shard s is a granne_hip_index of its own
  * (created on whatever device it should live on: granne_hip_index_create*, _load*, a builder's
- * get_index) over the elements [id_offsets[s], id_offsets[s] + len_s) of the whole set, with local ids.
- * granne_hip_sharded_search_batch = Granne::search on every shard + the merge: each shard searches the
- * same batch on its own device and stream, its packed top-k goes to shard 0's device (peer copy over
- * xGMI), merge by (dist, global id). Results equal the per-shard searches merged on the host.
- * The handle BORROWS the shard indexes (destroy them after it). One search at a time per handle.
- * n_shards <= 64, n_shards * num_neighbors <= 4096.                                              */
+ * get_index) over the elements [id_offsets[s], id_offsets[s] + len_s) of the whole set, with local ids
+ * (the split of src/elements/embeddings/parsing.rs:63-100). A search = Granne::search on every shard +
+ * the merge: each shard searches the same batch on its own device and stream and writes its packed
+ * top-k + status words into the gather buffer on shard 0's device -- directly when it lives there, by
+ * a peer copy over xGMI otherwise, or (GRANNE_HIP_SHARDED_OPT_EXCHANGE) through ONE ncclAllGather over
+ * the shard devices -- then merge by (dist, global id). Results equal the per-shard searches merged on
+ * the host, bit for bit. The handle BORROWS the shard indexes (destroy them after it).
+ * n_shards <= 64, n_shards * num_neighbors <= 4096.                                               */
 typedef struct granne_hip_sharded granne_hip_sharded;
 int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_index* const* shards,
                               const uint64_t* id_offsets, uint32_t n_shards);
 void granne_hip_sharded_destroy(granne_hip_sharded* sharded);
 uint32_t granne_hip_sharded_num_shards(const granne_hip_sharded* sharded);
 uint64_t granne_hip_sharded_len(const granne_hip_sharded* sharded);
-/* queries / outputs: HOST buffers; out_ids are global ids, ascending (dist, id), [nq][num_neighbors]. */
+int granne_hip_sharded_device(const granne_hip_sharded* sharded); /* where queries / results of the _device calls live */
+
+enum {
+    GRANNE_HIP_SHARDED_OPT_DEPTH = 1,    /* batches that can be in flight at once (begin without end): 1..8, default 2 */
+    GRANNE_HIP_SHARDED_OPT_EXCHANGE = 2  /* how the per-shard top-k reach the merge device */
+};
+enum {
+    GRANNE_HIP_SHARDED_EXCHANGE_PEER = 0, /* hipMemcpyPeerAsync per remote shard (default; nothing at all for local shards) */
+    GRANNE_HIP_SHARDED_EXCHANGE_RCCL = 1  /* one grouped, in-place ncclAllGather over a communicator of the shard devices;
+                                             librccl is loaded with dlopen (an already loaded one first, then
+                                             $GRANNE_HIP_RCCL_LIB, then librccl.so); needs the shards in device order, the
+                                             same number on every device */
+};
+int granne_hip_sharded_set_option(granne_hip_sharded* sharded, int option, uint64_t value);
+int granne_hip_sharded_get_option(const granne_hip_sharded* sharded, int option, uint64_t* value);
+
+/* Device buffers (on granne_hip_sharded_device), stream-ordered, not synchronised: the batch is ordered after
+ * what `stream` holds, `stream` continues after the merged result is written. d_status (u32[4], optional,
+ * zeroed by the caller) receives the shards' status words folded: [0] |= a shard ran out of exact-search
+ * scratch, [1] += queries served by the exact walker, [2] += walks that borrowed an overflow table.        */
+int granne_hip_sharded_search_batch_device(granne_hip_sharded* sharded, const void* d_queries, uint32_t nq,
+                                           uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
+                                           float* d_out_dists, uint32_t* d_out_counts, uint32_t* d_status,
+                                           void* stream);
+/* The same in two halves, so that batches overlap: begin enqueues the shard searches, the exchange and the
+ * merge on the handle's own streams (ordered after what `stream` holds now) and returns a ticket; end makes
+ * `stream` wait for that batch's merged result. Up to GRANNE_HIP_SHARDED_OPT_DEPTH batches may be begun and
+ * not yet ended: batch b+1 is searched while batch b is exchanged and merged. The buffers of a batch must
+ * stay untouched between its begin and the completion of what follows its end on `stream`.               */
+int granne_hip_sharded_begin_device(granne_hip_sharded* sharded, const void* d_queries, uint32_t nq,
+                                    uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
+                                    float* d_out_dists, uint32_t* d_out_counts, uint32_t* d_status,
+                                    void* stream, uint64_t* out_ticket);
+int granne_hip_sharded_end_device(granne_hip_sharded* sharded, uint64_t ticket, void* stream);
+
+/* HOST buffers (synchronous; pinned staging inside): queries [n_batches][nq][dim], out_ids (global ids,
+ * ascending (dist, id)) / out_dists [n_batches][nq][num_neighbors], out_counts [n_batches][nq]; batches
+ * are pipelined GRANNE_HIP_SHARDED_OPT_DEPTH deep (batch b+1's upload and search overlap batch b's
+ * exchange, merge and download). The host-pointer calls of one handle run one at a time.                */
+int granne_hip_sharded_search_batches(granne_hip_sharded* sharded, const void* queries, uint32_t n_batches,
+                                      uint32_t nq, uint32_t max_search, uint32_t num_neighbors,
+                                      uint64_t* out_ids, float* out_dists, uint32_t* out_counts);
 int granne_hip_sharded_search_batch(granne_hip_sharded* sharded, const void* queries, uint32_t nq,
                                     uint32_t max_search, uint32_t num_neighbors, uint64_t* out_ids,
                                     float* out_dists, uint32_t* out_counts);
@@ -358,7 +422,8 @@ enum {
     GRANNE_HIP_OPT_FORCE_SLOW = 2,    /* 1: route every query through the exact global-memory path */
     GRANNE_HIP_OPT_SLOW_SLOTS = 3,    /* global visited/queue slots per slow-path query (pow2)      */
     GRANNE_HIP_OPT_SLOW_BLOCKS = 4,   /* concurrent slow-path walkers serving hand-overs; a batch that is the exact walker's
-                                         as a whole (max_search beyond the register lists) runs up to 32x as many */
+                                         as a whole runs up to 32x as many, within 1 GB of scratch
+                                         (12 bytes x SLOW_SLOTS per walker; the block is kept per (index, stream)) */
     GRANNE_HIP_OPT_OVERFLOW_SLOTS = 5,/* global overflow slots per walk for a full LDS visited table:
                                          0 = auto, 1 = off (such walks go to the slow path), else pow2 */
     GRANNE_HIP_OPT_VISITED16 = 6,     /* the visited set of the register walkers (unless VISITED_SLOTS is set):

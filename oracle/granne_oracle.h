@@ -165,6 +165,7 @@ float gro_synth_component(uint64_t seed, uint64_t row, uint32_t col, uint32_t di
 void gro_synth_rows(uint64_t seed, uint64_t row0, uint64_t n_rows, uint32_t dim, float* out);
 
 int gro_max_threads(void);
+void gro_parallel_copy(void* dst, const void* src, size_t bytes, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -128,6 +128,8 @@ def lib():
         L.gro_synth_rows.restype = None
         L.gro_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
         L.gro_max_threads.restype = C.c_int
+        L.gro_parallel_copy.restype = None
+        L.gro_parallel_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _lib = L
     return _lib
 

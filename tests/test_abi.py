@@ -54,7 +54,7 @@ def test_rust_binding_in_integration_md_declares_the_whole_header():
 
 
 def test_abi_version(lib):
-    assert lib.granne_hip_abi_version() == 2
+    assert lib.granne_hip_abi_version() == 3
 
 
 def test_library_contains_gfx950_code_object():
@@ -103,3 +103,12 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.granne_hip_event_create(None) == _lib.ERR_INVALID
     assert lib.granne_hip_event_elapsed_ms(None, None, None) == _lib.ERR_INVALID
     lib.granne_hip_event_destroy(None)  # a no-op
+    # round 4: several batches per launch; the partitioned handle's device-pointer and option entries
+    assert lib.granne_hip_search_batches_device(None, 1, p, 1, 10, 1, p, p, p, None, None, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_sharded_search_batch_device(None, p, 1, 10, 1, p, p, p, None, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_sharded_begin_device(None, p, 1, 10, 1, p, p, p, None, None, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_sharded_end_device(None, 0, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_sharded_search_batches(None, p, 1, 1, 10, 1, p, p, p) == _lib.ERR_INVALID
+    assert lib.granne_hip_sharded_set_option(None, 1, 2) == _lib.ERR_INVALID
+    assert lib.granne_hip_sharded_get_option(None, 1, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_sharded_device(None) == -1

@@ -1,4 +1,4 @@
-"""Host-side pieces of bench.py that need no GPU: the in-flight rule, the workload labels, the source stamp."""
+"""Host-side pieces of bench.py that need no GPU: the batches-per-call rule, the workload labels, the source stamp."""
 import os
 import sys
 import types
@@ -11,22 +11,20 @@ if ROOT not in sys.path:
 import bench  # noqa: E402
 
 
-def test_batches_in_flight_divide_the_timed_steps():
-    auto = types.SimpleNamespace(inflight=0)
-    # the driver's K = 20: five f32 / ten int8 batches in flight (every round of the K steps is full)
-    assert bench.auto_inflight(auto, "f32", 20) == 5
-    assert bench.auto_inflight(auto, "i8", 20) == 10
-    # K a multiple of the saturating count: that count; no divisor within a quarter below it: that count too
-    assert bench.auto_inflight(auto, "f32", 12) == 6
-    assert bench.auto_inflight(auto, "i8", 24) == 12
-    assert bench.auto_inflight(auto, "f32", 7) == 6
-    assert bench.auto_inflight(auto, "i8", 13) == 12
-    # the sub-records' K = 10
-    assert bench.auto_inflight(auto, "f32", 10) == 5
-    assert bench.auto_inflight(auto, "i8", 10) == 10
-    # an explicit --inflight wins
-    assert bench.auto_inflight(types.SimpleNamespace(inflight=3), "i8", 20) == 3
-    assert bench.auto_inflight(types.SimpleNamespace(inflight=1), "f32", 20) == 1
+def test_batches_per_call_divide_the_timed_steps():
+    auto = types.SimpleNamespace(batches_per_call=0)
+    # the driver's K = 20 (and the sub-records' K = 10): all steps in one call = one launch
+    assert bench.auto_group(auto, 20) == 20
+    assert bench.auto_group(auto, 10) == 10
+    assert bench.auto_group(auto, 32) == 32
+    # more steps than one launch carries (32 batches): the largest divisor of K that fits, so every call has one shape
+    assert bench.auto_group(auto, 64) == 32
+    assert bench.auto_group(auto, 100) == 25
+    assert bench.auto_group(auto, 37) == 1  # a prime beyond 32: one batch per call
+    # an explicit --batches-per-call wins, bounded by K
+    assert bench.auto_group(types.SimpleNamespace(batches_per_call=4), 20) == 4
+    assert bench.auto_group(types.SimpleNamespace(batches_per_call=1), 20) == 1
+    assert bench.auto_group(types.SimpleNamespace(batches_per_call=50), 20) == 20
 
 
 def test_workload_label_names_baseline_configs_only_for_their_exact_shape():

@@ -549,6 +549,90 @@ def test_device_resident_api(ga, oracle):
     assert status.tolist() == [0, 0, 0, 0]
 
 
+@pytest.mark.parametrize("case", ["f32_100", "i8_100", "f32_gen33", "i8_wide600", "forced_slow", "ties_hand_over"])
+@pytest.mark.parametrize("n_batches", [1, 3, 35])
+def test_several_batches_in_one_launch(ga, oracle, case, n_batches):
+    """granne_hip_search_batches_device: a grid of n_batches x nq walkers (35 batches: two launches). Results, counts and
+    counters are those of n_batches separate searches -- on the register walker, the general walker (int8 rows of 640
+    bytes), the exact walker (every query handed over: the tail blocks address batches through the same table) and with
+    tied distances (hand-overs inside a batched launch)."""
+    import torch
+    from granne_amd import _lib
+    rng = np.random.default_rng(2600 + n_batches)
+    int8 = case.startswith("i8")
+    dim = {"f32_100": 100, "i8_100": 100, "f32_gen33": 33, "i8_wide600": 600, "forced_slow": 100, "ties_hand_over": 28}[case]
+    n, nq, ef, k = 3000, 40, 30, 7
+    raw = random_floats(rng, n, dim)
+    if case == "ties_hand_over":
+        raw[n // 2:] = raw[: n - n // 2]  # every vector twice: exact distance ties
+    el = prep(oracle, raw, int8)
+    oix = oracle.build_index(el, num_neighbors=12, max_search=20, reinsert_elements=False, n_threads=0)
+    gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
+    if case == "forced_slow":
+        gix.set_option(_lib.OPT_FORCE_SLOW, 1)
+    q = prep(oracle, random_floats(rng, n_batches * nq, dim), int8)
+    tdt = torch.int8 if int8 else torch.float32
+    # batches deliberately NOT contiguous with each other: separate allocations, one per batch
+    dq = [torch.from_numpy(q[b * nq:(b + 1) * nq].copy()).cuda() for b in range(n_batches)]
+    ids = [torch.full((nq, k), -7, dtype=torch.int64, device="cuda") for _ in range(n_batches)]
+    ds = [torch.zeros((nq, k), dtype=torch.float32, device="cuda") for _ in range(n_batches)]
+    cnt = [torch.full((nq,), 99, dtype=torch.int32, device="cuda") for _ in range(n_batches)]
+    st = [torch.zeros((nq, 3), dtype=torch.int64, device="cuda") for _ in range(n_batches)]
+    assert dq[0].dtype == tdt
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    ptrs = lambda ts: [t.data_ptr() for t in ts]  # noqa: E731
+    gix.search_batches_device(ptrs(dq), nq, ef, k, ptrs(ids), ptrs(ds), ptrs(cnt), ptrs(st), status.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    oi, od, oc, octr = oix.search_batch(q, ef, k)
+    for b in range(n_batches):
+        sl = slice(b * nq, (b + 1) * nq)
+        assert (ids[b].cpu().numpy().astype(np.uint64) == oi[sl]).all(), (case, b)
+        assert ds[b].cpu().numpy().tobytes() == od[sl].tobytes(), (case, b)
+        assert (cnt[b].cpu().numpy().astype(np.uint32) == oc[sl]).all()
+        exact = case in ("forced_slow", "i8_wide600")  # walkers that keep an exact visited set
+        assert_counters(st[b].cpu().numpy(), octr[sl], exact=exact)
+    assert status[0].item() == 0
+    if case == "forced_slow":
+        assert status[1].item() == n_batches * nq
+    # without statistics, and with num_neighbors 0 (.take(0)): counts only
+    for t in ids:
+        t.fill_(-7)
+    gix.search_batches_device(ptrs(dq), nq, ef, k, ptrs(ids), ptrs(ds), ptrs(cnt), None, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert all((ids[b].cpu().numpy().astype(np.uint64) == oi[b * nq:(b + 1) * nq]).all() for b in range(n_batches))
+    gix.search_batches_device(ptrs(dq), nq, ef, 0, ptrs(ids), ptrs(ds), ptrs(cnt), None, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert all(int(c.abs().sum().item()) == 0 for c in cnt)
+
+
+def test_many_streams_take_transient_scratch_blocks(ga, oracle):
+    """An index caches one scratch block per stream for 64 streams; further streams search with a block of the
+    stream-ordered allocator (no device-wide synchronisation, nothing discarded) and return the same results."""
+    import torch
+    rng = np.random.default_rng(2700)
+    el = prep(oracle, random_floats(rng, 3000, 100), False)
+    oix = oracle.build_index(el, num_neighbors=12, max_search=20, reinsert_elements=False, n_threads=0)
+    gix = ga.Granne("angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 64, 100), False)
+    oi, od, oc, _ = oix.search_batch(q, 40, 10)
+    dq = torch.from_numpy(q).cuda()
+    streams = [torch.cuda.Stream() for _ in range(70)]
+    outs = []
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for s_ in streams:
+            ids = torch.empty((64, 10), dtype=torch.int64, device="cuda")
+            ds = torch.empty((64, 10), dtype=torch.float32, device="cuda")
+            cnt = torch.empty(64, dtype=torch.int32, device="cuda")
+            gix.search_batch_device(dq.data_ptr(), 64, 40, 10, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), 0, 0, s_.cuda_stream)
+            outs.append((ids, ds, cnt))
+    torch.cuda.synchronize()
+    for ids, ds, cnt in outs:
+        assert (ids.cpu().numpy().astype(np.uint64) == oi).all() and ds.cpu().numpy().tobytes() == od.tobytes()
+        assert (cnt.cpu().numpy().astype(np.uint32) == oc).all()
+
+
 def test_concurrent_searches_on_a_shared_index(ga, oracle):
     """Granne::search takes &self and is re-entrant (SURVEY 8b); granne_hip_search_batch is
     documented thread-safe on a shared handle: four host threads, different batches."""

@@ -87,3 +87,132 @@ def test_sharded_c_abi(oracle, int8):
         assert lib.granne_hip_sharded_search_batch(sh, p(q), nq, 0, k, p(ids), p(ds), p(cnt)) == _lib.ERR_INVALID
     finally:
         lib.granne_hip_sharded_destroy(sh)
+
+
+def _batches(oracle, int8, n_batches, nq, seed):
+    rng = np.random.default_rng(seed)
+    raw = random_floats(rng, n_batches * nq, 32)
+    q = oracle.quantize(raw) if int8 else oracle.normalize_f32(raw)
+    return q.reshape(n_batches, nq, 32)
+
+
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("exchange", ["peer", "rccl"])
+def test_sharded_device_entries_pipelined(oracle, int8, exchange):
+    """The stream-ordered entries of the one-process handle: search_batch_device, begin / end with two batches in flight,
+    the pipelined host-pointer search_batches -- with peer copies and with the RCCL all-gather as the exchange step (one
+    device here: a one-rank communicator; librccl comes in by dlopen) -- against per-shard oracle searches + numpy merge."""
+    import torch
+    from granne_amd import _lib, sharded
+    shards, k, ef, nb, nq = 5, 6, 40, 6, 37
+    _, bounds, gixs, oixs = _shards(oracle, int8, shards, 91)
+    offsets = [b[0] for b in bounds]
+    sh = sharded.ShardedHost(gixs, offsets)
+    if exchange == "rccl":
+        sh.set_option(_lib.SHARDED_OPT_EXCHANGE, _lib.SHARDED_EXCHANGE_RCCL)
+        assert sh.get_option(_lib.SHARDED_OPT_EXCHANGE) == _lib.SHARDED_EXCHANGE_RCCL
+    assert sh.get_option(_lib.SHARDED_OPT_DEPTH) == 2 and len(sh) == sum(len(g) for g in gixs)
+    q = _batches(oracle, int8, nb, nq, 5)
+    want = [_want(oixs, q[b], ef, k, offsets) for b in range(nb)]
+    dq = torch.from_numpy(q).cuda()
+    ids = torch.zeros((nb, nq, k), dtype=torch.int64, device="cuda")
+    ds = torch.zeros((nb, nq, k), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros((nb, nq), dtype=torch.int32, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+
+    def check():
+        torch.cuda.synchronize()
+        for b in range(nb):
+            assert (cnt[b].cpu().numpy().astype(np.uint32) == want[b][2]).all()
+            assert (ids[b].cpu().numpy().astype(np.uint64) == want[b][0]).all()
+            assert ds[b].cpu().numpy().tobytes() == want[b][1].tobytes()
+        ids.zero_(), ds.zero_(), cnt.zero_()
+
+    for b in range(nb):  # one batch at a time, stream-ordered, no host synchronisation in between
+        sh.search_batch_device(dq[b].data_ptr(), nq, ef, k, ids[b].data_ptr(), ds[b].data_ptr(), cnt[b].data_ptr(),
+                               status.data_ptr(), s)
+    check()
+    assert status.tolist() == [0, 0, 0, 0]
+    tickets = []
+    for b in range(nb):  # two in flight: batch b is begun before batch b - 1 is ended
+        tickets.append(sh.begin_device(dq[b].data_ptr(), nq, ef, k, ids[b].data_ptr(), ds[b].data_ptr(), cnt[b].data_ptr(), 0, s))
+        if b >= 1:
+            sh.end_device(tickets[b - 1], s)
+    sh.end_device(tickets[-1], s)
+    check()
+    h_ids, h_ds, h_cnt = sh.search_batches(q, ef, k)  # host buffers, pipelined inside the library
+    for b in range(nb):
+        assert (h_cnt[b] == want[b][2]).all() and (h_ids[b] == want[b][0]).all() and h_ds[b].tobytes() == want[b][1].tobytes()
+    # another batch size on the same handle regrows the slots' buffers
+    q2 = _batches(oracle, int8, 3, 9, 6)
+    h2 = sh.search_batches(q2, ef, k)
+    for b in range(3):
+        w = _want(oixs, q2[b], ef, k, offsets)
+        assert (h2[0][b] == w[0]).all() and h2[1][b].tobytes() == w[1].tobytes()
+    sh.close()
+
+
+def test_sharded_depth_and_tickets(oracle):
+    import torch
+    from granne_amd import _lib, sharded
+    _, bounds, gixs, oixs = _shards(oracle, False, 3, 92)
+    sh = sharded.ShardedHost(gixs, [b[0] for b in bounds], depth=3)
+    assert sh.get_option(_lib.SHARDED_OPT_DEPTH) == 3
+    q = torch.from_numpy(_batches(oracle, False, 1, 8, 7)[0]).cuda()
+    outs = [(torch.empty((8, 4), dtype=torch.int64, device="cuda"), torch.empty((8, 4), dtype=torch.float32, device="cuda"),
+             torch.empty(8, dtype=torch.int32, device="cuda")) for _ in range(4)]
+    s = torch.cuda.current_stream().cuda_stream
+    t = [sh.begin_device(q.data_ptr(), 8, 30, 4, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), 0, s) for o in outs[:3]]
+    with pytest.raises(_lib.GranneHipError) as e:  # a fourth batch with three in flight
+        sh.begin_device(q.data_ptr(), 8, 30, 4, outs[3][0].data_ptr(), outs[3][1].data_ptr(), outs[3][2].data_ptr(), 0, s)
+    assert e.value.code == _lib.ERR_INVALID
+    with pytest.raises(_lib.GranneHipError):
+        sh.set_option(_lib.SHARDED_OPT_DEPTH, 2)  # not while batches are in flight
+    with pytest.raises(_lib.GranneHipError):
+        sh.end_device(t[0] + (1 << 8), s)  # not a ticket of a batch in flight
+    for x in t:
+        sh.end_device(x, s)
+    with pytest.raises(_lib.GranneHipError):
+        sh.end_device(t[0], s)  # ended already
+    torch.cuda.synchronize()
+    want = _want(oixs, q.cpu().numpy(), 30, 4, [b[0] for b in bounds])
+    for o in outs[:3]:
+        assert (o[0].cpu().numpy().astype(np.uint64) == want[0]).all()
+    sh.close()
+
+
+def test_sharded_status_words_are_folded_on_the_device(oracle):
+    """A shard whose exact-search scratch runs out: the device entry reports it in d_status[0] (and counts the hand-overs
+    in [1]), the host entry returns GRANNE_HIP_ERR_OVERFLOW -- and the handle stays usable."""
+    import torch
+    from granne_amd import _lib, sharded
+    _, bounds, gixs, oixs = _shards(oracle, False, 4, 93)
+    offsets = [b[0] for b in bounds]
+    sh = sharded.ShardedHost(gixs, offsets)
+    q = _batches(oracle, False, 2, 16, 8)
+    gixs[2].set_option(_lib.OPT_FORCE_SLOW, 1)
+    dq = torch.from_numpy(q[0]).cuda()
+    o = (torch.empty((16, 5), dtype=torch.int64, device="cuda"), torch.empty((16, 5), dtype=torch.float32, device="cuda"),
+         torch.empty(16, dtype=torch.int32, device="cuda"))
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    sh.search_batch_device(dq.data_ptr(), 16, 60, 5, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), status.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert status.tolist()[:2] == [0, 16]  # one shard served its 16 queries with the exact walker; results unchanged
+    want = _want(oixs, q[0], 60, 5, offsets)
+    assert (o[0].cpu().numpy().astype(np.uint64) == want[0]).all() and o[1].cpu().numpy().tobytes() == want[1].tobytes()
+    gixs[2].set_option(_lib.OPT_SLOW_SLOTS, 256)  # far too few for a walk of max_search 60
+    status.zero_()
+    sh.search_batch_device(dq.data_ptr(), 16, 60, 5, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), status.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert status[0].item() == 1
+    with pytest.raises(_lib.GranneHipError) as e:
+        sh.search_batches(q, 60, 5)
+    assert e.value.code == _lib.ERR_OVERFLOW
+    gixs[2].set_option(_lib.OPT_FORCE_SLOW, 0)
+    h = sh.search_batches(q, 60, 5)
+    for b in range(2):
+        w = _want(oixs, q[b], 60, 5, offsets)
+        assert (h[0][b] == w[0]).all() and h[1][b].tobytes() == w[1].tobytes()
+    sh.close()
