@@ -66,6 +66,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the process's CPU affinity as it was started (libgomp binds the master thread to its place at the first parallel region)
+AFFINITY_AT_START = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+
 SEED = 0x6772616E6E65  # "granne"; queries use SEED + 1
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 measured copy ceiling
 
@@ -632,7 +635,7 @@ class Bench:
                     return f.read().strip()
             except Exception:
                 return None
-        info = {"logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+        info = {"logical_cpus": os.cpu_count(), "affinity_cpus": AFFINITY_AT_START,
                 "cgroup_cpu_max": rd("/sys/fs/cgroup/cpu.max"), "thp_enabled": rd("/sys/kernel/mm/transparent_hugepage/enabled")}
         if info["cgroup_cpu_max"] is None:
             q, per = rd("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), rd("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
@@ -704,17 +707,26 @@ class Bench:
         nqs = h_q.shape[0]
         logical = os.cpu_count() or 1
         phys = max(1, logical // 2)
+        host = self.host_info()
+        quota = host.get("cgroup_quota_cpus")
         if a.cpu_threads:
             cands = [a.cpu_threads]
         elif sweep or not getattr(self, "_cpu_best_threads", None):
-            cands = sorted({t for t in (8, 16, 32, 64, 128, 256, phys, logical) if t <= logical})
+            full = (8, 16, 32, 64, 128, 256, phys, logical)
+            if quota:  # a container with a CPU quota: threads far beyond it only burn the quota early in every period
+                q = max(1, int(round(quota)))
+                full = (max(1, q // 2), q, 2 * q, 4 * q)
+            cands = sorted({t for t in full if t <= logical})
         else:
-            cands = sorted({self._cpu_best_threads, phys})
+            cands = sorted({self._cpu_best_threads})
         best, tried = None, []
         for th in cands:
-            # one untimed pass inside the same parallel region, then as many timed passes as fill cpu_seconds
+            # an untimed pass inside the same parallel region precedes every timed run; the number of timed passes comes
+            # from a probe of >= 0.3 s (a shorter one ends before a cgroup quota starts throttling the team)
             probe, _, _, _ = oix.search_batch_timed(h_q, ef, k, n_threads=th, repeats=1)
-            reps = max(1, int(math.ceil(a.cpu_seconds / max(probe, 1e-6))))
+            r2 = max(1, int(math.ceil(0.3 / max(probe, 1e-6))))
+            probe2, _, _, _ = oix.search_batch_timed(h_q, ef, k, n_threads=th, repeats=r2)
+            reps = max(1, int(math.ceil(a.cpu_seconds / max(probe2 / r2, 1e-6))))
             sec, o_ids, o_d, o_c = oix.search_batch_timed(h_q, ef, k, n_threads=th, repeats=reps)
             rate = reps * nqs / sec
             tried.append({"threads": th, "value": round(rate, 1), "passes": reps, "seconds": round(sec, 2)})
@@ -731,12 +743,11 @@ class Bench:
         single = m1 / (time.perf_counter() - t1)
         ids_ok = bool((g_ids == o_ids).all())
         d_ok = g_d.tobytes() == o_d.tobytes()
-        host = self.host_info()
         usable = min(threads, phys)
-        if host.get("cgroup_quota_cpus"):
-            usable = min(usable, host["cgroup_quota_cpus"])
-        if host.get("affinity_cpus"):
-            usable = min(usable, max(1, host["affinity_cpus"] // 2) if host["affinity_cpus"] == logical else host["affinity_cpus"])
+        if quota:
+            usable = min(usable, quota)
+        if host.get("affinity_cpus") and host["affinity_cpus"] < logical:
+            usable = min(usable, host["affinity_cpus"])
         return {
             "value": round(rate, 1), "unit": "queries/s", "cores": threads, "kind": "port",
             "single_thread": {"value": round(single, 1), "unit": "queries/s", "queries": int(m1)},
@@ -939,15 +950,18 @@ def c1_record(B, args):
     rate, reps = B.timed_window(run, 1)
     h_q = q.cpu().numpy()
     cb = B.cpu_baseline(oix, h_q, ef, k, ids.cpu().numpy().astype(np.uint64), ds.cpu().numpy(), single_thread_queries=128, sweep=False)
-    batch_self = bool((ids[:, 0] == mem).all().item())
+    # (a graph built with max_search 10 does not lead every member back to itself: the fraction is reported, the CPU
+    #  oracle on the same graph returns the same ids either way -- checked below)
+    self_frac = float((ids[:, 0] == mem).float().mean().item())
     rec = {"workload": "C1 (BASELINE.json configs[0], examples/glove.rs:46-60): %d x %d-d f32 angular (synthetic stand-in for GloVe-100), "
                        "build max_search 10, member queries at (max_search %d, k %d)" % (n, dim, ef, k),
            "layers": [builder.layer_len(l) for l in range(builder.num_layers())], "build_s": round(t_build, 2),
            "four_searches": singles, "four_searches_equal_oracle_bit_for_bit": bool(ok),
-           "self_is_nearest_at_distance_0": bool(self_first and batch_self),
+           "the_four_members_are_their_own_nearest_at_distance_0": bool(self_first),
            "members_1024": {"value": round(rate * 1024, 1), "unit": "queries/s", "calls_timed": reps,
+                            "fraction_that_found_itself_first": round(self_frac, 4),
                             "cpu_baseline": cb, "speedup_vs_cpu": round(rate * 1024 / cb["value"], 1)}}
-    if not (ok and self_first and batch_self and cb["gpu_matches_oracle"]["ids_bit_exact"] and cb["gpu_matches_oracle"]["dists_bit_exact"]):
+    if not (ok and self_first and cb["gpu_matches_oracle"]["ids_bit_exact"] and cb["gpu_matches_oracle"]["dists_bit_exact"]):
         raise RuntimeError("C1 parity failed: %s" % json.dumps(rec)[:600])
     del oix, index, builder, el
     torch.cuda.empty_cache()

@@ -14,7 +14,8 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OVERFLOW, ERR_IO = -1, -2, -3, -4, -5
 
 OPT_VISITED_SLOTS, OPT_FORCE_SLOW, OPT_SLOW_SLOTS, OPT_SLOW_BLOCKS, OPT_OVERFLOW_SLOTS = 1, 2, 3, 4, 5
-OPT_VISITED16, OPT_VISITED16_LG = 6, 7
+OPT_VISITED16, OPT_VISITED16_LG, OPT_LAST_WALKER = 6, 7, 8
+WALKER_NONE, WALKER_REGISTER, WALKER_REGISTER_WIDE, WALKER_GENERAL, WALKER_EXACT = 0, 1, 2, 3, 4
 SHARDED_OPT_DEPTH, SHARDED_OPT_EXCHANGE = 1, 2
 SHARDED_EXCHANGE_PEER, SHARDED_EXCHANGE_RCCL = 0, 1
 

@@ -116,6 +116,7 @@ struct granne_hip_index {
     uint64_t opt_visited16 = 0;      // 0 auto, 1 off, 2 always the 20-bit entries (tests)
     uint64_t opt_visited16_lg = 0;   // 0 auto, else log2(buckets)
     std::atomic<uint64_t> last_slow_count{0};
+    std::atomic<uint64_t> last_walker{0}; // GRANNE_HIP_OPT_LAST_WALKER
     // host-pointer searches (granne_hip_search / _search_batch): a stream, a device buffer and a pinned
     // staging buffer per concurrent caller, kept for the life of the index -- the reference's API is one
     // query per call (src/index/mod.rs:140-150), so a call must not pay stream creation and hipMalloc
@@ -490,6 +491,7 @@ extern "C" int granne_hip_index_get_option(const granne_hip_index* ix, int optio
     case GRANNE_HIP_OPT_OVERFLOW_SLOTS: *value = ix->opt_overflow_slots; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_VISITED16: *value = ix->opt_visited16; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_VISITED16_LG: *value = ix->opt_visited16_lg; return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_LAST_WALKER: *value = ix->last_walker.load(); return GRANNE_HIP_OK;
     default: return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -515,6 +517,7 @@ struct SearchTarget {
     uint64_t opt_visited_slots, opt_force_slow, opt_slow_slots, opt_slow_blocks, opt_overflow_slots;
     uint64_t opt_visited16 = 0, opt_visited16_lg = 0;
     ScratchCache* scratch; // search_launch's per-stream scratch blocks
+    std::atomic<uint64_t>* last_walker = nullptr; // which kernel the last launch took (an index's read-only option)
 };
 
 static SearchTarget target_of(const granne_hip_index* ix) {
@@ -536,6 +539,7 @@ static SearchTarget target_of(const granne_hip_index* ix) {
     T.opt_visited16 = ix->opt_visited16;
     T.opt_visited16_lg = ix->opt_visited16_lg;
     T.scratch = &const_cast<granne_hip_index*>(ix)->scratch;
+    T.last_walker = &const_cast<granne_hip_index*>(ix)->last_walker;
     return T;
 }
 
@@ -583,8 +587,10 @@ static search_fn pick_kernel(int dtype, uint32_t ef) {
 // hold max_search of them plus a few spare places: two distances of a walk tie surprisingly often (4000
 // candidates share 2^23 float values), and a tie between entry max_search-1 and an entry pushed off the
 // end hands the walk over -- with spare places that takes a run of ties.
-constexpr uint32_t FAST_MAX_SEARCH = 1024;
-static uint32_t fast_list_slots(uint32_t ef) { return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : 17u; }
+constexpr uint32_t FAST_MAX_SEARCH = 4096; // f32 rows of 100 / 200 dims and int8 rows of 128 bytes: lists of up to 65 x 64 keys
+static uint32_t fast_list_slots(uint32_t ef) {
+    return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : ef <= 1024 ? 17u : ef <= 2048 ? 33u : 65u;
+}
 // v16: the form of the visited set (FastWalker's V16): 0 = 32-bit table, 1 = 16-bit entries, 2 = 20-bit entries, 3 = none
 template <int DT, int DIM, int S>
 static search_fn pick_fast_v(int v16) {
@@ -606,18 +612,33 @@ static search_fn pick_fast_s(uint32_t S, bool trail, int v16) {
     case 4: return pick_fast_v<DT, DIM, 4>(v16);
     case 8: return v16 >= 3 ? fast_kernel<DT, DIM, 8, false, 3> : fast_kernel<DT, DIM, 8>;
     default:
-        if constexpr (DT == DT_F32 && DIM == 0) return fast_kernel<DT, DIM, 8>; // not reached: max_search <= 508 there
-        else return v16 >= 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
+        if constexpr (DT == DT_F32 && DIM == 0) {
+            return fast_kernel<DT, DIM, 8>; // not reached: max_search <= 508 there
+        } else {
+            // lists of 33 / 65 slots (max_search up to 2048 / 4096) exist without a visited set only: plan_launch sends
+            // such a search there whatever the option says (an exact set of ~40 x max_search ids fits no LDS)
+            if (S == 33) return fast_kernel<DT, DIM, 33, false, 3>;
+            if (S == 65) return fast_kernel<DT, DIM, 65, false, 3>;
+            return v16 >= 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
+        }
     }
 }
+// Layers of up to 64 ids per node (graphs with num_neighbors 33..63: the GPU builder makes them, BuildConfig::num_neighbors
+// src/index/mod.rs:242) are walked in two passes of 32 pairs per expansion (FastWalker's WIDE) -- instantiated for lists of
+// up to 4 x 64 keys, without a visited set, not for Granne::reorder's trail walks, and for int8 rows of 128 bytes only.
+static bool fast_wide(const SearchTarget* ix) { return ix->max_dev_width == 64; }
 static bool fast_shape(const SearchTarget* ix) {
-    if (ix->max_dev_width != 32 || ix->n_elements > WALK_MAX_ELEMENTS) return false;
-    if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128 || ix->row_bytes == 256 || ix->row_bytes == 512; // dims <= 512
+    // (ids: 31 bits. A 2^31-element index needs 275 GB for its bottom layer's 128-byte adjacency rows alone, so the
+    //  reference's 2^32 - 2 capacity, src/index/mod.rs:27-28, is out of one device's reach whatever the key layout)
+    if (ix->max_dev_width > 64 || ix->n_elements > WALK_MAX_ELEMENTS) return false;
+    if (ix->dtype == GRANNE_HIP_I8)
+        return ix->row_bytes == 128 || (!fast_wide(ix) && (ix->row_bytes == 256 || ix->row_bytes == 512)); // dims <= 512
     return true; // f32: 100 and 200 fully unrolled, any other dim streamed (dims below 32: the tail alone)
 }
 static bool fast_generic(const SearchTarget* ix) { return ix->dtype == GRANNE_HIP_F32 && ix->dim != 100 && ix->dim != 200; }
 // the longest max_search the register walker is instantiated for, by shape
 static uint32_t fast_max_search(const SearchTarget* ix) {
+    if (fast_wide(ix)) return 252u;                                                        // layers of 64 ids: lists of up to 4 x 64 keys
     if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128 ? FAST_MAX_SEARCH : 252u; // wide int8 rows: lists of up to 4 x 64 keys
     return fast_generic(ix) ? 508u : FAST_MAX_SEARCH;                                       // streamed f32 dims: up to 8 x 64 keys
 }
@@ -631,7 +652,21 @@ static search_fn pick_fast_i8_wide(uint32_t S, bool trail, int v16) {
     default: return pick_fast_v<DT_I8, ROWB, 4>(v16);
     }
 }
+template <int DT, int DIM>
+static search_fn pick_fast_wide(uint32_t S) {
+    switch (S) {
+    case 1: return fast_kernel<DT, DIM, 1, false, 3, true>;
+    case 2: return fast_kernel<DT, DIM, 2, false, 3, true>;
+    default: return fast_kernel<DT, DIM, 4, false, 3, true>;
+    }
+}
 static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail, int v16) {
+    if (fast_wide(ix)) { // (search_launch sends trail walks and longer lists of such graphs to the general walker)
+        if (ix->dtype == GRANNE_HIP_I8) return pick_fast_wide<DT_I8, 0>(S);
+        if (ix->dim == 100) return pick_fast_wide<DT_F32, 100>(S);
+        if (ix->dim == 200) return pick_fast_wide<DT_F32, 200>(S);
+        return pick_fast_wide<DT_F32, 0>(S);
+    }
     if (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes == 256) return pick_fast_i8_wide<256>(S, trail, v16);
     if (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes == 512) return pick_fast_i8_wide<512>(S, trail, v16);
     if (ix->dtype == GRANNE_HIP_I8) return pick_fast_s<DT_I8, 0>(S, trail, v16);
@@ -666,7 +701,8 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
     // flight never slower and up to twice as fast -- no LDS bounds the walkers per CU, nothing spills.
     const int vmode = ix->opt_visited16 ? ix->opt_visited16 : knobs().visited;
     const bool none = vmode == 4 || vmode == 0;
-    if (fastS >= 1 && !trail && none && !ix->opt_visited_slots && ix->n_elements < WALK_MAX_ELEMENTS) {
+    const bool longest = fastS >= 33 || fast_wide(ix); // (lists of 33 / 65 slots, and 64-id layers: instantiated without a set only, whatever the options say)
+    if (fastS >= 1 && !trail && ((none && !ix->opt_visited_slots) || longest) && ix->n_elements < WALK_MAX_ELEMENTS) {
         // a launch of a few queries leaves the chip idle: its walkers touch the next node's rows ahead (walk_fast.h, TOUCH)
         const uint32_t touch_max = knobs().touch_max >= 0 ? (uint32_t)knobs().touch_max : 64u;
         const bool touch_shape = fastS == 1 && !fast_generic(ix) && !(ix->dtype == GRANNE_HIP_I8 && ix->row_bytes != 128);
@@ -853,7 +889,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     if (!d_queries || (!d_trail && (!d_ids || !d_dists || !d_counts))) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
 
     // (the streamed run-time-dim walker is instantiated up to 8 x 64 keys: beyond that the exact walker)
-    const bool fast = fast_shape(ix) && ef <= fast_max_search(ix);
+    const bool fast = fast_shape(ix) && ef <= fast_max_search(ix) && !(fast_wide(ix) && d_trail);
     const uint32_t fastS = fast ? fast_list_slots(ef) : 0u;
     const uint32_t ef_walk = fast ? ef : (ef > 256 ? 256 : ef); // what the register/LDS walker is sized for
     const bool all_slow = ix->opt_force_slow || (!fast && ef > 256);
@@ -973,6 +1009,10 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     sp.status2 = d_status;
     sp.host_status = host_status;
 
+    if (ix->last_walker)
+        ix->last_walker->store(all_slow ? GRANNE_HIP_WALKER_EXACT
+                                        : fast ? (fast_wide(ix) ? GRANNE_HIP_WALKER_REGISTER_WIDE : GRANNE_HIP_WALKER_REGISTER)
+                                               : GRANNE_HIP_WALKER_GENERAL);
     const uint32_t slow_lds = lds_query_bytes(ix->row_bytes) + 64 * 8;
     if (all_slow) { // every query on the exact walker: its kernel alone
         if (ev_before) HIP_TRY(hipEventRecord(ev_before, s));

@@ -271,7 +271,12 @@ __host__ __device__ inline uint32_t fast_query_bytes(bool i8, bool gen, uint32_t
 // queries); the exact sets: 0 = 32-bit open addressing (VisitedSet); 1 = 16-bit entries in two-choice buckets (half the
 // LDS; id spaces of up to 32767 ids per bucket); 2 = 20-bit entries (three eighths more LDS per id than 16-bit ones,
 // id spaces of up to 524286 ids per bucket). wave_prims.h; the host picks (plan_launch, granne_hip.hip).
-template <int DT, int DIM, int S, int V16 = 0>
+// WIDE: layers of up to 64 ids per node (graphs built with num_neighbors 33..63): an expansion takes the row's ids in two
+// passes of 32 pairs -- rows, distances, filter, insert for ids 0..31, then for ids 32..63 when the row goes that far.
+// `res` does not change within an expansion (mod.rs:1025-1033 pushes to pq only), so the reference's filter gives every
+// neighbor of the row the same answer whichever pass it is in; the list's own bookkeeping (dead candidates beyond entry
+// max_search-1, the tie test after a pass's last insert) is per insert group and does not care where a group ends.
+template <int DT, int DIM, int S, int V16 = 0, bool WIDE = false>
 struct FastWalker {
     static constexpr bool F32 = (DT == DT_F32);
     // DIM == 0: any f32 dim, known at run time (below 32 the row is its tail only). The chunks stream through the registers in groups of
@@ -303,6 +308,7 @@ struct FastWalker {
     // 128-byte line, data dropped -- so that, when that node is expanded next (half of the time), its rows come from L2.
     // With a thousand walks in a launch the same touches cost throughput and are not compiled in.
     static constexpr bool TOUCH = V16 == 4;
+    static_assert(!WIDE || V16 == 3, "layers of 64 ids: walked without a visited set only");
     typename std::conditional<V16 == 0, VisitedSet,
         typename std::conditional<V16 == 1, VisitedSet16,
             typename std::conditional<V16 == 2, VisitedSet20, VisitedNone>::type>::type>::type vis;
@@ -655,13 +661,14 @@ struct FastWalker {
         L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;
+        const uint32_t W = WIDE ? Ly.width : 32u; // ids per adjacency row on the device: 32, or 64 in a WIDE launch
         uint32_t pre_id = entrypoint, pre_nb; // adjacency row fetched ahead (one id per pair) and whose it is
 
         // distance to the entry point (mod.rs:1012-1016); the first pop of the loop takes it. On every layer
         // but the first the entry point is the node the layer above returned as its closest, and its distance
         // to the same query was evaluated there: the same operations on the same inputs give the same bits, so
         // the value is reused (the evaluation still counts) and the layer starts one memory round trip earlier.
-        pre_nb = adjg[(size_t)entrypoint * 32u + R]; // get_neighbors(entrypoint): needed right after
+        pre_nb = adjg[(size_t)entrypoint * W + R]; // get_neighbors(entrypoint): needed right after
         if constexpr (NOVIS) {}
         else if constexpr (V16 != 0) vis.insert(entrypoint, R == 0u, h, p.ovf, lane, bail);
         else vis.insert(entrypoint, lane == 0, p.ovf);
@@ -695,11 +702,23 @@ struct FastWalker {
             const uint32_t xid = wkey_id(x);
             uint32_t nb;
             if (pre_id == xid) nb = pre_nb;
-            else nb = adjg[(size_t)xid * 32u + R];
+            else nb = adjg[(size_t)xid * W + R];
+            [[maybe_unused]] uint32_t nb_hi = ID_EMPTY; // WIDE: ids 32..63 of the row, wanted once the first pass is through
+            if constexpr (WIDE) {
+                if (W > 32u) nb_hi = adjg[(size_t)xid * W + 32u + R];
+            }
             PT_MARK(0); // pop, break test, mark
             PT_WAIT_VM();
             PT_MARK(8); // wait for the adjacency row
             PT_COUNT();
+            uint64_t ykey = KEY_INF; // the entry that is first in line (or the candidate that has beaten it): set by pass 0
+            for (uint32_t half = 0; half < (WIDE ? 2u : 1u); ++half) {
+            if constexpr (WIDE) {
+                if (half == 1u) { // the row went through all of its first 32 places: its second 32
+                    nb = nb_hi;
+                    if (wave_ballot(nb != ID_EMPTY) == 0) break;
+                }
+            }
             const uint64_t unused = wave_ballot(nb == ID_EMPTY);
             const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
             st.n_adj += nvalid;
@@ -707,12 +726,14 @@ struct FastWalker {
                 const uint32_t last_id = nvalid ? readlane32(nb, 2u * (nvalid - 1u)) : xid;
                 issue_rows((R < nvalid) ? nb : last_id, rr);
             }
-            // fetch ahead the row of the node that is first in line now; always one load: static wait counts
-            uint32_t ypos = 0;
-            const bool has_y = L.first_unexpanded(ypos);
-            const uint64_t ykey = has_y ? L.at(ypos) : KEY_INF;
-            pre_id = has_y ? wkey_id(ykey) : xid;
-            pre_nb = adjg[(size_t)pre_id * 32u + R];
+            if (half == 0u) {
+                // fetch ahead the row of the node that is first in line now; always one load: static wait counts
+                uint32_t ypos = 0;
+                const bool has_y = L.first_unexpanded(ypos);
+                ykey = has_y ? L.at(ypos) : KEY_INF;
+                pre_id = has_y ? wkey_id(ykey) : xid;
+                pre_nb = adjg[(size_t)pre_id * W + R];
+            }
             PT_MARK(1); // row loads and the fetch-ahead issued
 
             // visited set under the loads, then the distances (mod.rs:1026-1027)
@@ -773,7 +794,8 @@ struct FastWalker {
                     }
                 }
                 pre_id = wkey_id(K);
-                pre_nb = adjg[(size_t)pre_id * 32u + R];
+                pre_nb = adjg[(size_t)pre_id * W + R];
+                if constexpr (WIDE) ykey = K; // the second pass's candidates have this one to beat
                 break;
             }
             PT_MARK(5); // filter, next-node decision, its adjacency request
@@ -791,18 +813,22 @@ struct FastWalker {
             if (!vis.make_room(p.ovf, lane)) bail = true;
             PT_MARK(9); // visited-set housekeeping
             if (bail) return;
+            if constexpr (WIDE) {
+                if (nvalid < 32u) break; // the row ended inside this pass
+            }
+            } // passes over the row
         }
     }
 };
 
-template <int DT, int DIM, int S, bool TRAIL, int V16>
+template <int DT, int DIM, int S, bool TRAIL, int V16, bool WIDE = false>
 __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint32_t qi, uint8_t* smem) {
     const uint32_t lane = threadIdx.x;
     if (p.force_slow) {
         hand_over(p, qi);
         return;
     }
-    FastWalker<DT, DIM, S, V16> w(p, smem);
+    FastWalker<DT, DIM, S, V16, WIDE> w(p, smem);
     w.load_query(qi);
 
     if constexpr (TRAIL) { // find_entrypoint_trail (reorder.rs:180-208): every walk starts at node 0
@@ -898,23 +924,25 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
 // waves per SIMD the register allocator is asked to keep possible (__launch_bounds__'s second argument is
 // per SIMD on AMD; 5 waves = 96 VGPRs, 4 = 128, 3 = 168, 2 = 256). Chosen from the unconstrained
 // allocation of each instantiation so that none spills (tools/isa_report.py prints both).
-constexpr int fast_waves_per_simd(int DT, int DIM, int S) {
+constexpr int fast_waves_per_simd(int DT, int DIM, int S, bool WIDE = false) {
 #if GRANNE_HIP_PHASE_TIMERS
     return 1; // the phase clocks live in registers too: no cap, the diagnostics run is one wave per SIMD anyway
 #endif
+    if (S >= 33) return 1; // lists of 2112 / 4160 keys: 2 registers per 64 keys + the merge's counters; 17-33 KB of LDS mirror each
     if (DT == DT_I8 && DIM >= 256) return DIM == 256 ? 3 : 2; // 2 / 4 blocks of row data and of query per lane
     if (DT == DT_I8) return S == 1 ? 5 : S <= 4 ? 4 : S == 8 ? 3 : 2;
     if (DIM == 0) return 2; // the streamed walker keeps a group of chunks, the tail and the accumulators: ~210 VGPRs
     if (DIM > 128) return S == 1 ? 3 : 2;
+    if (WIDE && S == 2) return 3; // (the second half of the row is one register too many for 128)
     return S == 1 ? (GRANNE_HIP_QUERY_IN_LDS ? 4 : 3) : S == 2 ? 4 : S <= 8 ? 3 : 2;
 }
 
 // Blocks nq.. are the tail (slow_kernel.h): they serve the hand-over list inside the same launch.
-template <int DT, int DIM, int S, bool TRAIL = false, int V16 = 0>
-__global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S)) void fast_kernel(const SlowParams P) {
+template <int DT, int DIM, int S, bool TRAIL = false, int V16 = 0, bool WIDE = false>
+__global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S, WIDE)) void fast_kernel(const SlowParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     if (blockIdx.x < P.sp.nq) {
-        fast_walk_one<DT, DIM, S, TRAIL, V16>(P.sp, blockIdx.x, smem);
+        fast_walk_one<DT, DIM, S, TRAIL, V16, WIDE>(P.sp, blockIdx.x, smem);
         walker_done(P);
     } else {
         tail_block<DT>(P, smem);

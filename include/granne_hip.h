@@ -435,7 +435,16 @@ enum {
                                          two-choice buckets of 16-bit entries when the index's ids fit their tags
                                          (32767 ids per bucket), else of 20-bit entries (524286 ids per bucket), the
                                          32-bit table beyond; 2 = the same with 20-bit entries whatever the ids */
-    GRANNE_HIP_OPT_VISITED16_LG = 7   /* log2 of its bucket count (a bucket = 8 entries = 16 bytes): 0 = auto, else 6..12 */
+    GRANNE_HIP_OPT_VISITED16_LG = 7,  /* log2 of its bucket count (a bucket = 8 entries = 16 bytes): 0 = auto, else 6..12 */
+    GRANNE_HIP_OPT_LAST_WALKER = 8    /* read-only (get_option): which kernel the index's last search launch took */
+};
+enum {
+    GRANNE_HIP_WALKER_NONE = 0,          /* no search yet */
+    GRANNE_HIP_WALKER_REGISTER = 1,      /* walk_fast.h: layers of up to 32 ids, max_search up to 4096 (508 for f32 dims other
+                                            than 100 / 200, 252 for int8 rows of 256 / 512 bytes) */
+    GRANNE_HIP_WALKER_REGISTER_WIDE = 2, /* walk_fast.h, two passes per expansion: layers of up to 64 ids, max_search up to 252 */
+    GRANNE_HIP_WALKER_GENERAL = 3,       /* search_kernel.h: everything else up to max_search 256 */
+    GRANNE_HIP_WALKER_EXACT = 4          /* slow_kernel.h: max_search beyond those, GRANNE_HIP_OPT_FORCE_SLOW */
 };
 int granne_hip_index_set_option(granne_hip_index* index, int option, uint64_t value);
 int granne_hip_index_get_option(const granne_hip_index* index, int option, uint64_t* value);

@@ -40,6 +40,10 @@ CASES = [
     (1200, 32, False, 20, 300, True, 128),
     (900, 100, True, 30, 600, False, 64),
     (700, 100, False, 16, 1024, True, 64),
+    # num_neighbors beyond 32: rows of 64 ids on the device, the build's searches on the two-pass register walker
+    (2000, 100, False, 40, 60, True, 256),
+    (1500, 100, True, 63, 100, False, 128),
+    (1200, 24, False, 48, 200, True, 128),
 ]
 
 

@@ -208,3 +208,43 @@ def test_reorder_at_full_size(built):
         assert ix.get_element(i).tobytes() == rows[j].tobytes()
         nb = ix.get_neighbors(i)
         assert nb == sorted(nb) and len(set(nb)) == len(nb) and all(x < N for x in nb)
+
+
+def test_c1_glove_example_shape(oracle):
+    """BASELINE.json configs[0] = examples/glove.rs:46-60: ~400k x 100-d f32, `BuildConfig::default().max_search(10)`,
+    then `index.search(&index.get_element(i), 200, 10)` for i in 0, 134, 5555, 37000 (one query per call, members of the
+    set). GloVe is not in this image: the benchmark's synthetic rows stand in. Through the product: GranneBuilder ->
+    get_index -> get_element -> search (granne_hip_search, host pointers), against the CPU oracle on the same graph."""
+    import torch
+    import granne_amd
+    from granne_amd import _lib
+    lib = _lib.lib()
+    n, dim = 400_000, 100
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    el = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    _lib.check(lib.granne_hip_synth_rows_device(C.c_void_p(el.data_ptr()), SEED + 50, 0, n, dim, 0, sp))
+    _lib.check(lib.granne_hip_normalize_f32_device(C.c_void_p(el.data_ptr()), n, dim, 0, sp))
+    torch.cuda.synchronize()
+    b = granne_amd.GranneBuilder.from_device("angular", el.data_ptr(), n, dim, num_neighbors=30, max_search=10,
+                                             reinsert_elements=True)
+    b.build()
+    assert [b.layer_len(l) for l in range(b.num_layers())] == [8, 119, 1778, 26667, 400000]  # src/index/tests.rs:314-334
+    ix = b.get_index()
+    oix = oracle.Index(el.cpu().numpy(), b.layers())
+    for i in (0, 134, 5555, 37000):
+        x = ix.get_element(i)
+        res = ix.search(x, 200, 10)
+        oi, od, oc, _ = oix.search_batch(x[None], 200, 10)
+        assert len(res) == int(oc[0]) == 10
+        assert [r[0] for r in res] == oi[0].tolist()
+        assert np.array([r[1] for r in res], np.float32).tobytes() == od[0].tobytes()
+        # whenever the walk reaches the member itself it is the nearest, at max(0, 1 - x.x) (a few ulps of 1 at most)
+        if i in [r[0] for r in res]:
+            assert res[0][0] == i and 0.0 <= res[0][1] <= 4e-7
+    # 512 members in one call: same ids as the oracle; most find themselves (the graph was built with max_search 10)
+    mem = np.arange(0, n, n // 512)[:512]
+    q = el[torch.from_numpy(mem).cuda()].cpu().numpy()
+    ids, ds, cnt = ix.search_batch(q, 200, 10)
+    oi, od, oc, _ = oix.search_batch(q, 200, 10)
+    assert (ids == oi).all() and ds.tobytes() == od.tobytes() and (cnt == oc).all()
+    assert (ids[:, 0] == mem).mean() > 0.5

@@ -31,7 +31,7 @@ def prep(oracle, raw, int8):
     return oracle.quantize(raw) if int8 else oracle.normalize_f32(raw)
 
 
-def assert_same(oracle_index, gpu_index, queries, max_search, k, check_stats=True):
+def assert_same(oracle_index, gpu_index, queries, max_search, k, check_stats=True, has_exact_set=True):
     """ids, distance bits, counts and counters against the oracle. An index whose visited-set option is on auto is
     walked in both forms: without a visited set (the default of the register walkers: n_dist counts evaluations,
     conftest.assert_counters) and with the exact tables (every counter the reference's)."""
@@ -51,7 +51,9 @@ def assert_same(oracle_index, gpu_index, queries, max_search, k, check_stats=Tru
             assert ds[i, :c].tobytes() == od[i, :c].tobytes(), (m, i, ds[i, :c], od[i, :c])
             assert (ids[i, c:] == np.iinfo(np.uint64).max).all() and np.isinf(ds[i, c:]).all()
         if check_stats:
-            assert_counters(st, octr, exact=(m in (1, 2, 3)))
+            # (lists of 33 / 65 slots -- max_search 1025..4096 -- keep no visited set whatever the option asks for)
+            # (and has_exact_set=False: graphs of 64-id layers, walked without a set whatever the option asks for)
+            assert_counters(st, octr, exact=(m in (1, 2, 3) and not 1024 < max_search <= 4096 and has_exact_set))
     return ids, ds, cnt
 
 
@@ -299,6 +301,55 @@ def test_wide_rows_and_large_degree(ga, oracle):
     assert_same(oix, gix, q, 3, 3)
 
 
+@pytest.mark.parametrize("case", ["f32_100", "i8_100", "f32_200", "f32_gen48"])
+@pytest.mark.parametrize("nn", [40, 63])
+def test_layers_of_up_to_64_ids_stay_on_the_register_walker(ga, oracle, case, nn):
+    """BuildConfig::num_neighbors beyond 32 (src/index/mod.rs:242-250; the GPU builder takes up to 63): rows of 64 ids on
+    the device, walked by the register walker in two passes per expansion for max_search up to 252."""
+    from granne_amd import _lib
+    int8 = case.startswith("i8")
+    dim = {"f32_100": 100, "i8_100": 100, "f32_200": 200, "f32_gen48": 48}[case]
+    rng = np.random.default_rng(640 + nn)
+    el = prep(oracle, random_floats(rng, 5000, dim), int8)
+    oix = oracle.build_index(el, num_neighbors=nn, max_search=60, n_threads=4)
+    assert max(int((l != oracle.UNUSED).sum(axis=1).max()) for l in oix.layers) > 32
+    gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 64, dim), int8)
+    for ms in (1, 50, 100, 200, 252):
+        assert_same(oix, gix, q, ms, 10, has_exact_set=False)
+        assert gix.get_option(_lib.OPT_LAST_WALKER) == _lib.WALKER_REGISTER_WIDE, ms
+        assert gix.last_slow_count() == 0
+    assert_same(oix, gix, q, 300, 10)  # longer lists of such graphs: the exact walker
+    assert gix.get_option(_lib.OPT_LAST_WALKER) == _lib.WALKER_EXACT
+
+
+def test_rows_of_64_ids_with_every_prefix_length(ga, oracle):
+    """Hand-made rows of 0..64 ids -- exactly 31, 32, 33 and 64 among them, a row that names a node in both halves, one
+    that names it twice in its second half -- on the two-pass register walker (12-d rows: the streamed f32 shape)."""
+    from granne_amd import _lib
+    rng = np.random.default_rng(641)
+    n = 700
+    el = prep(oracle, random_floats(rng, n, 12), False)
+    layer = np.full((n, 64), oracle.UNUSED, np.uint32)
+    for i in range(n):
+        d = [31, 32, 33, 64, 0, 1][i] if i < 6 else int(rng.integers(0, 65))
+        layer[i, :d] = rng.choice(n, d, replace=False)
+    layer[6, :40] = rng.choice(n, 40, replace=False)
+    layer[6, 39] = layer[6, 3]           # the same node in both halves of the row
+    layer[7, :40] = rng.choice(n, 40, replace=False)
+    layer[7, 38] = layer[7, 35]          # twice in the second half
+    top = np.full((12, 64), oracle.UNUSED, np.uint32)
+    for i in range(12):
+        top[i, :5] = rng.choice(12, 5, replace=False)
+    oix = oracle.Index(el, [top, layer])
+    gix = ga.Granne("angular", el, [top, layer])
+    q = prep(oracle, random_floats(rng, 32, 12), False)
+    for ms in (30, 3, 120):
+        assert_same(oix, gix, q, ms, 10, has_exact_set=False)
+        assert gix.get_option(_lib.OPT_LAST_WALKER) == _lib.WALKER_REGISTER_WIDE
+    assert_same(oix, gix, el[:8], 60, 10, has_exact_set=False)  # member queries: the walk starts among the hand-made rows
+
+
 def test_csr_layers_equal_fixed_width_layers(ga, oracle):
     """Layers::Compressed (sorted ids, src/slice_vector/set_vector.rs:40-46) and Layers::FixWidth
     search identically."""
@@ -331,33 +382,53 @@ def test_slow_path_equals_fast_path(ga, oracle):
         assert gix.last_slow_count() == 40
         assert_same(oix, gix, q, 300, 50)
         gix.set_option(_lib.OPT_FORCE_SLOW, 0)
-        assert_same(oix, gix, q, 300, 50)  # the register walker takes max_search up to 1024 (walk_fast.h)
+        assert_same(oix, gix, q, 300, 50)  # the register walker takes max_search up to 4096 (walk_fast.h)
         assert gix.last_slow_count() == 0
-        assert_same(oix, gix, q, 1100, 50)  # beyond that: always the exact global-memory walker
+        assert_same(oix, gix, q, 1100, 50)
+        assert gix.last_slow_count() == 0
+        assert_same(oix, gix, q, 4200, 50)  # beyond that: always the exact global-memory walker
         assert gix.last_slow_count() == 40
 
 
 @pytest.mark.parametrize("int8", [False, True])
-@pytest.mark.parametrize("ms", [61, 64, 125, 128, 253, 300, 512, 1000, 1024])
+@pytest.mark.parametrize("ms", [61, 64, 125, 128, 253, 300, 512, 1000, 1024, 1025, 1500, 2048, 2049, 3000, 4096])
 def test_large_max_search_stays_on_the_register_walker(ga, oracle, int8, ms):
-    """The reference takes any max_search (src/index/mod.rs:1006-1010). Up to 1024 the walk stays in
-    registers/LDS (lists of 64..1024 keys); only distance ties at the list's end may hand a walk over."""
+    """The reference takes any max_search (src/index/mod.rs:1006-1010). Up to 4096 the walk stays in
+    registers/LDS (lists of 64..4160 keys); only distance ties at the list's end may hand a walk over.
+    The long lists (33 / 65 slots: max_search beyond 1024) are walked on 9000 points, more than their lists hold."""
     rng = np.random.default_rng(1000 + ms)
-    el = prep(oracle, random_floats(rng, 4000, 100), int8)
+    el = prep(oracle, random_floats(rng, 4000 if ms <= 1024 else 9000, 100), int8)
     oix = oracle.build_index(el, num_neighbors=30, max_search=40, n_threads=4)
     gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
-    q = prep(oracle, random_floats(rng, 48, 100), int8)
+    q = prep(oracle, random_floats(rng, 48 if ms <= 1024 else 24, 100), int8)
     assert_same(oix, gix, q, ms, 20)
     assert_same(oix, gix, q, ms, ms)
     if not int8:
         assert gix.last_slow_count() == 0
 
 
+def test_long_lists_on_200d_rows_and_with_an_exact_set_requested(ga, oracle):
+    """max_search 1500 / 4096 on 800-byte rows; the long lists keep no visited set whatever OPT_VISITED16 asks for."""
+    from granne_amd import _lib
+    rng = np.random.default_rng(77)
+    el = prep(oracle, random_floats(rng, 6000, 200), False)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=30, n_threads=4)
+    gix = ga.Granne("angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 16, 200), False)
+    for ms in (1500, 4096):
+        assert_same(oix, gix, q, ms, 10, check_stats=False)
+        assert gix.last_slow_count() == 0
+    gix.set_option(_lib.OPT_VISITED16, 3)
+    oi, od, oc, _ = oix.search_batch(q, 2000, 10)
+    ids, ds, cnt = gix.search_batch(q, 2000, 10)
+    assert (ids == oi).all() and ds.tobytes() == od.tobytes() and gix.last_slow_count() == 0
+
+
 def test_max_search_beyond_the_register_lists(ga, oracle):
-    """max_search above 1024 (above 252 for wide int8 rows, 508 for streamed f32 dims) is the exact global-memory
+    """max_search above 4096 (above 252 for wide int8 rows, 508 for streamed f32 dims) is the exact global-memory
     walker's as a whole batch -- its own launch, one block per query up to 32 x OPT_SLOW_BLOCKS. Same results."""
     rng = np.random.default_rng(41)
-    for int8, dim, ms in [(False, 100, 1500), (True, 100, 2048), (True, 200, 300), (False, 50, 600)]:
+    for int8, dim, ms in [(False, 100, 4500), (True, 100, 4097), (True, 200, 300), (False, 50, 600)]:
         el = prep(oracle, random_floats(rng, 5000, dim), int8)
         oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
         gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)

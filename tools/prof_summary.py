@@ -4,11 +4,20 @@ root = sys.argv[1]; out = sys.argv[2]
 lines = []
 # bench.py also walks its timed batches once with the exact visited tables (the counting pass: fast_kernel<.., 1> / <.., 2>);
 # the launches summarised here are the timed form's (fast_kernel<.., 3>: no visited set) whenever the trace holds any
-TIMED = ", 3>("
+import re
+TIMED_RE = re.compile(r"(false|true), [34](, (false|true))?>")  # V16 = 3 / 4: no visited set
+# the launches of interest by their walker count: PROF_WALKERS walker blocks + up to 64 tail blocks, 64 threads each
+# (default: one batch of 1024; round 4's timed shape is --steps x 1024 walkers in one launch, shards 10 x 4096)
+WALKERS = int(os.environ.get("PROF_WALKERS", "1024"))
+GRID_LO, GRID_HI = WALKERS * 64, WALKERS * 64 + 64 * 64
+
+
+def is_timed(n):
+    return TIMED_RE.search(n) is not None
 
 
 def timed_only(names):
-    return any(TIMED in n for n in names)
+    return any(is_timed(n) for n in names)
 # kernel trace
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
@@ -19,8 +28,8 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         agg[r["Kernel_Name"]].append(dur)
         # the benchmark's launches: 1024 walker blocks + the tail blocks (slow_kernel.h), 64 threads each
-        if ("search_kernel" in r["Kernel_Name"] or "fast_kernel" in r["Kernel_Name"]) and 65536 <= int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0)) <= 65536 + 64 * 64:
-            if only3 and TIMED not in r["Kernel_Name"]:
+        if ("search_kernel" in r["Kernel_Name"] or "fast_kernel" in r["Kernel_Name"]) and GRID_LO <= int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0)) <= GRID_HI:
+            if only3 and not is_timed(r["Kernel_Name"]):
                 continue
             bench.append(dur)
     tot = sum(sum(v) for v in agg.values())
@@ -29,7 +38,7 @@ for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recur
         lines.append("%s,%d,%.3f,%.2f,%.2f,%.2f,%.2f" % (k[:100], len(v), sum(v) / 1e3, statistics.mean(v), min(v), max(v), 100 * sum(v) / tot))
     if bench:
         t = bench[3:] if len(bench) > 3 else bench
-        lines.append("# walker launches of the timed steps (grid (1024 + tail) x 64): n=%d mean %.1f us min %.1f us max %.1f us" % (len(t), statistics.mean(t), min(t), max(t)))
+        lines.append("# walker launches of the timed shape (grid (%d + tail) x 64): n=%d mean %.1f us min %.1f us max %.1f us" % (WALKERS, len(t), statistics.mean(t), min(t), max(t)))
 # pmc
 for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -43,9 +52,9 @@ for d in sorted(glob.glob(os.path.join(root, "pmc*"))):
             if "search_kernel" not in r["Kernel_Name"] and "fast_kernel" not in r["Kernel_Name"]:
                 continue
             gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
-            if not (65536 <= gs <= 65536 + 64 * 64):
+            if not (GRID_LO <= gs <= GRID_HI):
                 continue
-            if only3 and TIMED not in r["Kernel_Name"]:
+            if only3 and not is_timed(r["Kernel_Name"]):
                 continue
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in agg.items():
