@@ -120,7 +120,7 @@ def parse():
     ap.add_argument("--no-partitioned", action="store_true", help="WORLD_SIZE > 1: skip the partitioned sub-record")
     ap.add_argument("--force-partitioned", action="store_true", help="take the partitioned sub-record with one rank too (tests)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--sweep-ef", default="50,100,200,400,800,1600,3200", help="ef values of ef_sweep ('' = skip)")
+    ap.add_argument("--sweep-ef", default="50,100,200,400,800,1600,2048,4096", help="ef values of ef_sweep ('' = skip)")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the int8 / secondary / latency sub-records")
     ap.add_argument("--visited-slots", type=int, default=0,
@@ -387,6 +387,26 @@ class Bench:
             step(warmup + i, self.stream)
         torch.cuda.synchronize()
         seq_elapsed = time.perf_counter() - t1
+        # one batch per call again, with up to GRANNE_HIP_SEARCH_DEPTH calls in flight beside the ONE caller stream
+        # (granne_hip_search_begin_device / _end_device: the index's own streams; default hardware queues)
+        depth_ = _glib.SEARCH_DEPTH
+
+        def begin_end(first, count):
+            tickets = []
+            for i in range(count):
+                b = first + i
+                tickets.append(index.search_begin_device(q_ptr[b], nq, ef, k, i_ptr[b], d_ptr[b], c_ptr[b], s_ptr[b], st_ptr, self.stream))
+                if i >= depth_ - 1:
+                    index.search_end_device(tickets[i - depth_ + 1], self.stream)
+            for tk in tickets[max(0, count - depth_ + 1):]:
+                index.search_end_device(tk, self.stream)
+
+        begin_end(0, min(n_batches, 2 * depth_))  # (the index's streams have searched once: their scratch blocks exist)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        begin_end(warmup, steps)
+        torch.cuda.synchronize()
+        be_elapsed = time.perf_counter() - t1
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         kev = [(hip_event(), hip_event()) for _ in range(steps)]
         for i in range(steps):
@@ -445,6 +465,9 @@ class Bench:
             launch_ms, alg_per_launch = mean_ms, alg_per_batch
         return {
             "elapsed": elapsed, "value_local": steps * nq / elapsed, "seq_elapsed": seq_elapsed, "steady": steady,
+            "begin_end": {"value": round(steps * nq / be_elapsed, 1), "ms_per_step": round(be_elapsed / steps * 1e3, 4), "depth": depth_,
+                          "note": "one batch per call, granne_hip_search_begin_device / _end_device: up to %d calls in flight "
+                                  "beside one caller stream (rank-local)" % depth_},
             "ids": ids, "dists": dists, "counts": counts, "status": status, "inflight": inflight, "group": group,
             "calls": len(timed_calls), "slow": slow_n, "spill": spill_n,
             "alg_per_launch": alg_per_launch, "achieved": alg_per_launch / (launch_ms * 1e-3) / 1e9, "launch_ms_mean": launch_ms,
@@ -834,6 +857,7 @@ def run_replica(B, args):
         "sequential": {"value": round(args.steps * nq / m["seq_elapsed"], 1),
                        "ms_per_step": round(m["seq_elapsed"] / args.steps * 1e3, 4),
                        "note": "same K steps, one stream, one batch PER CALL (rank-local)"},
+        "one_batch_calls_in_flight": m["begin_end"],
         "steady": m["steady"],
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
@@ -1003,6 +1027,7 @@ def sub_record(B, args, dtype, data, n, dim, nq, ef, steps, warmup, cpu_batches=
         "inflight_batches": m["inflight"], "batches_per_call": m["group"] if m["inflight"] == 1 else 1,
         "ms_per_step": round(m["elapsed"] / steps * 1e3, 4),
         "sequential": {"value": round(steps * nq / m["seq_elapsed"], 1), "ms_per_step": round(m["seq_elapsed"] / steps * 1e3, 4)},
+        "one_batch_calls_in_flight": m["begin_end"],
         "steady": m["steady"],
         "slow_path_queries": m["slow"], "visited_spill_walks": m["spill"],
         "recall_at_10": round(B.recall(gt, m["ids"][warmup][:rq], k), 4),

@@ -16,6 +16,7 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OVERFLOW, ERR_IO = -1, -2, -3, -4, -5
 OPT_VISITED_SLOTS, OPT_FORCE_SLOW, OPT_SLOW_SLOTS, OPT_SLOW_BLOCKS, OPT_OVERFLOW_SLOTS = 1, 2, 3, 4, 5
 OPT_VISITED16, OPT_VISITED16_LG, OPT_LAST_WALKER = 6, 7, 8
 WALKER_NONE, WALKER_REGISTER, WALKER_REGISTER_WIDE, WALKER_GENERAL, WALKER_EXACT = 0, 1, 2, 3, 4
+SEARCH_DEPTH = 3  # GRANNE_HIP_SEARCH_DEPTH
 SHARDED_OPT_DEPTH, SHARDED_OPT_EXCHANGE = 1, 2
 SHARDED_EXCHANGE_PEER, SHARDED_EXCHANGE_RCCL = 0, 1
 
@@ -65,6 +66,8 @@ SIGNATURES = {
     "granne_hip_search_batch": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp]),
     "granne_hip_search_batch_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]),
     "granne_hip_search_batches_device": (i32, [vp, u32, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]),
+    "granne_hip_search_begin_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, C.POINTER(u64)]),
+    "granne_hip_search_end_device": (i32, [vp, u64, vp]),
     "granne_hip_event_create": (i32, [vp]),
     "granne_hip_event_destroy": (None, [vp]),
     "granne_hip_event_elapsed_ms": (i32, [vp, vp, vp]),

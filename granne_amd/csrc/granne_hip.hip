@@ -130,6 +130,17 @@ struct granne_hip_index {
     std::mutex call_mu;
     std::vector<HostCall*> call_free;
     ScratchCache scratch;
+    // granne_hip_search_begin_device / _end_device: batches in flight on streams of the index's own
+    struct Flight {
+        hipStream_t stream = nullptr;
+        hipEvent_t ready = nullptr, done = nullptr;
+        bool busy = false;
+        uint64_t seq = 0;
+    };
+    std::mutex flight_mu;
+    Flight flights[GRANNE_HIP_SEARCH_DEPTH];
+    uint32_t next_flight = 0;
+    uint64_t next_seq = 1;
 };
 
 static inline uint32_t elem_size(int dtype) { return dtype == GRANNE_HIP_F32 ? 4u : 1u; }
@@ -188,6 +199,12 @@ static void destroy_index(granne_hip_index* ix) {
         if (c->d_buf) (void)hipFree(c->d_buf);
         if (c->h_pin) (void)hipHostFree(c->h_pin);
         delete c;
+    }
+    for (auto& f : ix->flights) {
+        if (f.stream) (void)hipStreamSynchronize(f.stream);
+        if (f.ready) (void)hipEventDestroy(f.ready);
+        if (f.done) (void)hipEventDestroy(f.done);
+        if (f.stream) (void)hipStreamDestroy(f.stream);
     }
     ix->scratch.free_all();
     delete ix;
@@ -1066,6 +1083,59 @@ extern "C" int granne_hip_search_batch_device_timed(const granne_hip_index* ix, 
     return search_launch(&T, d_queries, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors,
                          d_out_ids, d_out_dists, d_out_counts, d_out_stats, d_status, (hipStream_t)stream, nullptr,
                          nullptr, 0, (hipEvent_t)ev_before, (hipEvent_t)ev_after);
+}
+
+// A batch in flight beside the caller's stream. begin: the search is ordered after what `stream` holds (an event), runs on
+// one of the index's own streams, and the call returns a ticket at once; end: `stream` waits for that search. Between
+// the two the caller begins further batches -- the walks of up to GRANNE_HIP_SEARCH_DEPTH batches share the chip, which
+// is what a host with a stream of independent batch-sized requests needs (one launch of 1024 walks is one wave per SIMD).
+extern "C" int granne_hip_search_begin_device(const granne_hip_index* cix, const void* d_queries, uint32_t nq,
+                                              uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
+                                              float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
+                                              uint32_t* d_status, void* stream, uint64_t* out_ticket) {
+    if (!cix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    if (!out_ticket) return fail(GRANNE_HIP_ERR_INVALID, "out_ticket is null");
+    if (max_search == 0) return fail(GRANNE_HIP_ERR_INVALID, "max_search must be > 0 (the reference panics, src/index/mod.rs:1019)");
+    granne_hip_index* ix = const_cast<granne_hip_index*>(cix);
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+    std::lock_guard<std::mutex> lk(ix->flight_mu);
+    const uint32_t fi = ix->next_flight;
+    auto& F = ix->flights[fi];
+    if (F.busy) return fail(GRANNE_HIP_ERR_INVALID, "%d batches are in flight already: end one first", GRANNE_HIP_SEARCH_DEPTH);
+    if (!F.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&F.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&F.ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(F.ready, (hipStream_t)stream));
+    HIP_TRY(hipStreamWaitEvent(F.stream, F.ready, 0));
+    SearchTarget T = target_of(ix);
+    int rc = search_launch(&T, d_queries, (int64_t)ix->dim * elem_size(ix->dtype), nq, max_search, num_neighbors, d_out_ids,
+                           d_out_dists, d_out_counts, d_out_stats, d_status, F.stream, nullptr);
+    if (rc) {
+        (void)hipStreamSynchronize(F.stream); // an error return leaves nothing running
+        return rc;
+    }
+    HIP_TRY(hipEventRecord(F.done, F.stream));
+    F.busy = true;
+    F.seq = ix->next_seq++;
+    ix->next_flight = (fi + 1) % GRANNE_HIP_SEARCH_DEPTH;
+    *out_ticket = (F.seq << 8) | fi;
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_search_end_device(const granne_hip_index* cix, uint64_t ticket, void* stream) {
+    if (!cix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
+    granne_hip_index* ix = const_cast<granne_hip_index*>(cix);
+    std::lock_guard<std::mutex> lk(ix->flight_mu);
+    const uint32_t fi = (uint32_t)(ticket & 0xFF);
+    if (fi >= GRANNE_HIP_SEARCH_DEPTH || !ix->flights[fi].busy || ix->flights[fi].seq != (ticket >> 8))
+        return fail(GRANNE_HIP_ERR_INVALID, "no batch in flight has this ticket");
+    DeviceGuard g(ix->device);
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ix->flights[fi].done, 0));
+    ix->flights[fi].busy = false;
+    return GRANNE_HIP_OK;
 }
 
 // Several batches of `nq` queries in ONE launch: a grid of n_batches x nq walkers, which the dispatcher refills from as

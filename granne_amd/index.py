@@ -279,6 +279,19 @@ class Granne:
                                                      arr(d_stats) if d_stats is not None else None, C.c_void_p(d_status),
                                                      C.c_void_p(stream)))
 
+    def search_begin_device(self, d_queries, nq, max_search, num_elements, d_ids, d_dists, d_counts, d_stats=0, d_status=0,
+                            stream=0):
+        """granne_hip_search_begin_device: the batch runs beside `stream` on a stream of the index; returns the ticket."""
+        t = C.c_uint64(0)
+        check(lib().granne_hip_search_begin_device(self._h, C.c_void_p(d_queries), int(nq), int(max_search), int(num_elements),
+                                                   C.c_void_p(d_ids), C.c_void_p(d_dists), C.c_void_p(d_counts),
+                                                   C.c_void_p(d_stats), C.c_void_p(d_status), C.c_void_p(stream), C.byref(t)))
+        return int(t.value)
+
+    def search_end_device(self, ticket, stream=0):
+        """granne_hip_search_end_device: `stream` continues after the batch of `ticket`."""
+        check(lib().granne_hip_search_end_device(self._h, C.c_uint64(ticket), C.c_void_p(stream)))
+
     def search_batch_device_timed(self, d_queries, nq, max_search, num_elements, d_ids, d_dists, d_counts, d_stats,
                                   d_status, stream, ev_before, ev_after):
         """search_batch_device plus two raw hipEvent_t recorded around the search kernel's dispatch."""

@@ -210,6 +210,56 @@ private:
     std::shared_ptr<granne_hip_index> h_;
 };
 
+// A partitioned index: shard s is a Granne of its own over the elements [offsets[s], offsets[s] + shard.len()) of the
+// whole set -- how the reference's shard helper cuts an element file (src/elements/embeddings/parsing.rs:63-100). A search
+// asks every shard and keeps the best by (distance, global id); ids in the results are global. One host process drives
+// all shards (granne_hip_sharded_*); batches are pipelined inside the library.
+template <class Elements>
+class ShardedGranne {
+public:
+    using Element = typename Elements::Element;
+    ShardedGranne(std::vector<Granne<Elements>> shards, const std::vector<uint64_t>& offsets) : shards_(std::move(shards)) {
+        if (shards_.empty() || shards_.size() != offsets.size()) throw std::runtime_error("need one offset per shard");
+        std::vector<granne_hip_index*> hs;
+        for (auto& s : shards_) hs.push_back(s.raw());
+        granne_hip_sharded* h = nullptr;
+        check(granne_hip_sharded_create(&h, hs.data(), offsets.data(), (uint32_t)hs.size()));
+        h_.reset(h, granne_hip_sharded_destroy); // destroyed before shards_ (declared after it): the handle borrows them
+    }
+    size_t len() const { return granne_hip_sharded_len(h_.get()); }
+    size_t num_shards() const { return granne_hip_sharded_num_shards(h_.get()); }
+    // the exchange step as ONE RCCL all-gather over the shard devices instead of peer copies (librccl by dlopen)
+    void use_rccl_all_gather() { check(granne_hip_sharded_set_option(h_.get(), GRANNE_HIP_SHARDED_OPT_EXCHANGE, GRANNE_HIP_SHARDED_EXCHANGE_RCCL)); }
+    void set_depth(size_t depth) { check(granne_hip_sharded_set_option(h_.get(), GRANNE_HIP_SHARDED_OPT_DEPTH, depth)); }
+
+    std::vector<std::pair<size_t, float>> search(const Element& element, size_t max_search, size_t num_neighbors) const {
+        return search_batches(&element, 1, 1, max_search, num_neighbors)[0];
+    }
+    // n_batches batches of nq queries each (elements: n_batches * nq of them), pipelined inside the library
+    std::vector<std::vector<std::pair<size_t, float>>> search_batches(const Element* elements, size_t n_batches, size_t nq,
+                                                                      size_t max_search, size_t num_neighbors) const {
+        const size_t total = n_batches * nq, dim = granne_hip_index_dim(shards_[0].raw());
+        std::vector<typename decltype(Element::data)::value_type> q(total * dim);
+        for (size_t i = 0; i < total; ++i) {
+            if (elements[i].len() != dim) throw std::runtime_error("query dimension mismatch");
+            std::memcpy(q.data() + i * dim, elements[i].as_slice(), dim * sizeof(q[0]));
+        }
+        std::vector<uint64_t> ids(total * num_neighbors);
+        std::vector<float> ds(total * num_neighbors);
+        std::vector<uint32_t> counts(total);
+        check(granne_hip_sharded_search_batches(h_.get(), q.data(), (uint32_t)n_batches, (uint32_t)nq, (uint32_t)max_search,
+                                                (uint32_t)num_neighbors, ids.data(), ds.data(), counts.data()));
+        std::vector<std::vector<std::pair<size_t, float>>> out(total);
+        for (size_t i = 0; i < total; ++i)
+            for (uint32_t j = 0; j < counts[i]; ++j) out[i].emplace_back((size_t)ids[i * num_neighbors + j], ds[i * num_neighbors + j]);
+        return out;
+    }
+
+private:
+    std::vector<Granne<Elements>> shards_;
+    std::shared_ptr<granne_hip_sharded> h_;
+};
+
 // GranneBuilder (src/index/mod.rs:293-531) + the Builder trait (:303-315)
 template <class Elements>
 class GranneBuilder {

@@ -152,6 +152,18 @@ int granne_hip_search_batches_device(const granne_hip_index* index, uint32_t n_b
                                      float* const* d_out_dists, uint32_t* const* d_out_counts,
                                      uint64_t* const* d_out_stats, uint32_t* d_status, void* stream);
 
+/* granne_hip_search_batch_device in two halves, for a host whose batches arrive one at a time: begin orders the
+ * search after what `stream` holds, runs it on one of the index's own streams and returns a ticket at once; end
+ * makes `stream` wait for that search. Up to GRANNE_HIP_SEARCH_DEPTH batches of an index may be begun and not yet
+ * ended (tickets are ended in any order); their walks share the chip. Arguments as granne_hip_search_batch_device;
+ * the buffers of a batch must stay untouched between its begin and the completion of what follows its end.    */
+#define GRANNE_HIP_SEARCH_DEPTH 3 /* HIP maps streams onto 4 hardware queues by default: the caller's + these */
+int granne_hip_search_begin_device(const granne_hip_index* index, const void* d_queries, uint32_t nq,
+                                   uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
+                                   float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
+                                   uint32_t* d_status, void* stream, uint64_t* out_ticket);
+int granne_hip_search_end_device(const granne_hip_index* index, uint64_t ticket, void* stream);
+
 /* granne_hip_search_batch_device, and two optional hipEvent_t recorded on `stream` immediately
  * before and after the dispatch of the search kernel itself (the call also enqueues a small
  * scratch memset before it and the slow-path kernel after it): lets a caller time the dominant

@@ -4,6 +4,7 @@
 //   with_borrowed_elements (config)     src/index/tests.rs:64-82
 //   incremental build_partial           src/index/tests.rs:134-168
 //   write_and_load                      src/index/tests.rs:337-394
+#include <algorithm>
 #include <cstdio>
 #include <random>
 
@@ -118,6 +119,47 @@ int main(int argc, char** argv) {
         double p1 = verify_search(builder.get_index(), 40);
         std::printf("with_borrowed_elements p1 = %.3f\n", p1);
         REQUIRE(p1 > 0.95);
+    }
+    {   // a partitioned index (src/elements/embeddings/parsing.rs:63-100): three shards of consecutive elements, every
+        // shard asked, best by (distance, global id) -- against the per-shard searches merged here; then the same with
+        // the RCCL all-gather as the exchange step (this process has no PyTorch: the system's librccl comes in by dlopen)
+        const size_t n = 1800, dim = 24, G = 3, per = n / G;
+        auto all = random_vectors<angular::Vectors>(dim, n, [](std::vector<float> v) { return angular::from(std::move(v)); });
+        std::vector<Granne<angular::Vectors>> shards;
+        std::vector<uint64_t> offsets;
+        for (size_t g = 0; g < G; ++g) {
+            angular::Vectors part;
+            for (size_t i = g * per; i < (g + 1) * per; ++i) part.push(all.get_element(i));
+            GranneBuilder<angular::Vectors> b(BuildConfig().num_neighbors(16).max_search(30), part);
+            b.build();
+            shards.push_back(b.get_index());
+            offsets.push_back(g * per);
+        }
+        std::vector<angular::Vector> queries;
+        for (size_t i = 0; i < 40; ++i) queries.push_back(angular::from(random_floats(dim)));
+        std::vector<std::vector<std::pair<size_t, float>>> want(queries.size());
+        for (size_t i = 0; i < queries.size(); ++i) {
+            std::vector<std::pair<float, size_t>> cand;
+            for (size_t g = 0; g < G; ++g)
+                for (auto& r : shards[g].search(queries[i], 40, 5)) cand.emplace_back(r.second, r.first + offsets[g]);
+            std::sort(cand.begin(), cand.end());
+            for (size_t j = 0; j < 5 && j < cand.size(); ++j) want[i].emplace_back(cand[j].second, cand[j].first);
+        }
+        ShardedGranne<angular::Vectors> sharded(shards, offsets);
+        REQUIRE(sharded.len() == n && sharded.num_shards() == G);
+        for (int pass = 0; pass < 2; ++pass) {
+            auto got = sharded.search_batches(queries.data(), 4, 10, 40, 5); // four batches of ten, pipelined
+            REQUIRE(got.size() == queries.size());
+            for (size_t i = 0; i < queries.size(); ++i) {
+                REQUIRE(got[i].size() == want[i].size());
+                for (size_t j = 0; j < got[i].size(); ++j)
+                    REQUIRE(got[i][j].first == want[i][j].first && got[i][j].second == want[i][j].second);
+            }
+            auto one = sharded.search(queries[3], 40, 5);
+            REQUIRE(one.size() == want[3].size() && one[0].first == want[3][0].first);
+            if (pass == 0) sharded.use_rccl_all_gather();
+        }
+        std::printf("sharded: 3 shards, peer copies and RCCL all-gather agree with the merged per-shard searches\n");
     }
     std::printf("ok\n");
     return 0;

@@ -105,6 +105,8 @@ def test_argument_validation_needs_no_device(lib):
     lib.granne_hip_event_destroy(None)  # a no-op
     # round 4: several batches per launch; the partitioned handle's device-pointer and option entries
     assert lib.granne_hip_search_batches_device(None, 1, p, 1, 10, 1, p, p, p, None, None, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_search_begin_device(None, p, 1, 10, 1, p, p, p, None, None, None, None) == _lib.ERR_INVALID
+    assert lib.granne_hip_search_end_device(None, 0, None) == _lib.ERR_INVALID
     assert lib.granne_hip_sharded_search_batch_device(None, p, 1, 10, 1, p, p, p, None, None) == _lib.ERR_INVALID
     assert lib.granne_hip_sharded_begin_device(None, p, 1, 10, 1, p, p, p, None, None, None) == _lib.ERR_INVALID
     assert lib.granne_hip_sharded_end_device(None, 0, None) == _lib.ERR_INVALID

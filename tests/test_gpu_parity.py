@@ -677,6 +677,48 @@ def test_several_batches_in_one_launch(ga, oracle, case, n_batches):
     assert all(int(c.abs().sum().item()) == 0 for c in cnt)
 
 
+def test_begin_end_keeps_batches_in_flight_beside_one_stream(ga, oracle):
+    """granne_hip_search_begin_device / _end_device: up to GRANNE_HIP_SEARCH_DEPTH batches begun and not ended; the
+    caller's stream is ordered after each batch by its end; results are those of plain calls; tickets are checked."""
+    import torch
+    from granne_amd import _lib
+    rng = np.random.default_rng(2800)
+    el = prep(oracle, random_floats(rng, 4000, 100), True)
+    oix = oracle.build_index(el, num_neighbors=16, max_search=20, reinsert_elements=False, n_threads=0)
+    gix = ga.Granne("angular_int", el, oix.layers)
+    nb, nq, D = 8, 96, _lib.SEARCH_DEPTH
+    q = prep(oracle, random_floats(rng, nb * nq, 100), True)
+    oi, od, oc, _ = oix.search_batch(q, 40, 10)
+    dq = torch.from_numpy(q).cuda()
+    ids = torch.zeros((nb, nq, 10), dtype=torch.int64, device="cuda")
+    ds = torch.zeros((nb, nq, 10), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros((nb, nq), dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    tickets = []
+    for b in range(nb):
+        tickets.append(gix.search_begin_device(dq[b * nq:(b + 1) * nq].data_ptr(), nq, 40, 10, ids[b].data_ptr(), ds[b].data_ptr(),
+                                               cnt[b].data_ptr(), 0, 0, s))
+        if b >= D - 1:
+            gix.search_end_device(tickets[b - D + 1], s)
+    with pytest.raises(ga.GranneHipError):
+        gix.search_end_device(tickets[0], s)  # ended already
+    for t in tickets[nb - D + 1:]:
+        gix.search_end_device(t, s)
+    got = ids.clone()  # on the caller's stream: ordered after every batch by its end
+    torch.cuda.synchronize()
+    assert (got.cpu().numpy().reshape(-1, 10).astype(np.uint64) == oi).all()
+    assert ds.cpu().numpy().reshape(-1, 10).tobytes() == od.tobytes()
+    assert (cnt.cpu().numpy().reshape(-1).astype(np.uint32) == oc).all()
+    for _ in range(D):
+        tickets.append(gix.search_begin_device(dq.data_ptr(), nq, 40, 10, ids[0].data_ptr(), ds[0].data_ptr(), cnt[0].data_ptr(), 0, 0, s))
+    with pytest.raises(ga.GranneHipError) as e:  # one more than the depth
+        gix.search_begin_device(dq.data_ptr(), nq, 40, 10, ids[1].data_ptr(), ds[1].data_ptr(), cnt[1].data_ptr(), 0, 0, s)
+    assert e.value.code == _lib.ERR_INVALID
+    for t in tickets[-D:]:
+        gix.search_end_device(t, s)
+    torch.cuda.synchronize()
+
+
 def test_many_streams_take_transient_scratch_blocks(ga, oracle):
     """An index caches one scratch block per stream for 64 streams; further streams search with a block of the
     stream-ordered allocator (no device-wide synchronisation, nothing discarded) and return the same results."""
