@@ -485,12 +485,11 @@ extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uin
         ix->opt_overflow_slots = value;
         return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_VISITED16:
-        if (value > 4) return fail(GRANNE_HIP_ERR_INVALID, "visited16 must be 0 (auto), 1 (32-bit table), 2 (20-bit entries), 3 (16- or 20-bit entries by the ids) or 4 (none)");
+        if (value > 4) return fail(GRANNE_HIP_ERR_INVALID, "the visited-set option must be 0 (auto = none), 1..3 (the exact set) or 4 (none)");
         ix->opt_visited16 = value;
         return GRANNE_HIP_OK;
-    case GRANNE_HIP_OPT_VISITED16_LG:
-        if (value != 0 && (value < V16_MIN_LG || value > 12))
-            return fail(GRANNE_HIP_ERR_INVALID, "visited16 log2(buckets) must be 0 (auto) or in [6, 12]");
+    case GRANNE_HIP_OPT_VISITED16_LG: // (retired with the bucket tables it sized: accepted, ignored)
+        if (value > 12) return fail(GRANNE_HIP_ERR_INVALID, "value out of range");
         ix->opt_visited16_lg = value;
         return GRANNE_HIP_OK;
     default:
@@ -564,7 +563,7 @@ typedef void (*search_fn)(const SlowParams);
 
 // experiment knobs, read once per process
 struct EnvKnobs {
-    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, v16_lg = 0, tail_blocks = -1, touch_max = -1;
+    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, tail_blocks = -1, touch_max = -1;
     EnvKnobs() {
         auto geti = [](const char* name, int dflt) {
             const char* e = getenv(name);
@@ -575,7 +574,6 @@ struct EnvKnobs {
         maxc = geti("GRANNE_HIP_MAXC", 0);
         lds_pad = geti("GRANNE_HIP_LDS_PAD", 0);
         visited = geti("GRANNE_HIP_VISITED", 0); // GRANNE_HIP_OPT_VISITED16's values, where the option says auto
-        v16_lg = geti("GRANNE_HIP_V16_LG", 0); // log2(buckets) of the 16-bit table
         touch_max = geti("GRANNE_HIP_TOUCH_MAX", -1); // launches of up to this many queries touch rows ahead (-1: default)
     }
 };
@@ -608,17 +606,14 @@ constexpr uint32_t FAST_MAX_SEARCH = 4096; // f32 rows of 100 / 200 dims and int
 static uint32_t fast_list_slots(uint32_t ef) {
     return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : ef <= 1024 ? 17u : ef <= 2048 ? 33u : 65u;
 }
-// v16: the form of the visited set (FastWalker's V16): 0 = 32-bit table, 1 = 16-bit entries, 2 = 20-bit entries, 3 = none
+// v16: the form of the visited set (FastWalker's V16): 0 = the exact 32-bit table, 3 = none, 4 = none + rows touched ahead
 template <int DT, int DIM, int S>
 static search_fn pick_fast_v(int v16) {
     if constexpr (S == 1 && !(DT == DT_F32 && DIM == 0) && !(DT == DT_I8 && DIM >= 256)) {
         if (v16 == 4) return fast_kernel<DT, DIM, S, false, 4>; // no visited set + rows touched ahead (few queries)
     }
     if (v16 >= 3) return fast_kernel<DT, DIM, S, false, 3>;
-    if constexpr (!(DT == DT_I8 && DIM >= 256)) { // (wide int8 rows: no 20-bit instantiation)
-        if (v16 == 2) return fast_kernel<DT, DIM, S, false, 2>;
-    }
-    return v16 ? fast_kernel<DT, DIM, S, false, 1> : fast_kernel<DT, DIM, S>;
+    return fast_kernel<DT, DIM, S>;
 }
 template <int DT, int DIM>
 static search_fn pick_fast_s(uint32_t S, bool trail, int v16) {
@@ -694,7 +689,7 @@ static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail
 
 struct LaunchPlan {
     uint32_t visited_slots, upper_slots, maxc, lrow_bytes, stage_bytes, adjspec_bytes, lds_bytes;
-    int v16; // the visited set's front table: 0 = 32-bit open addressing, 1 / 2 = two-choice buckets of 16- / 20-bit entries
+    int v16; // FastWalker's V16: 0 = the exact 32-bit table, 3 = no visited set, 4 = none + rows touched ahead
 };
 
 // LDS plan. The visited table dominates; the f32 stage gets what keeps four walkers per CU
@@ -704,18 +699,10 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
                               bool trail) {
     LaunchPlan P;
     P.v16 = 0;
-    // The register walkers with short lists keep the visited set in 16-bit two-choice buckets (VisitedSet16,
-    // wave_prims.h) whenever the ids fit its tags: nb buckets of 16 bytes hold up to 32767 * nb ids' worth of id space
-    // and ~5.8 * nb ids before the first one spills (two-choice, 8 entries per bucket). A walk visits ~40 x
-    // max_search nodes on 10M uniform points: nb = 8 * max_search rounded up to a power of two -- 512 buckets =
-    // 8 KB at max_search 50 (the 32-bit table: 16 KB), so twice the walkers fit a CU's LDS.
-    // Id spaces beyond the 16-bit entries' tags (32767 ids per bucket: 125M ids would need 64 KB) take 20-bit entries
-    // (524286 ids per bucket, six entries per bucket instead of eight); wide int8 rows have no 20-bit instantiation.
-    // Lists of up to 256 keys walk without a visited set (VisitedNone, wave_prims.h: the list itself is searched for a
-    // candidate's id): no table in LDS, only the query's staging area and what a tail block needs.
-    // Measured against the exact tables below (10M x 100-d): equal to 5 % faster per launch at max_search
-    // 50, 3-4 % slower at 100, 17-31 % faster at 200 with 4096 queries, 30-40 % faster at 400-800; with batches in
-    // flight never slower and up to twice as fast -- no LDS bounds the walkers per CU, nothing spills.
+    // The register walkers walk without a visited set by default (VisitedNone, wave_prims.h: the list itself is searched for
+    // a candidate's id): no table in LDS, only the query's staging area and what a tail block needs, so the registers
+    // alone bound the walkers per CU. GRANNE_HIP_OPT_VISITED16 = 1..3 switches the exact set on (a 32-bit open-addressing
+    // table in LDS + a global overflow table): n_dist is then the reference's count of distinct evaluated nodes.
     const int vmode = ix->opt_visited16 ? ix->opt_visited16 : knobs().visited;
     const bool none = vmode == 4 || vmode == 0;
     const bool longest = fastS >= 33 || fast_wide(ix); // (lists of 33 / 65 slots, and 64-id layers: instantiated without a set only, whatever the options say)
@@ -733,36 +720,6 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         const uint32_t least = lds_query_bytes(ix->row_bytes) + 64u * 8u; // int8 query staging; a tail block (slow_kernel.h)
         if (P.lds_bytes < least) P.lds_bytes = least;
         return P;
-    }
-    if (fastS >= 1 && fastS <= 4 && !trail && vmode != 1 && !ix->opt_visited_slots) {
-        uint32_t lg = V16_MIN_LG;
-        while ((1u << lg) < ef * 8u) ++lg;
-        // big launches keep more walkers resident with a smaller table and let the largest walks spill
-        const uint32_t lg_cap = nq >= 2048 ? 10u : 11u;
-        if (lg > lg_cap) lg = lg_cap;
-        if (knobs().v16_lg) lg = (uint32_t)knobs().v16_lg;
-        if (ix->opt_visited16_lg) lg = (uint32_t)ix->opt_visited16_lg;
-        if (lg > 12) lg = 12;
-        const bool wide_i8 = ix->dtype == GRANNE_HIP_I8 && ix->row_bytes != 128;
-        int kind = 0;
-        uint32_t lg_ids = v16_lg_for_ids(ix->n_elements, V16_TAG_MAX);
-        if (lg_ids <= lg && vmode != 2) {
-            kind = 1;
-        } else if (!wide_i8) {
-            lg_ids = v16_lg_for_ids(ix->n_elements, V20_TAG_MAX);
-            if (lg_ids <= lg) kind = 2;
-        }
-        if (kind) {
-            P.v16 = kind;
-            P.visited_slots = lg;
-            P.upper_slots = lg_ids; // upper layers: the smallest table whose tags hold the ids (<= lg)
-            P.maxc = 0;
-            P.lrow_bytes = 16;
-            P.stage_bytes = 0;
-            P.adjspec_bytes = 0;
-            P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, 4u << lg);
-            return P;
-        }
     }
     // The front table must hold the walk's visited ids (~40 x max_search on 10M uniform points) below its 7/8
     // load limit: 4096 slots at max_search 50. (Tables of 3 * 2^k slots are accepted as an option; 3072 slots --

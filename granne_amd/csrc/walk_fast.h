@@ -15,8 +15,8 @@
 //       and is taken once per query (same operation on the same input: same bits).
 // All row loads of an expansion are issued from the neighbor ids alone. The walker keeps NO visited set by default
 // (V16 = 3; wave_prims.h VisitedNone says why the results stay the reference's): every neighbor is evaluated and a
-// candidate that passed the filter is looked up in the list before it is inserted. With an exact set switched on
-// (V16 = 0 / 1 / 2: LDS front table + global overflow) its look-ups run under the row loads.
+// candidate that passed the filter is looked up in the list before it is inserted. With the exact set switched on
+// (V16 = 0: LDS front table + global overflow) its look-ups run under the row loads.
 //
 // The reference's two heaps (`res`: the max_search best popped nodes, `pq`: the unbounded
 // candidate queue, mod.rs:1006-1007) are ONE ascending list of 64*S keys in registers, each key
@@ -268,9 +268,8 @@ __host__ __device__ inline uint32_t fast_query_bytes(bool i8, bool gen, uint32_t
 }
 
 // V16: the form of the visited set. 3 = none (the default; 4 = none + rows touched ahead, for launches of a few
-// queries); the exact sets: 0 = 32-bit open addressing (VisitedSet); 1 = 16-bit entries in two-choice buckets (half the
-// LDS; id spaces of up to 32767 ids per bucket); 2 = 20-bit entries (three eighths more LDS per id than 16-bit ones,
-// id spaces of up to 524286 ids per bucket). wave_prims.h; the host picks (plan_launch, granne_hip.hip).
+// queries); 0 = the exact set: 32-bit open addressing in LDS + a global overflow table (VisitedSet, wave_prims.h) --
+// kept so that n_dist can be counted the way the reference counts it. The host picks (plan_launch, granne_hip.hip).
 // WIDE: layers of up to 64 ids per node (graphs built with num_neighbors 33..63): an expansion takes the row's ids in two
 // passes of 32 pairs -- rows, distances, filter, insert for ids 0..31, then for ids 32..63 when the row goes that far.
 // `res` does not change within an expansion (mod.rs:1025-1033 pushes to pq only), so the reference's filter gives every
@@ -309,9 +308,8 @@ struct FastWalker {
     // With a thousand walks in a launch the same touches cost throughput and are not compiled in.
     static constexpr bool TOUCH = V16 == 4;
     static_assert(!WIDE || V16 == 3, "layers of 64 ids: walked without a visited set only");
-    typename std::conditional<V16 == 0, VisitedSet,
-        typename std::conditional<V16 == 1, VisitedSet16,
-            typename std::conditional<V16 == 2, VisitedSet20, VisitedNone>::type>::type>::type vis;
+    static_assert(V16 == 0 || V16 == 3 || V16 == 4, "the exact 32-bit table, or no visited set (4: + rows touched ahead)");
+    typename std::conditional<V16 == 0, VisitedSet, VisitedNone>::type vis;
     WalkList<S> L;
     WalkStats st;
     bool bail;
@@ -652,12 +650,7 @@ struct FastWalker {
     __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
                                                  bool d0_known = false, float d0_value = 0.0f) {
         PT_RESET();
-        if constexpr (NOVIS) {
-        } else if constexpr (V16 != 0) { // `slots` is log2(buckets) here (the host sizes it for the ids' tags: SearchParams)
-            vis.reset(vis_tab, slots, lane);
-        } else {
-            vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
-        }
+        if constexpr (!NOVIS) vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
         L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;
@@ -669,9 +662,7 @@ struct FastWalker {
         // to the same query was evaluated there: the same operations on the same inputs give the same bits, so
         // the value is reused (the evaluation still counts) and the layer starts one memory round trip earlier.
         pre_nb = adjg[(size_t)entrypoint * W + R]; // get_neighbors(entrypoint): needed right after
-        if constexpr (NOVIS) {}
-        else if constexpr (V16 != 0) vis.insert(entrypoint, R == 0u, h, p.ovf, lane, bail);
-        else vis.insert(entrypoint, lane == 0, p.ovf);
+        if constexpr (!NOVIS) vis.insert(entrypoint, lane == 0, p.ovf);
         vis.count = 1;
         st.n_dist += 1;
         if (d0_known) {
@@ -739,7 +730,6 @@ struct FastWalker {
             // visited set under the loads, then the distances (mod.rs:1026-1027)
             bool fresh;
             if constexpr (NOVIS) fresh = h == 0u && R < nvalid; // every neighbor is evaluated
-            else if constexpr (V16 != 0) fresh = vis.insert(nb, R < nvalid, h, p.ovf, lane, bail) && h == 0u;
             else fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
             PT_MARK(2); // visited set (under the loads)
             PT_WAIT_VM();

@@ -293,255 +293,11 @@ struct VisitedSet {
     }
 };
 
-// ---- the same exact set in HALF the LDS: 16-bit entries, two-choice buckets ----------------------------------
-// For id spaces of at most 32767 * nb ids (nb = number of buckets, a power of two): 10M ids fit nb = 512, i.e. an
-// 8 KB table instead of 16 KB -- LDS is what bounds the walkers per CU.
-//   id = q * nb + r.   tag = q + 1 (1..32767, so 0 can mean "empty").   Home bucket b1 = r ^ scramble(q), second
-//   bucket b2 = b1 ^ g(q) with g odd (never b1).   (bucket, choice bit, tag) names the id exactly: q from the tag, r
-//   from the bucket and q -- nothing is hashed away, the set is exact.
-//   A bucket is 8 entries = 16 bytes = one ds_read_b128; entry = choice << 15 | tag; buckets fill front to back.
-// The two lanes of a pair (walk_fast.h: both hold the same neighbor id) take one bucket each: one read, a packed
-// 16-bit compare of the eight entries, the fill count; one DPP exchange decides present / which bucket is emptier
-// (ties: b1); the lane that owns the chosen bucket claims the first free entry with ONE ds_cmpst on its 32-bit word.
-// A claim fails only when another lane of the same expansion took that word in the same round (two ids sharing a
-// bucket: ~0.4 pairs per expansion); those pairs go round again. Two-choice placement keeps every bucket below 8
-// entries up to ~0.72 load (2,930 ids in 512 buckets, simulated: tools/model_visited16.py); an id that finds both
-// of its buckets full goes to the walk's overflow table in global memory, exactly as with the 32-bit table, and is
-// looked up there by every later pair that finds both of its buckets full. Buckets never lose entries, so an id is
-// in the set iff it is in b1, in b2, or (both full) in the overflow table.
-//
-// Id spaces beyond 32767 * nb (125M ids would need 4096 buckets = 64 KB) keep the 32-bit table. Measured and dropped
-// (round 3): 15-bit tags as a filter with the entries' full ids mirrored in the walk's global region and read back on a
-// tag match. 97 % of a walk's lookups find no matching tag and never leave LDS, but every insert then costs a scattered
-// 4-byte store (a read-modify-write at the memory side: as many transactions as the int8 row gather itself) whose
-// acknowledgement every later vmcnt wait also waits for: 0.28 ms per launch against 0.185 ms with the 32-bit table on
-// 40M int8 rows at max_search 50, no better than it at max_search 200.
-__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_min1_u16(uint32_t a) { // min(each half, 1): 1 where the half is non-zero
-    uint32_t r;
-    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
-    return r;
-}
-// The lane id, computed where it is used. (Table wipes run once per layer; the compiler otherwise keeps their loop
-// counters -- lane, lane + 64 -- alive through the whole walk, and under the f32 walkers' register pressure spills them.)
-__device__ __forceinline__ uint32_t lane_id_here() {
-    uint32_t l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l));
-    return l;
-}
-__device__ __forceinline__ uint32_t dpp_pair_swap(uint32_t v) { // the other lane of the pair (lane ^ 1)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);
-}
-
-constexpr uint32_t V16_TAG_MAX = 32767u;   // 16-bit entries: tags 1..32767
-constexpr uint32_t V20_TAG_MAX = 524287u;  // 20-bit entries: tags 1..524287
-constexpr uint32_t V16_MIN_LG = 6;         // smallest table: 64 buckets = 1 KB (upper layers)
-__host__ __device__ inline uint32_t v16_lg_for_ids(uint64_t n_ids, uint32_t tag_max = V16_TAG_MAX) { // smallest log2(nb) whose tags hold n_ids ids
-    uint32_t lg = V16_MIN_LG;
-    while (((uint64_t)tag_max << lg) < n_ids && lg < 31) ++lg;
-    return lg;
-}
-
-// TB = bits of an entry: 16 (8 entries per bucket, tags of 15 bits: up to 32767 ids per bucket) or 20 (6 entries per bucket
-// -- three per 64-bit half, claimed with a 64-bit ds_cmpst -- tags of 19 bits: up to 524286 ids per bucket, which puts
-// the 125M-id shards of BASELINE.json's configs[4] into a 16 KB table). Everything but the probe is shared.
-template <int TB>
-struct VisitedSetB {
-    static_assert(TB == 16 || TB == 20, "entries of 16 or 20 bits");
-    static constexpr uint32_t PER_BUCKET = TB == 16 ? 8u : 6u;
-    uint32_t* tab;     // LDS: nb buckets of 4 words
-    uint32_t lg;       // log2(nb)
-    static constexpr uint32_t NONE = 0xFFFFFFFFu;
-    uint32_t region;   // overflow region borrowed from the pool, or NONE
-    uint32_t ocount;   // ids in the overflow table
-    uint32_t count;    // statistics only
-#if GRANNE_HIP_PHASE_TIMERS
-    uint32_t pt_rounds = 0;
-#endif
-
-    __device__ __forceinline__ void init_walker() {
-        region = NONE;
-        ocount = 0;
-    }
-    __device__ __forceinline__ uint32_t acquire(const OverflowPool& pool, uint32_t lane) {
-        uint32_t got = NONE;
-        if (pool.slots != 0 && lane == 0) {
-            uint32_t r = (blockIdx.x * 0x9E3779B1u) % pool.regions;
-            for (uint32_t tries = 0; tries < pool.regions; ++tries) {
-                if (atomicCAS(&pool.state[r], 0u, 1u) == 0u) { got = r; break; }
-                r = (r + 1 == pool.regions) ? 0u : r + 1;
-            }
-        }
-        return (uint32_t)__shfl((int)got, 0, 64);
-    }
-    __device__ __forceinline__ void reset(uint32_t* lds, uint32_t lg_, uint32_t lane) {
-        tab = lds;
-        lg = lg_;
-        count = 0;
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        uint4* t4 = reinterpret_cast<uint4*>(lds);
-        (void)lane;
-        for (uint32_t i = lane_id_here(); i < (1u << lg_); i += 64) t4[i] = z;
-        if (region != NONE && ocount != 0) ocount = NONE; // a borrowed region is wiped before it is used again
-    }
-    __device__ __forceinline__ void added(uint32_t) {}
-
-    // One probe of the pair's two buckets, written without branches (bit operations and selects; only the claim itself
-    // runs under a mask): every lane executes it, lanes without `pending` change nothing. A lane with `pending` looks the
-    // id up and, when it is absent and a bucket has room, claims the bucket's first free entry. Outcome per pair (the
-    // same in both of its lanes):
-    //   fresh     the id was inserted (it was not in the set)
-    //   both_full it is in neither bucket and both are full: the overflow table decides
-    // `pending` stays set for a pair that lost its entry to another pair of the same expansion; it goes round again (and
-    // finds the id present if that other pair held the same id: a row that lists a neighbor twice).
-    __device__ __forceinline__ void probe16(uint32_t h, uint4* slot4, uint32_t entry, bool& pending, bool& fresh, bool& both_full) {
-        const uint4 w = *slot4;
-        const uint32_t pat = entry | (entry << 16);
-        const uint32_t m = pk_min_u16(pk_min_u16(w.x ^ pat, w.y ^ pat), pk_min_u16(w.z ^ pat, w.w ^ pat));
-        const uint32_t match = (uint32_t)((m & 0xFFFFu) == 0u) | (uint32_t)(m < 0x10000u);
-        const uint32_t c2 = pk_add_u16(pk_add_u16(pk_min1_u16(w.x), pk_min1_u16(w.y)),
-                                       pk_add_u16(pk_min1_u16(w.z), pk_min1_u16(w.w)));
-        const uint32_t cnt = (c2 & 0xFFFFu) + (c2 >> 16);
-        // one exchange: fill count in the low bits, "the tag is here" above them
-        const uint32_t other = dpp_pair_swap(cnt | (match << 8));
-        const uint32_t cnt_o = other & 0xFFu;
-        const bool present = (match | (other >> 8)) != 0u; // the tag names the id: it is in the set
-        const bool full2 = (cnt >= 8u) & (cnt_o >= 8u);
-        // this lane's bucket is the emptier one (ties: b1): it claims the bucket's first free entry
-        const bool mine_emptier = h ? (cnt < cnt_o) : (cnt <= cnt_o);
-        const bool claim = pending & !present & !full2 & mine_emptier;
-        const uint32_t wi = cnt >> 1;
-        const uint32_t old = wi == 0u ? w.x : wi == 1u ? w.y : wi == 2u ? w.z : w.w;
-        uint32_t ok = 0u;
-        if (claim) {
-            const uint32_t got = atomicCAS(reinterpret_cast<uint32_t*>(slot4) + (wi & 3u), old, old | (entry << ((cnt & 1u) * 16u)));
-            ok = got == old ? 1u : 0u;
-        }
-        const bool okp = (ok | dpp_pair_swap(ok)) != 0u;
-        fresh = fresh | (pending & okp);
-        both_full = both_full | (pending & !present & full2);
-        pending = pending & !present & !full2 & !okp;
-    }
-
-    // the same with 20-bit entries: a bucket is two 64-bit halves of three entries each (bits 0-19, 20-39, 40-59)
-    __device__ __forceinline__ void probe20(uint32_t h, uint4* slot4, uint32_t entry, bool& pending, bool& fresh, bool& both_full) {
-        const uint4 w = *slot4;
-        const uint32_t M = 0xFFFFFu;
-        const uint32_t f0 = w.x & M, f1 = __builtin_amdgcn_alignbit(w.y, w.x, 20) & M, f2 = (w.y >> 8) & M;
-        const uint32_t f3 = w.z & M, f4 = __builtin_amdgcn_alignbit(w.w, w.z, 20) & M, f5 = (w.w >> 8) & M;
-        const uint32_t match = (uint32_t)(f0 == entry) | (uint32_t)(f1 == entry) | (uint32_t)(f2 == entry) |
-                               (uint32_t)(f3 == entry) | (uint32_t)(f4 == entry) | (uint32_t)(f5 == entry);
-        const uint32_t cnt = (uint32_t)(f0 != 0u) + (uint32_t)(f1 != 0u) + (uint32_t)(f2 != 0u) + (uint32_t)(f3 != 0u) +
-                             (uint32_t)(f4 != 0u) + (uint32_t)(f5 != 0u); // entries fill front to back
-        const uint32_t other = dpp_pair_swap(cnt | (match << 8));
-        const uint32_t cnt_o = other & 0xFFu;
-        const bool present = (match | (other >> 8)) != 0u;
-        const bool full2 = (cnt >= 6u) & (cnt_o >= 6u);
-        const bool mine_emptier = h ? (cnt < cnt_o) : (cnt <= cnt_o);
-        const bool claim = pending & !present & !full2 & mine_emptier;
-        const bool hi = cnt >= 3u;
-        const uint32_t pos = hi ? cnt - 3u : cnt;
-        const uint64_t old = hi ? (((uint64_t)w.w << 32) | w.z) : (((uint64_t)w.y << 32) | w.x);
-        uint32_t ok = 0u;
-        if (claim) {
-            unsigned long long* half = reinterpret_cast<unsigned long long*>(slot4) + (hi ? 1 : 0);
-            const unsigned long long got = atomicCAS(half, (unsigned long long)old, (unsigned long long)(old | ((uint64_t)entry << (pos * 20u))));
-            ok = got == old ? 1u : 0u;
-        }
-        const bool okp = (ok | dpp_pair_swap(ok)) != 0u;
-        fresh = fresh | (pending & okp);
-        both_full = both_full | (pending & !present & full2);
-        pending = pending & !present & !full2 & !okp;
-    }
-    __device__ __forceinline__ void probe(uint32_t h, uint4* slot4, uint32_t entry, bool& pending, bool& fresh, bool& both_full) {
-        if constexpr (TB == 16) probe16(h, slot4, entry, pending, fresh, both_full);
-        else probe20(h, slot4, entry, pending, fresh, both_full);
-    }
-
-    // HashSet::insert for the id both lanes of a pair hold (h = lane & 1). `active` is the same in both lanes.
-    // Returns true in BOTH lanes iff the id was not present.
-    __device__ __forceinline__ bool insert(uint32_t id, bool active, uint32_t h, const OverflowPool& pool, uint32_t lane,
-                                           bool& bail) {
-        const uint32_t sh = 32u - lg;
-        const uint32_t q = id >> lg;
-        const uint32_t b1 = (id ^ ((q * 0x9E3779B1u) >> sh)) & ((1u << lg) - 1u);
-        const uint32_t mine = h ? (b1 ^ (((q * 0x85EBCA6Bu) >> sh) | 1u)) : b1;
-        // tag: q + 1 (never 0: 0 is "empty"); the host sizes the table so that it fits the entry's tag bits
-        const uint32_t entry = (q + 1u) | (h << (TB - 1));
-        uint4* slot4 = reinterpret_cast<uint4*>(tab) + mine;
-        bool pending = active, fresh = false, both_full = false;
-#if GRANNE_HIP_PHASE_TIMERS
-        uint32_t r_ = 0;
-#endif
-        while (wave_ballot(pending)) {
-#if GRANNE_HIP_PHASE_TIMERS
-            r_ += 1;
-#endif
-            probe(h, slot4, entry, pending, fresh, both_full);
-        }
-#if GRANNE_HIP_PHASE_TIMERS
-        pt_rounds += r_;
-#endif
-        if (wave_ballot(both_full)) { // rare: the walk outgrew its table's two-choice capacity
-            if (region == NONE) {
-                region = acquire(pool, lane);
-                ocount = NONE;
-            }
-            if (region == NONE) {
-                bail = true; // no overflow configured or none left: the exact global-memory walker takes the query
-                return false;
-            }
-            uint32_t* otab = pool.tables + (size_t)region * pool.stride;
-            if (ocount == NONE) { // first use (in this layer): wipe
-                if (lane == 0 && pool.spilled) atomicAdd(pool.spilled, 1u);
-                const uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
-                uint4* t4 = reinterpret_cast<uint4*>(otab);
-                for (uint32_t i = lane_id_here(); i < (pool.slots >> 2); i += 64) t4[i] = e;
-                __threadfence();
-                ocount = 0;
-            }
-            bool ofresh = false;
-            if (both_full && h == 0u) {
-                const uint32_t omask = pool.slots - 1;
-                const uint32_t ost = VisitedSet::step(id);
-                uint32_t slot = (VisitedSet::hash(id) >> 3) & omask;
-                for (;;) {
-                    const uint32_t old = atomicCAS(&otab[slot], ID_EMPTY, id);
-                    if (old == ID_EMPTY) { ofresh = true; break; }
-                    if (old == id) break;
-                    slot = (slot + ost) & omask;
-                }
-            }
-            const uint64_t om = wave_ballot(ofresh);
-            ocount += (uint32_t)__popcll(om);
-            if (((om | (om << 1)) >> lane) & 1ull) fresh = true; // both lanes of the pair
-        }
-        return fresh;
-    }
-    // after an expansion: false when the overflow table itself is full (75 % load)
-    __device__ __forceinline__ bool make_room(const OverflowPool& pool, uint32_t) {
-        return region == NONE || ocount == NONE || ocount <= pool.slots - (pool.slots >> 2) - 72u;
-    }
-    __device__ __forceinline__ void release(const OverflowPool& pool, uint32_t lane) {
-        if (region != NONE) {
-            __threadfence();
-            if (lane == 0) atomicExch(&pool.state[region], 0u);
-            region = NONE;
-        }
-    }
-};
-
-typedef VisitedSetB<16> VisitedSet16;
-typedef VisitedSetB<20> VisitedSet20;
+// (Rounds 3a-3 also carried two-choice bucket tables of 16- and 20-bit entries -- half the LDS per id, exact through
+//  (bucket, choice bit, tag) -- as a second and third form of this set. They bought residency while a set was the default;
+//  with no set at all as the default (VisitedNone below) the only job left for an exact set is to count the reference's
+//  n_dist for bench.py and the tests, which the 32-bit table above does for every list length and id range. Retired in
+//  round 4; profiles/r3a_* keep their measurements.)
 
 // No visited set at all (the register walkers with lists of up to 256 keys: FastWalker<.., V16 = 3>).
 // The reference's HashSet (mod.rs:1008,1016,1026) keeps a node from being evaluated twice; in a walk whose lanes

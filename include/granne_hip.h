@@ -119,8 +119,8 @@ int granne_hip_index_get_element(const granne_hip_index* index, uint64_t idx, vo
  *                           EVALUATED: by default the walkers keep no visited set and evaluate a
  *                           neighbor they have seen before again (same result, ~3 % more rows on
  *                           uniform data), so [0] >= the reference's dist_to_element calls
- *                           (mod.rs:1012,1027); with an exact visited set switched on
- *                           (GRANNE_HIP_OPT_VISITED16 = 1, 2 or 3) [0] IS the reference's count.
+ *                           (mod.rs:1012,1027); with the exact visited set switched on
+ *                           (GRANNE_HIP_OPT_VISITED16 = 1..3) [0] IS the reference's count.
  * Thread-safe on a shared index.                                                              */
 int granne_hip_search_batch(const granne_hip_index* index, const void* queries, uint32_t nq,
                             uint32_t max_search, uint32_t num_neighbors, uint64_t* out_ids,
@@ -442,12 +442,11 @@ enum {
                                          0 = auto = 4 = NONE -- every neighbor is evaluated and the list itself is
                                          searched for a candidate's id; the results are the reference's, the n_dist
                                          counter counts evaluations instead of distinct nodes
-                                         (granne_amd/csrc/wave_prims.h, VisitedNone). The exact sets, with which n_dist
-                                         is the reference's count: 1 = the 32-bit table; 3 = for max_search <= 252
-                                         two-choice buckets of 16-bit entries when the index's ids fit their tags
-                                         (32767 ids per bucket), else of 20-bit entries (524286 ids per bucket), the
-                                         32-bit table beyond; 2 = the same with 20-bit entries whatever the ids */
-    GRANNE_HIP_OPT_VISITED16_LG = 7,  /* log2 of its bucket count (a bucket = 8 entries = 16 bytes): 0 = auto, else 6..12 */
+                                         (granne_amd/csrc/wave_prims.h, VisitedNone). 1, 2, 3 = the EXACT set (a 32-bit
+                                         open-addressing table in LDS + a global overflow table): n_dist is then the
+                                         reference's count. (Rounds 3a-3 distinguished three forms of the exact set; one
+                                         is left.) Lists beyond 1024 keys and 64-id layers always walk without a set */
+    GRANNE_HIP_OPT_VISITED16_LG = 7,  /* retired with the bucket tables it sized: accepted (0..12), ignored */
     GRANNE_HIP_OPT_LAST_WALKER = 8    /* read-only (get_option): which kernel the index's last search launch took */
 };
 enum {
