@@ -145,8 +145,28 @@ struct WalkList : SortedList<S> {
         for (int s = 0; s < S; ++s) hit = hit || (((uint32_t)key[s]) >> 1) == id;
         return wave_ballot(hit) != 0;
     }
+    // Lists of 33 / 65 slots (LONG): everything before `fu_lb` is expanded -- a lower bound of the first unexpanded entry's
+    // position, kept across expansions (mark_expanded never breaks it; a merge lowers it to the smallest place a
+    // candidate took) -- so the search reads the mirror from there, 64 keys at a time, instead of asking every slot.
+    static constexpr bool LONG = S >= 33;
+    mutable uint32_t fu_lb;
     // position of the first entry whose expanded flag is clear (KEY_INF has it set)
     __device__ __forceinline__ bool first_unexpanded(uint32_t& pos) const {
+        if constexpr (LONG) {
+            const uint32_t lane = threadIdx.x;
+            for (;;) {
+                if (fu_lb >= CAP) return false;
+                const uint32_t e = fu_lb + lane;
+                const uint64_t v = mir[e < CAP ? e : CAP - 1u];
+                const uint64_t um = wave_ballot(e < CAP && (((uint32_t)v) & 1u) == 0u);
+                if (um) {
+                    fu_lb += (uint32_t)__builtin_ctzll(um);
+                    pos = fu_lb;
+                    return true;
+                }
+                fu_lb += 64u;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint64_t um = wave_ballot((((uint32_t)key[s]) & 1u) == 0u);
@@ -212,6 +232,7 @@ struct WalkList : SortedList<S> {
     }
     __device__ __forceinline__ void init_list(uint64_t* mirror, uint32_t lane) {
         mir = mirror;
+        fu_lb = 0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             key[s] = KEY_INF;
@@ -575,6 +596,86 @@ struct FastWalker {
         }
     }
 
+    // ---- lists of 33 / 65 slots (max_search 1025..4096) -----------------------------------------------------------------
+    // The bulk merge above costs (slots x candidates): every entry is compared with every candidate, every candidate is
+    // looked up in every slot. Long lists rank a candidate by a binary search in the list's LDS mirror instead (which holds
+    // the list exactly): the number of entries below its key -- and the entry it stops at is the candidate's own node
+    // when the list holds it already (same distance, same id: the same key up to the expanded flag), so the look-up of
+    // drop_known falls out of the same search. Entries then move up by the number of candidates whose rank is at most their
+    // position: uniform per slot (a running count) except in the few slots a candidate's rank falls into.
+    static constexpr bool LONG = WalkList<S>::LONG;
+    static constexpr int LONG_STEPS = CAP >= 4096u ? 13 : 12; // lower_bound over CAP + 1 outcomes: 2112 -> 12, 4160 -> 13
+
+    // Which candidates remain (the list holds some already; a row may name a node twice), and each one's rank in the list.
+    __device__ __forceinline__ uint64_t rank_long(bool& pass, uint64_t ck, uint32_t& rank) const {
+        uint32_t lo = 0, hi = CAP;
+#pragma unroll 1
+        for (int t = 0; t < LONG_STEPS; ++t) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint64_t v = mslot[mid < CAP ? mid : CAP - 1u];
+            const bool go = lo < hi, less = v < ck;
+            lo = (go && less) ? mid + 1u : lo;
+            hi = (go && !less) ? mid : hi;
+        }
+        rank = lo;
+        const uint64_t at = mslot[lo < CAP ? lo : CAP - 1u];
+        pass = pass && !(lo < CAP && (at | 1ull) == (ck | 1ull)); // in the list already, expanded or not
+        uint64_t pm = wave_ballot(pass);
+        for (uint64_t it = pm; it; it &= it - 1) { // the second of two lanes with one key leaves
+            const uint32_t j = (uint32_t)__builtin_ctzll(it);
+            const uint64_t K = readlane64(ck, j);
+            const uint64_t twin = wave_ballot(pass && ck == K && lane > j);
+            if (twin) {
+                pass = pass && !((twin >> lane) & 1ull);
+                pm &= ~twin;
+                it &= ~twin;
+            }
+        }
+        return pm;
+    }
+
+    // pq.push of the candidates in pm (pass: this lane is one of them), ranks from rank_long.
+    __device__ __forceinline__ void place_long(uint64_t pm, bool pass, uint64_t ck, uint32_t rank, uint32_t ef) {
+        const uint32_t m = (uint32_t)__popcll(pm);
+        if (m == 0) return;
+        uint32_t mypos = rank; // + the candidates below mine
+        for (uint64_t it = pm; it; it &= it - 1) {
+            const uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(it));
+            mypos += (pass && K < ck) ? 1u : 0u;
+        }
+        const uint32_t rslot = pass ? (rank >> 6) : 0xFFFFFFFFu, rlane = rank & 63u;
+        uint32_t base = 0;               // candidates whose rank lies in an earlier slot
+        uint32_t lost = 0xFFFFFFFFu;     // smallest distance bits among what falls off the end
+        uint32_t first_moved = S;        // slots before it keep their keys (no candidate below any of their entries)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint64_t in = wave_ballot(rslot == (uint32_t)s);
+            if (base == 0u && in == 0ull) continue; // nothing has been inserted below this slot's entries
+            if (first_moved == (uint32_t)S) first_moved = (uint32_t)s;
+            uint32_t shift = base;
+            for (uint64_t it = in; it; it &= it - 1) shift += (lane >= readlane32(rlane, (uint32_t)__builtin_ctzll(it))) ? 1u : 0u;
+            base += (uint32_t)__popcll(in);
+            const uint32_t newpos = (uint32_t)s * 64u + lane + shift;
+            const uint64_t mine = L.key[s];
+            if (newpos < CAP) mslot[newpos] = mine;
+            else lost = min(lost, wkey_hi(mine));
+        }
+        if (pass && mypos < CAP) mslot[mypos] = ck;
+        if (pass && mypos >= CAP) lost = min(lost, wkey_hi(ck));
+        asm volatile("" ::: "memory"); // one wave: LDS executes its accesses in program order
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if ((uint32_t)s >= first_moved) L.key[s] = mslot[(uint32_t)s * 64u + lane];
+        asm volatile("" ::: "memory");
+        // the first unexpanded entry may now be one of the candidates
+        const uint32_t myp = pass ? mypos : 0xFFFFFFFFu;
+        uint32_t minpos = myp;
+        for (int o = 32; o > 0; o >>= 1) minpos = min(minpos, (uint32_t)__shfl_xor((int)minpos, o, 64));
+        L.fu_lb = min(L.fu_lb, minpos);
+        theta = wkey_hi(L.at(ef - 1));
+        if (wave_ballot(lost != 0xFFFFFFFFu && lost == theta && theta != 0xFFFFFFFFu)) bail = true;
+    }
+
     // mod.rs:1029 for the candidates of one expansion (`cand` lanes hold a distance): which of them enter the list
     __device__ __forceinline__ bool filter(bool cand, float d, uint32_t ef) {
         const uint32_t dbits = __float_as_uint(d);
@@ -758,7 +859,10 @@ struct FastWalker {
             bool pass = filter(cand, d, ef);
             const uint64_t ck = wkey(d, nb);
             uint64_t pm = wave_ballot(pass);
-            if constexpr (NOVIS && WalkList<S>::MIRROR) { // bulk merge: the candidates the list holds already leave first
+            [[maybe_unused]] uint32_t lrank = 0;
+            if constexpr (NOVIS && LONG) { // long lists: rank by binary search; known candidates leave in the same search
+                pm = rank_long(pass, ck, lrank);
+            } else if constexpr (NOVIS && WalkList<S>::MIRROR) { // bulk merge: the candidates the list holds already leave first
                 pm = drop_known(pm, pass, nb);
                 pass = (pm >> lane) & 1ull;
             }
@@ -798,7 +902,8 @@ struct FastWalker {
                 PT_ADD(4, m_ > 6u ? 1u : 0u);
                 PT_ADD(5, beat0 ? 1u : 0u);
             }
-            insert(pm, pass, ck, ef);                      // pq.push, mod.rs:1029-1031
+            if constexpr (NOVIS && LONG) place_long(pm, pass, ck, lrank, ef);
+            else insert(pm, pass, ck, ef);                 // pq.push, mod.rs:1029-1031
             PT_MARK(6); // insert / merge
             if (!vis.make_room(p.ovf, lane)) bail = true;
             PT_MARK(9); // visited-set housekeeping
