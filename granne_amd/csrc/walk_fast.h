@@ -1023,7 +1023,11 @@ constexpr int fast_waves_per_simd(int DT, int DIM, int S, bool WIDE = false) {
 #if GRANNE_HIP_PHASE_TIMERS
     return 1; // the phase clocks live in registers too: no cap, the diagnostics run is one wave per SIMD anyway
 #endif
-    if (S >= 33) return 1; // lists of 2112 / 4160 keys: 2 registers per 64 keys + the merge's counters; 17-33 KB of LDS mirror each
+    // lists of 2112 / 4160 keys: 2 registers per 64 keys + the merge's bookkeeping; 17 / 33 KB of LDS mirror each. Two
+    // walkers per SIMD for the 33-slot lists (256 registers: measured 137 k against 97 k queries/s at max_search 1600 when the
+    // allocation crept to 259), one for the 65-slot ones
+    if (S >= 65) return 1;
+    if (S >= 33) return 2;
     if (DT == DT_I8 && DIM >= 256) return DIM == 256 ? 3 : 2; // 2 / 4 blocks of row data and of query per lane
     if (DT == DT_I8) return S == 1 ? 5 : S <= 4 ? 4 : S == 8 ? 3 : 2;
     if (DIM == 0) return 2; // the streamed walker keeps a group of chunks, the tail and the accumulators: ~210 VGPRs
