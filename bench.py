@@ -144,15 +144,16 @@ def csrc_sha():
 
 def auto_group(args, steps):
     """Batches handed to the library per call (one launch each, up to 32 batches): all K timed steps when they fit one
-    launch, else the largest divisor of K that does -- every call of the timed region then has the same shape."""
+    launch; else the largest divisor of K in [16, 32], so that every call of the timed region has the same shape; else 32
+    (the last call then carries the remainder)."""
     if args.batches_per_call:
         return max(1, min(args.batches_per_call, steps))
     if steps <= 32:
         return steps
-    for d in range(32, 0, -1):
+    for d in range(32, 15, -1):
         if steps % d == 0:
             return d
-    return 1
+    return 32
 
 
 def workload_label(n, dim, dtype, data, nq, ef, k):

@@ -274,8 +274,10 @@ int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, co
  * v_mfma_i32_32x32x16_i8; granne_amd/csrc/brute_force.h). Candidates are SELECTED by the MFMA score; the returned
  * distances are recomputed in the reference's arithmetic (bit-exact for the returned ids) and the results are ordered
  * ascending by (distance, id). The id set can differ from a scalar scan only between elements whose distances to the
- * query are within the MFMA's rounding (~1e-6) of each other at the k-th place. k <= 16; f32 rows of up to 256
- * dimensions, int8 rows of up to 128. queries: dense [nq][dim], prepared like the elements. Asynchronous on `stream`. */
+ * query are within the MFMA's rounding (~1e-6) of each other at the boundary of the selection: min(k + 6, 16)
+ * candidates per query are selected and re-ranked, so k <= 10 has six spare candidates, k = 16 none. k <= 16; f32 rows
+ * of up to 256 dimensions, int8 rows of up to 128. queries: dense [nq][dim], prepared like the elements (the Python and
+ * C++ wrappers check the width). Asynchronous on `stream`. */
 int granne_hip_brute_force_device(const granne_hip_index* index, const void* d_queries, uint32_t nq, uint32_t k,
                                   uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, void* stream);
 /* the same with host buffers in and out (synchronous) */

@@ -20,7 +20,8 @@ def test_batches_per_call_divide_the_timed_steps():
     # more steps than one launch carries (32 batches): the largest divisor of K that fits, so every call has one shape
     assert bench.auto_group(auto, 64) == 32
     assert bench.auto_group(auto, 100) == 25
-    assert bench.auto_group(auto, 37) == 1  # a prime beyond 32: one batch per call
+    assert bench.auto_group(auto, 37) == 32  # no divisor in [16, 32]: calls of 32, the last one carries 5
+    assert bench.auto_group(auto, 1000) == 25
     # an explicit --batches-per-call wins, bounded by K
     assert bench.auto_group(types.SimpleNamespace(batches_per_call=4), 20) == 4
     assert bench.auto_group(types.SimpleNamespace(batches_per_call=1), 20) == 1
