@@ -49,7 +49,7 @@ def main():
     esize = 4 if a.dtype == "f32" else 1
     steps, warmup = 6, 2
     queries = B.rows("uniform", bench.SEED + 1, 0, (steps + warmup) * a.nq, a.dim, a.dtype)
-    m = B.measure(index, queries, a.dim, esize, a.nq, a.ef, 10, steps, warmup, a.inflight)
+    m = B.measure(index, queries, a.dim, esize, a.nq, a.ef, 10, steps, warmup, 1, inflight=a.inflight)
     print("launch %.4f ms (min %.4f) with the stamps" % (m["launch_ms_mean"], m["launch_ms_min"]))
     # the clocks are those of the LAST launch, and measure() ends with its counting pass on the exact visited tables:
     # one more launch of the shipped form (or of the form GRANNE_HIP_VISITED names)

@@ -9,15 +9,15 @@ d = json.load(open(sys.argv[1]))
 def line(tag, r):
     rf = r.get("roofline", {})
     cb = r.get("cpu_baseline", {})
-    print("%-10s value %10.0f q/s (%.4f ms/step) | one at a time %10.0f | launch %.4f ms (min %.4f) frac %.4f traffic %s | ef %s recall %s | cpu %s (1t %s) x%s match %s slow %s spill %s"
+    print("%-10s value %10.0f q/s (%.4f ms/step) | one batch per call %10.0f | timed launch %.4f ms (min %.4f) frac %.4f traffic %s | ef %s recall %s | cpu %s (1t %s) x%s match %s slow %s spill %s"
           % (tag, r.get("value", 0), r.get("ms_per_step", 0), r.get("sequential", {}).get("value", 0), rf.get("launch_ms_mean", 0),
-             rf.get("launch_ms_min", 0), rf.get("frac", 0), rf.get("traffic"), r.get("ef_search", r.get("config", {}).get("ef_search")),
+             rf.get("launch", {}).get("ms_min", rf.get("launch_ms_min", 0)), rf.get("frac", 0), rf.get("traffic"), r.get("ef_search", r.get("config", {}).get("ef_search")),
              r.get("recall_at_10"), cb.get("value"), cb.get("single_thread", {}).get("value"), r.get("speedup_vs_cpu"),
              cb.get("gpu_matches_oracle"), r.get("slow_path_queries"), r.get("visited_spill_walks")))
 
 
 line(d.get("dtype", "main"), d)
-for k in ("int8", "secondary"):
+for k in ("int8", "secondary", "c4_shard", "c5_shard"):
     if k in d:
         line(k, d[k])
 for k in ("ef_sweep",):

@@ -10,6 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # (configs with inflight > 1 want more queues than streams)
 import bench  # noqa: E402
 
 
@@ -42,9 +43,10 @@ def main():
             print("nq=1 ef=%d" % ef, B.latency_nq1(index, queries, a.dim, ef, 10), flush=True)
     for c in a.cfg:
         kv = dict(x.split("=") for x in c.split(","))
-        ef, nq, infl, vs = int(kv.get("ef", 50)), int(kv.get("nq", 1024)), int(kv.get("inflight", 3)), int(kv.get("vs", 0))
+        ef, nq, infl, vs = int(kv.get("ef", 50)), int(kv.get("nq", 1024)), int(kv.get("inflight", 1)), int(kv.get("vs", 0))
+        group = int(kv.get("group", a.steps))  # batches per library call (round 4's timed shape); inflight > 1: round 3's streams
         index.set_option(B._lib.OPT_VISITED_SLOTS, vs)
-        m = B.measure(index, queries, a.dim, esize, nq, ef, 10, a.steps, a.warmup, infl)
+        m = B.measure(index, queries, a.dim, esize, nq, ef, 10, a.steps, a.warmup, group, inflight=infl)
         print("%-40s value %9.0f q/s | one at a time %9.0f | launch %.4f ms (min %.4f) frac %.4f | slow %d spill %d"
               % (c, m["value_local"], a.steps * nq / m["seq_elapsed"], m["launch_ms_mean"], m["launch_ms_min"],
                  m["achieved"] / 8000.0, m["slow"], m["spill"]), flush=True)
