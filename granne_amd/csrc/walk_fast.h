@@ -818,14 +818,6 @@ struct FastWalker {
                 const uint32_t last_id = nvalid ? readlane32(nb, 2u * (nvalid - 1u)) : xid;
                 issue_rows((R < nvalid) ? nb : last_id, rr);
             }
-            [[maybe_unused]] uint32_t atouch = 0;
-            if constexpr (TOUCH) {
-                // (few queries, idle chip) the adjacency rows of all 32 neighbors are touched with the element rows: whichever
-                // of them is expanded next -- a fresh candidate wins every other expansion -- finds its adjacency row in L2
-                // (~200 cycles) instead of HBM (~900) when it is requested after the distances. One 4-byte load per pair.
-                atouch = adjg[(size_t)((R < nvalid) ? nb : xid) * W + h];
-                asm volatile("" ::: "memory");
-            }
             if (half == 0u) {
                 // fetch ahead the row of the node that is first in line now; always one load: static wait counts
                 uint32_t ypos = 0;
@@ -845,7 +837,6 @@ struct FastWalker {
             PT_MARK(3); // what is left of the wait for the rows
             const float d = finish_rows(rr);
             if constexpr (TOUCH) {
-                asm volatile("" ::"v"(atouch)); // (issued right behind the rows: here by now)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(touched[j])); // (arrived before the rows did)
                 // y's adjacency row came in right behind the rows; a pair past its end touches y's own row
@@ -899,19 +890,6 @@ struct FastWalker {
                 pre_id = wkey_id(K);
                 pre_nb = adjg[(size_t)pre_id * W + R];
                 if constexpr (WIDE) ykey = K; // the second pass's candidates have this one to beat
-                if constexpr (TOUCH) {
-                    // (few queries, idle chip) the winner's adjacency row was touched with its element row, so it is back
-                    // from L2 in ~200 cycles: wait for it here and touch ITS neighbors' rows before the merge instead of
-                    // requesting them after it -- the gather of the next expansion is under way while this one inserts
-                    const uint32_t tid = pre_nb != ID_EMPTY ? pre_nb : pre_id;
-                    const uint8_t* tb = p.elements + (size_t)tid * ROWB;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const uint32_t off = h * 128u + (uint32_t)j * 256u;
-                        touched[j] = *reinterpret_cast<const uint32_t*>(tb + (off < ROWB ? off : ROWB - 4u));
-                    }
-                    asm volatile("" ::: "memory");
-                }
                 break;
             }
             PT_MARK(5); // filter, next-node decision, its adjacency request
