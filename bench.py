@@ -453,6 +453,9 @@ class Bench:
         if not bool((stats_x[:, :, 1:] == stats[warmup:, :, 1:]).all().item()):
             raise RuntimeError("expansion / adjacency counters differ between the two forms of the walk")
         st = stats_x.sum(dim=(0, 1)).cpu().numpy().astype(np.float64)  # n_dist, n_expand, n_adj (the reference's counts)
+        # (graphs of 64-id layers and lists beyond 1024 keys walk without a visited set whatever the option asks for: their
+        #  n_dist counts evaluated rows, a few percent above the reference's distinct nodes -- said in the record)
+        counted_exactly = index.get_option(_glib.OPT_LAST_WALKER) != _glib.WALKER_REGISTER_WIDE and ef <= 1024
         alg_total = st[0] * dim * esize + st[2] * 4 + steps * nq * (dim * esize + k * 8)
         alg_per_batch = alg_total / steps
         mean_ms = float(np.mean(step_ms))
@@ -477,7 +480,8 @@ class Bench:
                     "launch_ms_min": float(np.min(step_ms)), "call_ms_mean": float(np.mean(call_ms))},
             "per_query": {"n_dist": round(st[0] / (steps * nq), 1), "n_expand": round(st[1] / (steps * nq), 1),
                           "n_adj": round(st[2] / (steps * nq), 1), "rows_evaluated": round(evaluated / (steps * nq), 1)},
-            "same_as_exact_set_walk": {"queries": steps * nq, "ids_dists_counts_bit_exact": True},
+            "same_as_exact_set_walk": {"queries": steps * nq, "ids_dists_counts_bit_exact": True,
+                                       "n_dist_is_the_references_count": bool(counted_exactly)},
         }
 
     def roofline(self, m, traffic_key, value_per_gpu, nq):
