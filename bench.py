@@ -156,11 +156,14 @@ def auto_group(args, steps):
     return 32
 
 
-def workload_label(n, dim, dtype, data, nq, ef, k):
-    """Names what actually ran. BASELINE.json's configs get their tag only for their exact shape."""
+def workload_label(n, dim, dtype, data, nq, ef, k, default_graph=True):
+    """Names what actually ran. BASELINE.json's configs get their tag only for their exact shape (and the reference's
+    default graph: BuildConfig::default(), src/index/mod.rs:220-231)."""
     comp = "i.i.d. uniform components" if data == "uniform" else "16-d latent cube through a fixed random linear map"
     tag = "custom"
-    if data == "uniform" and dim == 100 and n == 10_000_000 and nq == 1024 and ef == 50:
+    if not default_graph:
+        tag = "custom (non-default graph)"
+    elif data == "uniform" and dim == 100 and n == 10_000_000 and nq == 1024 and ef == 50:
         tag = "C2 (BASELINE.json configs[1])" if dtype == "f32" else "C3 (BASELINE.json configs[2])"
     elif data == "uniform" and dtype == "f32" and dim == 200 and n == 12_500_000 and nq == 4096:
         tag = "C4 shard (one of the 8 shards of BASELINE.json configs[3]: 100M x 200-d f32)"
@@ -866,7 +869,8 @@ def run_replica(B, args):
         "steady": m["steady"],
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
-            "workload": workload_label(n, dim, args.dtype, args.data, nq, ef, k),
+            "workload": workload_label(n, dim, args.dtype, args.data, nq, ef, k,
+                                       default_graph=(args.num_neighbors == 30 and args.build_max_search == 200 and bool(args.build_reinsert))),
             "n_elements": n, "dim": dim, "batch": nq, "ef_search": ef, "k": k, "layers": layer_sizes,
             "graph": {"builder": "gpu-batched", "num_neighbors": args.num_neighbors,
                       "max_search": args.build_max_search, "reinsert": bool(args.build_reinsert),

@@ -35,6 +35,7 @@ def test_workload_label_names_baseline_configs_only_for_their_exact_shape():
     assert c3.startswith("C3 (BASELINE.json configs[2])")
     other = bench.workload_label(1_000_000, 100, "f32", "uniform", 1024, 50, 10)
     assert not other.startswith("C2") and "1000000 x 100-d f32" in other
+    assert not bench.workload_label(10_000_000, 100, "f32", "uniform", 1024, 50, 10, default_graph=False).startswith("C2")
     latent = bench.workload_label(10_000_000, 100, "f32", "latent", 1024, 30, 10)
     assert "latent" in latent and not latent.startswith("C2")
 
