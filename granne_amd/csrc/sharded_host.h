@@ -112,12 +112,16 @@ struct granne_hip_sharded {
         std::vector<hipEvent_t> searched; // per shard
         std::vector<hipEvent_t> q_there;  // per device: the queries have arrived
         std::vector<hipEvent_t> xdone;    // per device: its part of the exchange is over (buffers reusable)
-        // host-pointer calls: [queries | ids | dists | counts | status] in pinned memory and on the merge device
+    };
+    // host-pointer calls: [queries | ids | dists | counts | status] of one batch in pinned memory and on the merge device
+    // (the calls' own buffers, `depth` of them in rotation: independent of which slot a batch's begin happens to take)
+    struct HostIO {
         uint8_t* h_pin = nullptr;
         uint8_t* d_io = nullptr;
         size_t h_cap = 0, io_cap = 0;
         hipEvent_t h_done = nullptr;
     };
+    HostIO host_io[SHARDED_MAX_DEPTH];
     std::vector<Shard> shards;
     std::vector<Device> devices;
     std::vector<Slot> slots;
@@ -150,9 +154,6 @@ static void sharded_free_slot(granne_hip_sharded* sh, granne_hip_sharded::Slot& 
     DeviceGuard g(sh->merge_device);
     if (L.ready) (void)hipEventDestroy(L.ready);
     if (L.merged) (void)hipEventDestroy(L.merged);
-    if (L.h_done) (void)hipEventDestroy(L.h_done);
-    if (L.h_pin) (void)hipHostFree(L.h_pin);
-    if (L.d_io) (void)hipFree(L.d_io);
     L = granne_hip_sharded::Slot();
 }
 
@@ -189,6 +190,11 @@ static void sharded_free(granne_hip_sharded* sh) {
     }
     {
         DeviceGuard g(sh->merge_device);
+        for (auto& H : sh->host_io) {
+            if (H.h_done) (void)hipEventDestroy(H.h_done);
+            if (H.h_pin) (void)hipHostFree(H.h_pin);
+            if (H.d_io) (void)hipFree(H.d_io);
+        }
         if (sh->merge_stream) (void)hipStreamDestroy(sh->merge_stream);
         if (sh->io_stream) (void)hipStreamDestroy(sh->io_stream);
     }
@@ -217,7 +223,6 @@ static int sharded_init_slot(granne_hip_sharded* sh, granne_hip_sharded::Slot& L
     DeviceGuard g(sh->merge_device);
     HIP_TRY(hipEventCreateWithFlags(&L.ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&L.merged, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&L.h_done, hipEventDisableTiming));
     return GRANNE_HIP_OK;
 }
 
@@ -582,51 +587,49 @@ extern "C" int granne_hip_sharded_search_batches(granne_hip_sharded* sh, const v
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", sh->merge_device);
     struct Pending {
         uint32_t batch;
-        uint32_t slot;
+        uint32_t io; // which of the handle's host_io sets carries the batch
         uint64_t ticket;
     };
     std::vector<Pending> pending;
     auto finish = [&](const Pending& P) -> int {
-        auto& L = sh->slots[P.slot];
+        auto& H = sh->host_io[P.io];
         rc = granne_hip_sharded_end_device(sh, P.ticket, sh->io_stream);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(L.h_pin + o_ids, L.d_io + o_ids, total - o_ids, hipMemcpyDeviceToHost, sh->io_stream));
-        HIP_TRY(hipEventRecord(L.h_done, sh->io_stream));
-        HIP_TRY(hipEventSynchronize(L.h_done));
-        const uint32_t* st = (const uint32_t*)(L.h_pin + o_st);
+        HIP_TRY(hipMemcpyAsync(H.h_pin + o_ids, H.d_io + o_ids, total - o_ids, hipMemcpyDeviceToHost, sh->io_stream));
+        HIP_TRY(hipEventRecord(H.h_done, sh->io_stream));
+        HIP_TRY(hipEventSynchronize(H.h_done));
+        const uint32_t* st = (const uint32_t*)(H.h_pin + o_st);
         if (st[0]) return fail(GRANNE_HIP_ERR_OVERFLOW, "a shard's exact-search scratch is exhausted (raise GRANNE_HIP_OPT_SLOW_SLOTS)");
-        memcpy(out_ids + (size_t)P.batch * nq * k, L.h_pin + o_ids, (size_t)nq * k * 8);
-        memcpy(out_dists + (size_t)P.batch * nq * k, L.h_pin + o_d, (size_t)nq * k * 4);
-        memcpy(out_counts + (size_t)P.batch * nq, L.h_pin + o_c, (size_t)nq * 4);
+        memcpy(out_ids + (size_t)P.batch * nq * k, H.h_pin + o_ids, (size_t)nq * k * 8);
+        memcpy(out_dists + (size_t)P.batch * nq * k, H.h_pin + o_d, (size_t)nq * k * 4);
+        memcpy(out_counts + (size_t)P.batch * nq, H.h_pin + o_c, (size_t)nq * 4);
         return GRANNE_HIP_OK;
     };
+    const uint32_t depth = sh->depth;
     for (uint32_t b = 0; b < n_batches; ++b) {
-        uint32_t si;
-        {
-            std::lock_guard<std::mutex> lk(sh->mu);
-            si = sh->next_slot;
-        }
-        if (!pending.empty() && pending.front().slot == si) { // the slot's previous batch comes home first
+        if (pending.size() >= depth) { // the oldest batch comes home first: its buffers (and its slot) are the next ones
             rc = finish(pending.front());
             if (rc) return rc;
             pending.erase(pending.begin());
         }
-        auto& L = sh->slots[si];
-        if (L.h_cap < total) {
-            if (L.h_pin) (void)hipHostFree(L.h_pin);
-            L.h_pin = nullptr;
-            L.h_cap = 0;
-            HIP_TRY(hipHostMalloc((void**)&L.h_pin, total + (total >> 2), hipHostMallocDefault));
-            L.h_cap = total + (total >> 2);
+        const uint32_t io = b % depth;
+        auto& H = sh->host_io[io];
+        if (!H.h_done) HIP_TRY(hipEventCreateWithFlags(&H.h_done, hipEventDisableTiming));
+        if (H.h_cap < total) {
+            if (H.h_pin) (void)hipHostFree(H.h_pin);
+            H.h_pin = nullptr;
+            H.h_cap = 0;
+            HIP_TRY(hipHostMalloc((void**)&H.h_pin, total + (total >> 2), hipHostMallocDefault));
+            H.h_cap = total + (total >> 2);
         }
-        rc = slot_grow(&L.d_io, &L.io_cap, total);
+        rc = slot_grow(&H.d_io, &H.io_cap, total);
         if (rc) return rc;
-        memcpy(L.h_pin, (const uint8_t*)queries + (size_t)b * qb, qb);
-        HIP_TRY(hipMemcpyAsync(L.d_io, L.h_pin, qb, hipMemcpyHostToDevice, sh->io_stream));
-        HIP_TRY(hipMemsetAsync(L.d_io + o_st, 0, 16, sh->io_stream));
-        Pending P{b, si, 0};
-        rc = granne_hip_sharded_begin_device(sh, L.d_io, nq, max_search, num_neighbors, (uint64_t*)(L.d_io + o_ids),
-                                             (float*)(L.d_io + o_d), (uint32_t*)(L.d_io + o_c), (uint32_t*)(L.d_io + o_st),
+        memcpy(H.h_pin, (const uint8_t*)queries + (size_t)b * qb, qb);
+        HIP_TRY(hipMemcpyAsync(H.d_io, H.h_pin, qb, hipMemcpyHostToDevice, sh->io_stream));
+        HIP_TRY(hipMemsetAsync(H.d_io + o_st, 0, 16, sh->io_stream));
+        Pending P{b, io, 0};
+        rc = granne_hip_sharded_begin_device(sh, H.d_io, nq, max_search, num_neighbors, (uint64_t*)(H.d_io + o_ids),
+                                             (float*)(H.d_io + o_d), (uint32_t*)(H.d_io + o_c), (uint32_t*)(H.d_io + o_st),
                                              sh->io_stream, &P.ticket);
         if (rc) return rc;
         pending.push_back(P);

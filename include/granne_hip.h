@@ -359,7 +359,8 @@ int granne_hip_sharded_end_device(granne_hip_sharded* sharded, uint64_t ticket, 
 /* HOST buffers (synchronous; pinned staging inside): queries [n_batches][nq][dim], out_ids (global ids,
  * ascending (dist, id)) / out_dists [n_batches][nq][num_neighbors], out_counts [n_batches][nq]; batches
  * are pipelined GRANNE_HIP_SHARDED_OPT_DEPTH deep (batch b+1's upload and search overlap batch b's
- * exchange, merge and download). The host-pointer calls of one handle run one at a time.                */
+ * exchange, merge and download). The host-pointer calls of one handle run one at a time, and share the
+ * handle's depth with whatever device-pointer batches other threads have in flight.                      */
 int granne_hip_sharded_search_batches(granne_hip_sharded* sharded, const void* queries, uint32_t n_batches,
                                       uint32_t nq, uint32_t max_search, uint32_t num_neighbors,
                                       uint64_t* out_ids, float* out_dists, uint32_t* out_counts);

@@ -101,6 +101,30 @@ def _worker(rank, world, port, out_dir):
             raised = True
         assert raised, "rank %d did not see the other rank's exhausted shard" % rank
         sg._local_search = real_ls
+    # a launch that fails in the middle of a pipelined run (on every rank alike): the exception surfaces, no slot stays
+    # marked in flight, and the same object answers the next call as if nothing had happened
+    if True:
+        real_ls = sg._local_search
+        n_calls = {"n": 0}
+
+        def flaky(queries, max_search, k, out):
+            n_calls["n"] += 1
+            if n_calls["n"] == 3:
+                raise RuntimeError("launch failed")
+            real_ls(queries, max_search, k, out)
+        sg._local_search = flaky
+        try:
+            sg.search_batches(batches, 20, 5, depth=2)
+            raised = False
+        except RuntimeError:
+            raised = True
+        assert raised and not any(sl.busy for sl in sg._slots)
+        sg._local_search = real_ls
+        again = sg.search_batches(batches, 20, 5, depth=2)
+        for (pi, pd, pc), (ai, ad, ac) in zip(piped, again):
+            assert (pi == ai).all() and pd.numpy().tobytes() == ad.numpy().tobytes() and (pc == ac).all()
+        si, sd, sc = sg.search_batch(q, 20, 5)
+        assert (si == ids).all()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), ids=ids.numpy(), ds=ds.numpy(), cnt=cnt.numpy(),
              offsets=np.array(sg.offsets))
     # replica mode: disjoint query rows, all rows covered
