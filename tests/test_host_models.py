@@ -168,3 +168,75 @@ def test_one_candidate_add_and_limit_equals_the_full_pass():
         assert a > 200, a  # full rows of 30 did take the short form
         short, changed = short + a, changed + b
     assert short > 1000 and changed > 50, (short, changed)
+
+
+def test_long_list_merge_by_rank_and_prefix_shift_equals_a_sorted_merge():
+    """walk_fast.h, lists of 33 / 65 slots (rank_long / place_long): a candidate's rank is a lower_bound in the list (the
+    entry it stops at is its own node when the list holds it: same key up to the expanded flag), the second of two equal
+    candidates leaves, a candidate lands at rank + (candidates below it), an entry moves up by #{candidates with rank <=
+    its position} -- per 64-key slot a running count plus, only in the slots a rank falls into, a per-lane count -- what
+    falls off the end is reported, and the cached lower bound of the first unexpanded entry drops to the smallest place a
+    candidate took. Replayed against a plain merge of the two sorted sequences."""
+    rnd = random.Random(65)
+    INF = (1 << 64) - 1
+    for it in range(400):
+        S = rnd.choice([2, 3, 33])          # slots of 64 keys (the model does not care how many)
+        CAP = 64 * S
+        n_list = rnd.randrange(0, CAP + 1)
+        # keys: (dist bits << 32) | (id << 1) | expanded; few distinct distances -> many ties on distance
+        def key(d, i, f):
+            return (d << 32) | (i << 1) | f
+        ids = rnd.sample(range(1 << 20), n_list + 40)
+        entries = sorted(key(rnd.randrange(6 if it % 2 else 1 << 20), ids[j], rnd.randrange(2)) for j in range(n_list))
+        lst = entries + [INF] * (CAP - n_list)
+        fu_true = next((p for p, k in enumerate(lst) if k != INF and not (k & 1)), CAP)
+        fu_lb = rnd.randrange(0, fu_true + 1)  # any valid lower bound
+        # up to 32 candidates: fresh ids, some already in the list (revisits), some twice in the row
+        cands = []
+        for j in range(rnd.randrange(0, 33)):
+            r = rnd.random()
+            if r < 0.2 and n_list:
+                cands.append(entries[rnd.randrange(n_list)] & ~1)          # a node the list holds (flag cleared: a candidate key)
+            elif r < 0.3 and cands:
+                cands.append(cands[rnd.randrange(len(cands))])             # the row names a node twice
+            else:
+                cands.append(key(rnd.randrange(6 if it % 2 else 1 << 20), ids[n_list + j], 0))
+        # ---- the device's way
+        import bisect
+        rank, keep = [], []
+        for j, K in enumerate(cands):
+            r = bisect.bisect_left(lst, K)
+            known = r < CAP and (lst[r] | 1) == (K | 1)
+            twin = any(cands[i] == K for i in range(j))                     # an earlier lane with the same key (kept or not: then known too)
+            rank.append(r)
+            keep.append(not known and not twin)
+        kept = [j for j in range(len(cands)) if keep[j]]
+        mypos = {j: rank[j] + sum(1 for i in kept if cands[i] < cands[j]) for j in kept}
+        out = [None] * CAP
+        lost = []
+        base = 0
+        for s in range(S):
+            in_slot = [j for j in kept if rank[j] >> 6 == s]
+            for lane in range(64):
+                e = 64 * s + lane
+                shift = base + sum(1 for j in in_slot if lane >= (rank[j] & 63))
+                if e + shift < CAP:
+                    assert out[e + shift] is None
+                    out[e + shift] = lst[e]
+                elif lst[e] != INF:
+                    lost.append(lst[e])
+            base += len(in_slot)
+        for j in kept:
+            if mypos[j] < CAP:
+                assert out[mypos[j]] is None
+                out[mypos[j]] = cands[j]
+            else:
+                lost.append(cands[j])
+        new_lb = min([fu_lb] + [mypos[j] for j in kept])
+        # ---- a plain merge
+        fresh = sorted({K for K in cands if not any((e | 1) == (K | 1) for e in entries)})
+        merged = sorted(entries + fresh) + [INF] * CAP
+        assert out == merged[:CAP], (it, S, n_list, len(cands))
+        assert sorted(lost) == sorted(k for k in merged[CAP:CAP + len(entries) + len(fresh)] if k != INF)
+        first_unexp = next((p for p, k in enumerate(out) if k != INF and not (k & 1)), CAP)
+        assert new_lb <= first_unexp and all(k & 1 for k in out[:new_lb])
