@@ -1,4 +1,4 @@
-"""CPU models of two device-side arguments, replayed against the reference's plain algorithms.
+"""CPU models of device-side arguments, replayed against the reference's plain algorithms.
 
 * tools/model_unified.py: the walker's ONE sorted list with expanded flags and its once-per-expansion tie test
   (walk_fast.h, insert_sorted) against the reference's two heaps (src/index/mod.rs:999-1037) on tie-heavy graphs.
@@ -240,3 +240,36 @@ def test_long_list_merge_by_rank_and_prefix_shift_equals_a_sorted_merge():
         assert sorted(lost) == sorted(k for k in merged[CAP:CAP + len(entries) + len(fresh)] if k != INF)
         first_unexp = next((p for p, k in enumerate(out) if k != INF and not (k & 1)), CAP)
         assert new_lb <= first_unexp and all(k & 1 for k in out[:new_lb])
+
+
+def test_rows_taken_in_two_passes_equal_two_heaps():
+    """walk_fast.h's WIDE walker (layers of up to 64 ids): a row is evaluated, filtered and inserted in two passes of 32
+    neighbors. The reference's filter bound (res.peek()) belongs to the expansion, the list's own bound (entry
+    max_search-1) is re-read between the passes -- results, expansions and adjacency entries equal the reference's HashSet
+    walk on tie-heavy graphs with rows of up to 64 ids, duplicates within and across the halves included."""
+    spec = importlib.util.spec_from_file_location("model_unified", os.path.join(ROOT, "tools", "model_unified.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rnd = random.Random(64)
+    equal = bailed = 0
+    for it in range(500):
+        n = rnd.choice([70, 120, 400])
+        deg = rnd.choice([33, 40, 48, 63, 64])
+        ef = rnd.choice([1, 2, 10, 50, 60, 64])
+        adj = [rnd.sample(range(n), min(deg, n)) for _ in range(n)]
+        if it % 3 == 0:
+            for row in adj:
+                if rnd.random() < 0.4:
+                    row[-1] = row[rnd.randrange(len(row) - 1)]  # the same node in both halves (or twice in one)
+        mode = rnd.choice(["float", "int_small", "int_tiny"])
+        dv = [rnd.random() if mode == "float" else rnd.randrange(50 if mode == "int_small" else 4) / 50.0 for _ in range(n)]
+        ep = rnd.randrange(n)
+        r0, c0 = m.reference(adj, dv.__getitem__, ep, ef)
+        r1, c1 = m.unified_passes(adj, dv.__getitem__, ep, ef, 64, 32)
+        if r1 is None:
+            bailed += 1
+            continue
+        assert r0 == r1, (it, mode, n, deg, ef)
+        assert c0[1:] == c1[1:] and c1[0] >= c0[0], (it, c0, c1)
+        equal += 1
+    assert equal > 300

@@ -48,6 +48,50 @@ def reference(adj, dist, ep, ef):
     return sorted((-a, -b) for a, b in res), (n_dist, n_expand, n_adj)
 
 
+def unified_passes(adj, dist, ep, ef, cap, pass_size):
+    """The walker WITHOUT a visited set on rows wider than its lanes (walk_fast.h, WIDE: layers of up to 64 ids): an
+    expansion takes the row in passes of `pass_size` neighbors -- distances, filter, look-up, insert and the tie test per
+    pass. `worst` (res.peek(), mod.rs:1029) is the expansion's: res does not change while a row is processed; theta (the
+    dead-candidate bound, entry max_search-1) is re-read after every pass's inserts, as the kernel does."""
+    L = [[dist(ep), ep, True]]
+    n_dist, n_expand, n_adj = 1, 1, len(adj[ep])
+    x = ep
+    while True:
+        exp = [e for e in L if e[2]]
+        worst = exp[ef - 1][0] if len(exp) >= ef else None
+        row = adj[x]
+        for p0 in range(0, max(len(row), 1), pass_size):
+            theta = L[ef - 1][0] if len(L) >= ef else None
+            lost = None
+            for n in row[p0:p0 + pass_size]:
+                dn = dist(n)
+                n_dist += 1
+                if worst is not None and not dn < worst:
+                    continue
+                if theta is not None and dn > theta:
+                    continue
+                if any(e[1] == n for e in L):
+                    continue
+                keys = [(e[0], e[1]) for e in L]
+                L.insert(bisect.bisect_left(keys, (dn, n)), [dn, n, False])
+                while len(L) > cap:
+                    y = L.pop()
+                    lost = y[0] if lost is None else min(lost, y[0])
+            if lost is not None and lost == L[ef - 1][0]:
+                return None, None
+        ypos = next((i for i, e in enumerate(L) if not e[2]), None)
+        if ypos is None:
+            break
+        if ypos >= ef and sum(1 for e in L if e[0] < L[ypos][0]) >= ef:
+            break
+        L[ypos][2] = True
+        x = L[ypos][1]
+        n_expand += 1
+        n_adj += len(adj[x])
+    exp = [(e[0], e[1]) for e in L if e[2]]
+    return exp[:ef], (n_dist, n_expand, n_adj)
+
+
 def unified(adj, dist, ep, ef, cap, deferred=True, novis=False):
     """The list walker with walk_fast.h's control flow: the next node is decided (and its break test
     taken) BEFORE the candidates of the current expansion are merged.
