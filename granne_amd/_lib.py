@@ -102,6 +102,9 @@ SIGNATURES = {
     "granne_hip_sharded_num_shards": (u32, [vp]),
     "granne_hip_sharded_len": (u64, [vp]),
     "granne_hip_sharded_device": (i32, [vp]),
+    "granne_hip_sharded_shard": (vp, [vp, u32]),
+    "granne_hip_sharded_shard_offset": (u64, [vp, u32]),
+    "granne_hip_sharded_build": (i32, [C.POINTER(vp), vp, vp, u64, u32, i32, u32, vp, u32]),
     "granne_hip_sharded_set_option": (i32, [vp, i32, u64]),
     "granne_hip_sharded_get_option": (i32, [vp, i32, C.POINTER(u64)]),
     "granne_hip_sharded_search_batch_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp]),

@@ -24,6 +24,8 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+
 // ---- RCCL, bound at run time ------------------------------------------------------------------------------
 struct RcclApi {
     void* handle = nullptr;
@@ -137,6 +139,7 @@ struct granne_hip_sharded {
     int dtype = 0;
     std::mutex mu;      // slot bookkeeping + the enqueue of one begin / end (host work only; nothing waits for a GPU under it)
     std::mutex host_mu; // the host-pointer calls of a handle run one at a time (they are synchronous anyway)
+    bool owns_shards = false; // granne_hip_sharded_build: the shard indexes are the handle's and go with it
 };
 
 static void sharded_free_slot(granne_hip_sharded* sh, granne_hip_sharded::Slot& L) {
@@ -188,6 +191,9 @@ static void sharded_free(granne_hip_sharded* sh) {
         DeviceGuard g(S.ix->device);
         if (S.stream) (void)hipStreamDestroy(S.stream);
     }
+    if (sh->owns_shards)
+        for (auto& S : sh->shards)
+            if (S.ix) granne_hip_index_destroy(S.ix);
     {
         DeviceGuard g(sh->merge_device);
         for (auto& H : sh->host_io) {
@@ -290,6 +296,62 @@ extern "C" int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_in
     }
     *out = sh;
     return GRANNE_HIP_OK;
+}
+
+// SURVEY.md 8b's `index_create(..., device_ids, n_devices, partitioned)`: the whole element set in, a searchable
+// partitioned index out. Shard s takes the elements [s * ceil(n / n_shards), ...) -- the split of
+// src/elements/embeddings/parsing.rs:72-98 -- and is built with the GPU builder (GranneBuilder::new(config, shard).build())
+// on device_ids[s / ceil(n_shards / n_devices)]: device-major, so that the all-gather exchange is available when the
+// shards divide evenly. The handle owns the shard indexes.
+extern "C" int granne_hip_sharded_build(granne_hip_sharded** out, const granne_hip_build_config* config, const void* elements,
+                                        uint64_t n_elements, uint32_t dim, int dtype, uint32_t n_shards,
+                                        const int* device_ids, uint32_t n_devices) {
+    if (!out) return fail(GRANNE_HIP_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!config || !device_ids) return fail(GRANNE_HIP_ERR_INVALID, "null argument");
+    if (n_shards == 0 || n_shards > 64) return fail(GRANNE_HIP_ERR_INVALID, "n_shards must be in [1, 64]");
+    if (n_devices == 0 || n_devices > n_shards) return fail(GRANNE_HIP_ERR_INVALID, "n_devices must be in [1, n_shards]");
+    if (dtype != GRANNE_HIP_F32 && dtype != GRANNE_HIP_I8) return fail(GRANNE_HIP_ERR_INVALID, "unknown dtype %d", dtype);
+    if (dim == 0) return fail(GRANNE_HIP_ERR_INVALID, "dim must be > 0");
+    if (n_elements && !elements) return fail(GRANNE_HIP_ERR_INVALID, "elements is null");
+    const uint64_t per = (n_elements + n_shards - 1) / n_shards;
+    const uint32_t per_dev = (n_shards + n_devices - 1) / n_devices;
+    const size_t row = (size_t)dim * elem_size(dtype);
+    std::vector<granne_hip_index*> ixs;
+    std::vector<uint64_t> offs;
+    int rc = GRANNE_HIP_OK;
+    for (uint32_t s = 0; s < n_shards && rc == GRANNE_HIP_OK; ++s) {
+        const uint64_t lo = std::min(n_elements, (uint64_t)s * per), hi = std::min(n_elements, (uint64_t)(s + 1) * per);
+        granne_hip_builder* b = nullptr;
+        granne_hip_index* ix = nullptr;
+        rc = granne_hip_builder_create(&b, config, (const uint8_t*)elements + lo * row, hi - lo, dim, dtype, device_ids[s / per_dev]);
+        if (rc == GRANNE_HIP_OK) rc = granne_hip_builder_build(b, GRANNE_HIP_BUILD_ALL);
+        if (rc == GRANNE_HIP_OK) rc = granne_hip_builder_get_index(b, &ix);
+        if (b) granne_hip_builder_destroy(b);
+        if (rc == GRANNE_HIP_OK) {
+            ixs.push_back(ix);
+            offs.push_back(lo);
+        }
+    }
+    granne_hip_sharded* sh = nullptr;
+    if (rc == GRANNE_HIP_OK) rc = granne_hip_sharded_create(&sh, ixs.data(), offs.data(), n_shards);
+    if (rc != GRANNE_HIP_OK) {
+        const std::string why = g_last_error; // (destroying the shards must not lose the message)
+        for (auto* ix : ixs) granne_hip_index_destroy(ix);
+        g_last_error = why;
+        return rc;
+    }
+    sh->owns_shards = true;
+    *out = sh;
+    return GRANNE_HIP_OK;
+}
+
+// the shard indexes of a handle (borrowed: they live as long as the handle when it owns them, else as long as their owner)
+extern "C" granne_hip_index* granne_hip_sharded_shard(const granne_hip_sharded* sh, uint32_t shard) {
+    return (sh && shard < sh->shards.size()) ? sh->shards[shard].ix : nullptr;
+}
+extern "C" uint64_t granne_hip_sharded_shard_offset(const granne_hip_sharded* sh, uint32_t shard) {
+    return (sh && shard < sh->shards.size()) ? sh->shards[shard].offset : 0;
 }
 
 extern "C" void granne_hip_sharded_destroy(granne_hip_sharded* sh) { sharded_free(sh); }

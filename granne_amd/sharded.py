@@ -316,6 +316,58 @@ class ShardedHost:
         if exchange is not None:
             self.set_option(SHARDED_OPT_EXCHANGE, exchange)
 
+    @classmethod
+    def build(cls, element_type, elements, n_shards, devices=(0,), depth=None, exchange=None, **config):
+        """granne_hip_sharded_build: the whole element set ([n, dim], prepared) split into n_shards id ranges, every shard
+        built with the GPU builder under `config` (GranneBuilder's keyword arguments: num_neighbors, max_search,
+        reinsert_elements, layer_multiplier, batch_max, batch_div) on devices[s // ceil(n_shards / len(devices))].
+        The handle owns its shard indexes."""
+        from ._lib import BuildConfig, SHARDED_OPT_DEPTH, SHARDED_OPT_EXCHANGE, check, lib
+        from .index import _ELEMENT_TYPES
+        et = element_type.lower()
+        if et not in _ELEMENT_TYPES:
+            raise ValueError("Invalid element type")
+        code, np_dtype = _ELEMENT_TYPES[et]
+        el = np.ascontiguousarray(elements, dtype=np_dtype)
+        if el.ndim != 2:
+            raise ValueError("elements must be [n, dim]")
+        cfg = BuildConfig()
+        lib().granne_hip_build_config_default(C.byref(cfg))
+        for key, value in config.items():
+            if not hasattr(cfg, key):
+                raise TypeError("unknown build option %r" % key)
+            setattr(cfg, key, type(getattr(cfg, key))(value))
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self = cls.__new__(cls)
+        self._lib, self._check = lib(), check
+        self.indexes = []  # the handle owns its shards
+        self._h = C.c_void_p()
+        check(lib().granne_hip_sharded_build(C.byref(self._h), C.byref(cfg), el.ctypes.data_as(C.c_void_p), el.shape[0],
+                                             el.shape[1], code, int(n_shards), devs, len(devices)))
+        self.device = int(lib().granne_hip_sharded_device(self._h))
+        self.dim, self.np_dtype = el.shape[1], np_dtype
+        if depth is not None:
+            self.set_option(SHARDED_OPT_DEPTH, depth)
+        if exchange is not None:
+            self.set_option(SHARDED_OPT_EXCHANGE, exchange)
+        return self
+
+    def num_shards(self):
+        return int(self._lib.granne_hip_sharded_num_shards(self._h))
+
+    def shard_offset(self, shard):
+        return int(self._lib.granne_hip_sharded_shard_offset(self._h, int(shard)))
+
+    def shard_layer(self, shard, layer):
+        """Layer `layer` of shard `shard` as a host [layer_len, 32 or 64] uint32 matrix (UNUSED padded): for inspection."""
+        ix = self._lib.granne_hip_sharded_shard(self._h, int(shard))
+        n = int(self._lib.granne_hip_index_layer_len(ix, int(layer)))
+        rows = np.full((n, 64), 0xFFFFFFFF, np.uint32)
+        cnt = C.c_uint32()
+        for i in range(n):
+            self._check(self._lib.granne_hip_index_get_neighbors(ix, i, int(layer), rows[i].ctypes.data_as(C.c_void_p), 64, C.byref(cnt)))
+        return rows
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.granne_hip_sharded_destroy(self._h)

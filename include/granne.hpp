@@ -226,6 +226,17 @@ public:
         check(granne_hip_sharded_create(&h, hs.data(), offsets.data(), (uint32_t)hs.size()));
         h_.reset(h, granne_hip_sharded_destroy); // destroyed before shards_ (declared after it): the handle borrows them
     }
+    // the whole element set in, a searchable partitioned index out (granne_hip_sharded_build): n_shards id ranges
+    // (src/elements/embeddings/parsing.rs:72-98), each built with the GPU builder under `config`; the handle owns its shards
+    static ShardedGranne build(const BuildConfig& config, const Elements& elements, size_t n_shards, const std::vector<int>& devices = {0}) {
+        using Scalar = typename decltype(Elements::Element::data)::value_type;
+        granne_hip_sharded* h = nullptr;
+        check(granne_hip_sharded_build(&h, &config.raw(), elements.as_slice(), elements.len(), (uint32_t)(elements.dim() ? elements.dim() : 1),
+                                       detail::dtype_of<Scalar>::value, (uint32_t)n_shards, devices.data(), (uint32_t)devices.size()));
+        ShardedGranne s;
+        s.h_.reset(h, granne_hip_sharded_destroy);
+        return s;
+    }
     size_t len() const { return granne_hip_sharded_len(h_.get()); }
     size_t num_shards() const { return granne_hip_sharded_num_shards(h_.get()); }
     // the exchange step as ONE RCCL all-gather over the shard devices instead of peer copies (librccl by dlopen)
@@ -238,7 +249,7 @@ public:
     // n_batches batches of nq queries each (elements: n_batches * nq of them), pipelined inside the library
     std::vector<std::vector<std::pair<size_t, float>>> search_batches(const Element* elements, size_t n_batches, size_t nq,
                                                                       size_t max_search, size_t num_neighbors) const {
-        const size_t total = n_batches * nq, dim = granne_hip_index_dim(shards_[0].raw());
+        const size_t total = n_batches * nq, dim = granne_hip_index_dim(granne_hip_sharded_shard(h_.get(), 0));
         std::vector<typename decltype(Element::data)::value_type> q(total * dim);
         for (size_t i = 0; i < total; ++i) {
             if (elements[i].len() != dim) throw std::runtime_error("query dimension mismatch");
@@ -256,7 +267,8 @@ public:
     }
 
 private:
-    std::vector<Granne<Elements>> shards_;
+    ShardedGranne() = default;
+    std::vector<Granne<Elements>> shards_; // empty when the handle owns its shards (build)
     std::shared_ptr<granne_hip_sharded> h_;
 };
 

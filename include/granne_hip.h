@@ -320,6 +320,9 @@ int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_index* const*
                               const uint64_t* id_offsets, uint32_t n_shards);
 void granne_hip_sharded_destroy(granne_hip_sharded* sharded);
 uint32_t granne_hip_sharded_num_shards(const granne_hip_sharded* sharded);
+/* shard s of the handle (borrowed) and the first global id it holds */
+granne_hip_index* granne_hip_sharded_shard(const granne_hip_sharded* sharded, uint32_t shard);
+uint64_t granne_hip_sharded_shard_offset(const granne_hip_sharded* sharded, uint32_t shard);
 uint64_t granne_hip_sharded_len(const granne_hip_sharded* sharded);
 int granne_hip_sharded_device(const granne_hip_sharded* sharded); /* where queries / results of the _device calls live */
 
@@ -430,6 +433,15 @@ int granne_hip_builder_get_layer(const granne_hip_builder* builder, uint32_t lay
  * layers (device-to-device copy; the builder stays usable). */
 int granne_hip_builder_get_index(const granne_hip_builder* builder, granne_hip_index** out);
 void granne_hip_builder_destroy(granne_hip_builder* builder);
+
+/* SURVEY.md 8b's `index_create(..., device_ids, n_devices, partitioned)` in one call: the whole element set (host rows,
+ * prepared like a Vectors file) is split into n_shards id ranges of ceil(n / n_shards) elements
+ * (src/elements/embeddings/parsing.rs:72-98), shard s is built with the GPU builder under `config`
+ * (GranneBuilder::new(config, shard).build()) on device_ids[s / ceil(n_shards / n_devices)], and the searchable
+ * partitioned index is returned. The handle OWNS its shard indexes (granne_hip_sharded_destroy releases them).      */
+int granne_hip_sharded_build(granne_hip_sharded** out, const granne_hip_build_config* config, const void* elements,
+                             uint64_t n_elements, uint32_t dim, int dtype, uint32_t n_shards,
+                             const int* device_ids, uint32_t n_devices);
 
 /* ---- options (per index) ---------------------------------------------------------------------- */
 enum {

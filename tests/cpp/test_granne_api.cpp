@@ -159,7 +159,16 @@ int main(int argc, char** argv) {
             REQUIRE(one.size() == want[3].size() && one[0].first == want[3][0].first);
             if (pass == 0) sharded.use_rccl_all_gather();
         }
-        std::printf("sharded: 3 shards, peer copies and RCCL all-gather agree with the merged per-shard searches\n");
+        // granne_hip_sharded_build: the same element set, split and built in one call (the same builder, the same ranges)
+        auto built = ShardedGranne<angular::Vectors>::build(BuildConfig().num_neighbors(16).max_search(30), all, G);
+        REQUIRE(built.len() == n && built.num_shards() == G);
+        auto again = built.search_batches(queries.data(), 4, 10, 40, 5);
+        for (size_t i = 0; i < queries.size(); ++i) {
+            REQUIRE(again[i].size() == want[i].size());
+            for (size_t j = 0; j < again[i].size(); ++j)
+                REQUIRE(again[i][j].first == want[i][j].first && again[i][j].second == want[i][j].second);
+        }
+        std::printf("sharded: 3 shards, peer copies and RCCL all-gather agree with the merged per-shard searches; sharded_build too\n");
     }
     std::printf("ok\n");
     return 0;

@@ -114,3 +114,5 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.granne_hip_sharded_set_option(None, 1, 2) == _lib.ERR_INVALID
     assert lib.granne_hip_sharded_get_option(None, 1, None) == _lib.ERR_INVALID
     assert lib.granne_hip_sharded_device(None) == -1
+    assert lib.granne_hip_sharded_build(None, None, p, 4, 8, 0, 2, None, 1) == _lib.ERR_INVALID
+    assert not lib.granne_hip_sharded_shard(None, 0) and lib.granne_hip_sharded_shard_offset(None, 0) == 0

@@ -216,3 +216,30 @@ def test_sharded_status_words_are_folded_on_the_device(oracle):
         w = _want(oixs, q[b], 60, 5, offsets)
         assert (h[0][b] == w[0]).all() and h[1][b].tobytes() == w[1].tobytes()
     sh.close()
+
+
+@pytest.mark.parametrize("int8", [False, True])
+def test_sharded_build_from_the_whole_element_set(oracle, int8):
+    """granne_hip_sharded_build (index_create with device_ids / n_devices / partitioned): the element set is
+    split into id ranges (src/elements/embeddings/parsing.rs:72-98), every shard built by the GPU builder. The shard graphs
+    equal the oracle's batched builds of the same ranges; searches equal per-shard oracle searches + the numpy merge."""
+    from granne_amd import sharded
+    rng = np.random.default_rng(94)
+    n, shards, k, ef = 3100, 3, 5, 40  # (3100 = 1034 + 1034 + 1032: the last range is shorter)
+    raw = random_floats(rng, n, 32)
+    el = oracle.quantize(raw) if int8 else oracle.normalize_f32(raw)
+    q = oracle.quantize(random_floats(rng, 30, 32)) if int8 else oracle.normalize_f32(random_floats(rng, 30, 32))
+    sh = sharded.ShardedHost.build("angular_int" if int8 else "angular", el, shards, devices=(0,), num_neighbors=12, max_search=30)
+    bounds = sharded.shard_bounds(n, shards)
+    assert sh.num_shards() == shards and len(sh) == n
+    assert [sh.shard_offset(s) for s in range(shards)] == [b[0] for b in bounds]
+    oixs = [oracle.build_index(np.ascontiguousarray(el[lo:hi]), num_neighbors=12, max_search=30, n_threads=0, batch_max=65536, batch_div=8)
+            for lo, hi in bounds]
+    bottom = len(oixs[1].layers) - 1
+    got = sh.shard_layer(1, bottom)
+    want = oixs[1].layers[bottom]
+    assert (got[:, :want.shape[1]] == want).all() and (got[:, want.shape[1]:] == 0xFFFFFFFF).all()
+    ids, ds, cnt = sh.search_batch(q, ef, k)
+    w = _want(oixs, q, ef, k, [b[0] for b in bounds])
+    assert (cnt == w[2]).all() and (ids == w[0]).all() and ds.tobytes() == w[1].tobytes()
+    sh.close()
