@@ -56,3 +56,17 @@ def test_traffic_in_profiles_is_stamped_with_the_current_kernel_sources():
         import pytest
         pytest.skip("profiles/pmc_traffic.json was measured on other kernel sources (%s != %s): retake the PMC passes "
                     "(tools/r3_prof.sh + tools/prof_to_traffic.py)" % (stamped[stale[0]], sha))
+
+
+def test_ground_truth_rows_merge_by_distance_then_id():
+    """bench.py's recall over a partitioned index: the per-shard exact top-k lists ([nq, shards * k] distances and global
+    ids) merged into the k smallest by (distance, id)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    nq, m, k = 40, 24, 10
+    d = rng.integers(0, 6, (nq, m)).astype(np.float32) / 8  # many ties on distance
+    ids = np.stack([rng.permutation(1000)[:m] for _ in range(nq)]).astype(np.int64)
+    gi, gd = bench._merge_rows_numpy(d, ids, k)
+    for q in range(nq):
+        want = sorted(zip(d[q].tolist(), ids[q].tolist()))[:k]
+        assert [(float(a), int(b)) for a, b in zip(gd[q], gi[q])] == want
