@@ -268,6 +268,10 @@ extern "C" int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_in
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, S.ix->device, sh->merge_device) == hipSuccess && can)
                     (void)hipDeviceEnablePeerAccess(sh->merge_device, 0); // already enabled is fine
+                DeviceGuard gm(sh->merge_device);
+                can = 0;
+                if (gm.ok && hipDeviceCanAccessPeer(&can, sh->merge_device, S.ix->device) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(S.ix->device, 0);
             }
         }
         // one all-gather needs equal contributions in rank order: shard s on device s / n_local
