@@ -115,13 +115,17 @@ def parse():
                          "the walker in the trace is then a timed-shape launch); prints a reduced line")
     ap.add_argument("--cpu-batches", type=int, default=16, help="batches of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=2.0, help="wall seconds the CPU baseline is timed over (repeats its sample)")
-    ap.add_argument("--c5-elements", type=int, default=125_000_000, help="elements of the c5_shard sub-record (0 = skip)")
+    ap.add_argument("--c5-elements", type=int, default=0,
+                    help="elements of the c5_shard sub-record (0 = skip, the default: the shard of BASELINE's configs[4] is "
+                         "--c5-elements 125000000 and adds ~110 s: build 80 s)")
     ap.add_argument("--c4-elements", type=int, default=12_500_000, help="elements of the c4_shard sub-record (0 = skip)")
     ap.add_argument("--no-partitioned", action="store_true", help="WORLD_SIZE > 1: skip the partitioned sub-record")
     ap.add_argument("--force-partitioned", action="store_true", help="take the partitioned sub-record with one rank too (tests)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--sweep-ef", default="50,100,200,400,800,1600,2048,4096", help="ef values of ef_sweep ('' = skip)")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--full-line", action="store_true", help="print the full record on stdout (default: the compact line; the "
+                    "full record goes to bench_extras.json and stderr)")
     ap.add_argument("--no-extras", action="store_true", help="skip the int8 / secondary / latency sub-records")
     ap.add_argument("--visited-slots", type=int, default=0,
                     help="GRANNE_HIP_OPT_VISITED_SLOTS: LDS visited-table slots per walker (0 = auto)")
@@ -1340,8 +1344,181 @@ def run_partitioned(B, args):
     return out
 
 
+LINE_LIMIT = 6000  # bytes of the stdout line (the driver keeps the last 8 KB of stdout)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short(s, n=160):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _finite(o):
+    """NaN / Infinity are not JSON: a strict parser on the other side must read the line."""
+    if isinstance(o, float):
+        return o if math.isfinite(o) else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def _compact_roofline(r):
+    if not isinstance(r, dict):
+        return r
+    c = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
+                  "alg_bytes_per_launch", "launch_ms_mean", "whole_timed_region_frac", "per_query"))
+    if "launch" in r:
+        c["launch"] = _pick(r["launch"], ("batches", "queries"))
+    if "one_batch_per_launch" in r:
+        c["one_batch_per_launch"] = _pick(r["one_batch_per_launch"], ("achieved", "frac", "alg_bytes_per_launch", "launch_ms_mean"))
+    if r.get("traffic") is None and "traffic_note" in r:
+        c["traffic_note"] = _short(r["traffic_note"], 120)
+    return c
+
+
+def _compact_cpu(cb):
+    if not isinstance(cb, dict):
+        return cb
+    c = _pick(cb, ("value", "unit", "cores", "kind"))
+    host = cb.get("host") or {}
+    if "cgroup_quota_cpus" in host:
+        c["quota_cpus"] = host["cgroup_quota_cpus"]
+    if "logical_cpus" in host:
+        c["host_logical_cpus"] = host["logical_cpus"]
+    if "single_thread" in cb:
+        c["single_thread"] = cb["single_thread"].get("value")
+    if "thread_sweep" in cb:
+        c["thread_sweep"] = {str(t["threads"]): t["value"] for t in cb["thread_sweep"]}
+    c["sample"] = _short(cb.get("sample", ""), 200)
+    g = cb.get("gpu_matches_oracle") or {}
+    c["gpu_matches_oracle"] = {"bit_exact": bool(g.get("ids_bit_exact") and g.get("dists_bit_exact")),
+                               "queries": g.get("queries_checked")}
+    return c
+
+
+def _compact_sub(rec):
+    """A sub-record on the line: {workload, value, frac, cpu, bit_exact} and the one-batch forms; the rest is in the side file."""
+    if not isinstance(rec, dict):
+        return rec
+    c = {"workload": _short(rec.get("workload", ""), 110)}
+    c.update(_pick(rec, ("value", "recall_at_10", "ef_search", "slow_path_queries", "wall_s")))
+    if isinstance(rec.get("roofline"), dict):
+        c["frac"] = rec["roofline"].get("frac")
+        c["traffic_over_algorithmic"] = rec["roofline"].get("traffic_over_algorithmic")
+        ob = rec["roofline"].get("one_batch_per_launch") or {}
+        c["frac_one_batch_per_launch"] = ob.get("frac")
+    for k in ("sequential", "one_batch_calls_in_flight", "steady"):
+        if isinstance(rec.get(k), dict):
+            c[k] = rec[k].get("value")
+    cb = rec.get("cpu_baseline")
+    if isinstance(cb, dict):
+        g = cb.get("gpu_matches_oracle") or {}
+        c["cpu"] = cb.get("value")
+        c["cpu_cores"] = cb.get("cores")
+        c["bit_exact"] = bool(g.get("ids_bit_exact") and g.get("dists_bit_exact"))
+        c["checked"] = g.get("queries_checked")
+    return c
+
+
+def compact_line(out, extras_path=None):
+    """The ONE stdout line: the contract's keys, `config`, `roofline`, `cpu_baseline` and a few figures per sub-record,
+    under LINE_LIMIT bytes whatever the full record holds (which goes to bench_extras.json and stderr)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "batches_per_call", "library_calls", "inflight_batches", "slow_path_queries", "recall_at_10",
+            "speedup_vs_cpu", "kernel_sources_sha")
+    line = _pick(out, keep)
+    cfg = dict(out.get("config") or {})
+    if "parallelism" in cfg:
+        cfg["parallelism"] = _short(cfg["parallelism"], 230)
+    if "graph" in cfg:
+        cfg["graph"] = _pick(cfg["graph"], ("builder", "num_neighbors", "max_search", "reinsert", "build_s", "reordered"))
+    line["config"] = cfg
+    for k in ("sequential", "one_batch_calls_in_flight", "steady"):
+        if isinstance(out.get(k), dict):
+            line[k] = _pick(out[k], ("value", "ms_per_step", "depth"))
+    if "roofline" in out:
+        line["roofline"] = _compact_roofline(out["roofline"])
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _compact_cpu(out["cpu_baseline"])
+    bf = out.get("brute_force")
+    if isinstance(bf, dict) and bf:
+        line["brute_force"] = _pick(bf, ("ms", "value", "frac", "bound", "peak", "unit"))
+    if isinstance(out.get("ef_sweep"), list):
+        line["ef_sweep"] = [[s.get("ef"), s.get("recall_at_10"), s.get("qps")] for s in out["ef_sweep"]]
+    if isinstance(out.get("latency_nq1"), dict):
+        line["latency_nq1_us"] = _pick(out["latency_nq1"], ("median", "p99"))
+    c1 = out.get("c1")
+    if isinstance(c1, dict):
+        m1 = c1.get("members_1024") or {}
+        line["c1"] = {"workload": _short(c1.get("workload", ""), 110), "value": m1.get("value"),
+                      "cpu": (m1.get("cpu_baseline") or {}).get("value"),
+                      "bit_exact": bool(c1.get("four_searches_equal_oracle_bit_for_bit")),
+                      "call_us": [s.get("call_us") for s in c1.get("four_searches", [])]}
+    for k in ("int8", "secondary", "c4_shard", "c5_shard", "partitioned"):
+        if k in out:
+            line[k] = _compact_sub(out[k])
+    for k in ("drivers",):  # (--mode partitioned)
+        if k in out:
+            line[k] = _short(json.dumps(out[k]), 300)
+    if extras_path:
+        line["full_record"] = extras_path
+    line = _finite(line)
+    # whatever a later edit adds: the line stays under the limit (drop the widest optional parts first)
+    for k in ("ef_sweep", "brute_force", "c1", "c5_shard", "c4_shard", "secondary", "int8", "partitioned", "latency_nq1_us", "steady"):
+        if len(json.dumps(line, allow_nan=False)) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return json.dumps(line, allow_nan=False)
+
+
+def write_extras(out):
+    """The full record: next to the script, under gpurun_out/ when that exists (it travels back from a GPU box), and on stderr."""
+    text = json.dumps(_finite(out), allow_nan=False)
+    here = os.path.dirname(os.path.abspath(__file__))
+    wrote = None
+    for d in (here, os.path.join(here, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_extras.json"), "w") as f:
+                    f.write(text + "\n")
+                wrote = wrote or "bench_extras.json"
+            except OSError:
+                pass
+    log("full record: " + text)
+    return wrote
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here (one process per GPU over
+    RCCL), exactly as the driver's torch.distributed.run line would."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s): refusing to report an %d-GPU number from fewer devices\n"
+                         % (args.gpus, have, args.gpus))
+        sys.exit(2)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])
     # stdout carries exactly ONE line (the JSON): anything libraries print meanwhile (RCCL's version
     # banner, progress output) is routed to stderr by pointing fd 1 at fd 2 until the very end
     sys.stdout.flush()
@@ -1350,9 +1527,10 @@ def main():
     B = Bench(args)
     out = run_partitioned(B, args) if args.mode == "partitioned" else run_replica(B, args)
     if B.rank == 0:
+        extras = write_extras(out)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(_finite(out), allow_nan=False) if args.full_line else compact_line(out, extras), flush=True)
         os.dup2(2, 1)
     if B.use_dist:
         B.dist.barrier()

@@ -70,3 +70,76 @@ def test_ground_truth_rows_merge_by_distance_then_id():
     for q in range(nq):
         want = sorted(zip(d[q].tolist(), ids[q].tolist()))[:k]
         assert [(float(a), int(b)) for a, b in zip(gd[q], gi[q])] == want
+
+
+def _fake_full_record():
+    """A record with every part the r4 line carried (profiles/r4_bench_default.json, 26 KB), and worse: long notes, a NaN."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r4_bench_default.json")) as f:
+        d = json.load(f)
+    d["c5_shard"] = dict(d["c4_shard"])
+    d["partitioned"] = dict(d["c4_shard"])
+    d["cpu_baseline"]["sample"] = "x" * 4000
+    d["config"]["parallelism"] = "y" * 3000
+    d["roofline"]["whole_timed_region_frac"] = float("nan")
+    d["steady"]["value"] = float("inf")
+    return d
+
+
+def test_stdout_line_stays_under_the_drivers_tail_and_parses_strictly():
+    """The driver keeps the last 8 KB of stdout and parses ONE JSON line from it (round 4's 26 KB line came back
+    `parsed: null`)."""
+    import json
+    line = bench.compact_line(_fake_full_record(), "bench_extras.json")
+    assert len(line.encode()) < 8192 and len(line.encode()) <= bench.LINE_LIMIT and "\n" not in line
+
+    def no_constants(x):
+        raise ValueError("not JSON: " + x)
+    d = json.loads(line, parse_constant=no_constants)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["config"]["workload"].startswith("C2")
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "one_batch_per_launch"):
+        assert key in d["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert d["roofline"]["whole_timed_region_frac"] is None and d["steady"]["value"] is None  # (NaN / inf never reach the line)
+    for sub in ("int8", "secondary", "c4_shard", "c5_shard"):
+        assert {"workload", "value", "frac", "cpu", "bit_exact"} <= set(d[sub]), sub
+    # and a record far beyond anything bench.py produces still fits: optional parts are dropped, the contract stays
+    big = _fake_full_record()
+    big["ef_sweep"] = big["ef_sweep"] * 40
+    big["config"]["layers"] = list(range(400))
+    line = bench.compact_line(big, None)
+    assert len(line.encode()) <= bench.LINE_LIMIT
+    d = json.loads(line, parse_constant=no_constants)
+    assert "roofline" in d and "cpu_baseline" in d and "value" in d
+
+
+def test_gpus_n_without_a_launcher_never_measures_one_gpu_silently():
+    """`python bench.py --gpus 8` with WORLD_SIZE unset starts the ranks itself (torch.distributed.run); on a node with
+    fewer GPUs it refuses (exit 2) instead of reporting a one-GPU number under n_gpus 8."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+    # the launch line itself
+    seen = {}
+
+    def fake_exec(file, argv, env):
+        seen["argv"] = argv
+        raise SystemExit(0)
+    real, real_count = os.execvpe, torch.cuda.device_count
+    os.execvpe, torch.cuda.device_count = fake_exec, lambda: 8
+    try:
+        with pytest.raises(SystemExit):
+            bench.self_launch(types.SimpleNamespace(gpus=8), ["--gpus", "8", "--steps", "20", "--warmup", "5"])
+    finally:
+        os.execvpe, torch.cuda.device_count = real, real_count
+    a = seen["argv"]
+    assert a[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and a[a.index("--nproc-per-node") + 1] == "8"
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
