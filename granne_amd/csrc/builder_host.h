@@ -409,7 +409,7 @@ static int index_elements_in_last_layer(granne_hip_builder* b, uint64_t max_num_
             h[l].adj = b->layers[l].d_adj;
             h[l].len = b->layers[l].len;
             h[l].width = b->W;
-            h[l].pad_ = 0;
+            h[l].flags = 0; // connect_nodes never lists a neighbor twice (mod.rs:913-917)
         }
         HIP_TRY(hipMalloc((void**)&S.d_layers, sizeof(LayerDev) * h.size()));
         HIP_TRY(hipMemcpyAsync(S.d_layers, h.data(), sizeof(LayerDev) * h.size(), hipMemcpyHostToDevice, s));

@@ -232,12 +232,33 @@ static int upload_elements_from_device(granne_hip_index* ix, const void* d_src, 
 static int finish_layers(granne_hip_index* ix, hipStream_t s) {
     std::vector<LayerDev> h(ix->layers.size());
     ix->max_dev_width = 32;
+    // rows that name a neighbor twice (LAYER_TWIN_ROWS, walk_fast.h): looked for once, here, on the device rows
+    uint32_t* d_found = nullptr;
+    std::vector<uint32_t> found(h.size(), 0u);
+    if (!h.empty()) {
+        HIP_TRY(hipMalloc((void**)&d_found, h.size() * 4));
+        if (hipMemsetAsync(d_found, 0, h.size() * 4, s) != hipSuccess) {
+            (void)hipFree(d_found);
+            return fail(GRANNE_HIP_ERR_HIP, "hipMemsetAsync failed");
+        }
+    }
     for (size_t l = 0; l < ix->layers.size(); ++l) {
         h[l].adj = ix->layers[l].d_adj;
         h[l].len = ix->layers[l].len;
         h[l].width = ix->layers[l].dev_width;
-        h[l].pad_ = 0;
+        h[l].flags = 0;
         if (ix->layers[l].dev_width > ix->max_dev_width) ix->max_dev_width = ix->layers[l].dev_width;
+        if (h[l].len && h[l].width <= 64)
+            hipLaunchKernelGGL(twin_rows_kernel, dim3(grid_for(h[l].len * 64, 256)), dim3(256), 0, s, h[l].adj, h[l].len,
+                               h[l].width, d_found + l);
+    }
+    if (!h.empty()) {
+        hipError_t e = hipMemcpyAsync(found.data(), d_found, h.size() * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(d_found);
+        if (e != hipSuccess) return fail(GRANNE_HIP_ERR_HIP, "twin_rows_kernel: %s", hipGetErrorString(e));
+        for (size_t l = 0; l < h.size(); ++l)
+            if (found[l]) h[l].flags |= LAYER_TWIN_ROWS;
     }
     size_t bytes = sizeof(LayerDev) * (h.size() ? h.size() : 1);
     HIP_TRY(hipMalloc((void**)&ix->d_layers, bytes));

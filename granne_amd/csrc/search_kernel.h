@@ -34,8 +34,9 @@ struct LayerDev {
     const uint32_t* adj; // [len][width] u32, UNUSED-padded, valid ids first
     uint64_t len;
     uint32_t width;      // device row width (multiple of 32 -> rows are 128-byte aligned)
-    uint32_t pad_;
+    uint32_t flags;      // LAYER_*
 };
+constexpr uint32_t LAYER_TWIN_ROWS = 1u; // some row names a neighbor twice (no builder of the reference makes such rows; a foreign file may hold them)
 
 // one batch of a launch that serves several (SearchParams::batch)
 constexpr uint32_t MAX_LAUNCH_BATCHES = 32;

@@ -54,6 +54,24 @@ __global__ void check_adj_kernel(const uint32_t* __restrict__ rows, uint64_t tot
     if (mine) atomicAdd(bad, mine);
 }
 
+// Does some row of a layer name a neighbor twice? (No builder of the reference writes such a row, mod.rs:913-917; a foreign
+// file may hold one.) The register walker ranks an expansion's candidates against each other and needs to know whether two
+// lanes can hold one node (walk_fast.h, LAYER_TWIN_ROWS). One wavefront per row of W <= 64 ids (wider layers are not the
+// register walker's): lane i holds id i and meets the ids at distance 1..W/2 by rotation.
+__global__ void twin_rows_kernel(const uint32_t* __restrict__ adj, uint64_t len, uint32_t W, uint32_t* __restrict__ found) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    bool hit = false;
+    for (uint64_t row = wave; row < len; row += waves) {
+        const uint32_t mine = lane < W ? adj[row * W + lane] : 0xFFFFFFFFu;
+        for (uint32_t o = 1; o <= W / 2u; ++o) {
+            const uint32_t other = (uint32_t)__shfl((int)mine, (int)((lane + o) % W), 64);
+            hit = hit || (lane < W && mine != 0xFFFFFFFFu && mine == other);
+        }
+    }
+    if (__ballot(hit) && lane == 0) atomicOr(found, 1u);
+}
+
 // CSR adjacency -> [len][W], UNUSED padded
 __global__ void csr_to_adj_kernel(const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ ids,
                                   uint32_t* __restrict__ dst, uint64_t len, uint32_t W) {

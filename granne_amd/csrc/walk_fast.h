@@ -48,7 +48,7 @@ namespace granne_hip {
 #define GRANNE_HIP_PHASE_TIMERS 0
 #endif
 #if GRANNE_HIP_PHASE_TIMERS
-constexpr uint32_t PHASE_SLOTS = 32, PHASE_QUERIES = 4096;
+constexpr uint32_t PHASE_SLOTS = 48, PHASE_QUERIES = 4096;
 __device__ uint64_t g_phase[PHASE_QUERIES * PHASE_SLOTS];
 #define PT_MARK(i)                                                                   \
     do {                                                                             \
@@ -88,6 +88,7 @@ __device__ __forceinline__ uint32_t wkey_hi(uint64_t k) { return (uint32_t)(k >>
 __device__ __forceinline__ uint32_t wkey_id(uint64_t k) { return ((uint32_t)k) >> 1; }
 __device__ __forceinline__ float wkey_dist(uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); }
 constexpr uint32_t WPOS_NONE = 0xFFFFFFFFu;
+constexpr uint32_t VCACHE_SLOTS = 512; // FastWalker::vcache (power of two, 2 KB of LDS per walker)
 constexpr uint64_t WALK_MAX_ELEMENTS = 1ull << 31; // ids must fit 31 bits
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) { // set bits of m below this lane
@@ -112,39 +113,6 @@ struct WalkList : SortedList<S> {
     using SortedList<S>::key;
     static constexpr uint32_t CAP = 64u * S;
 
-    // Insert K (wave-uniform, not in the list): the entries that sort after it move up one place, the last one
-    // falls off. No rank, no scalar round trip: entry e keeps its key when that is below K, else it takes
-    // max(key of entry e-1, K) -- which is K exactly at the insertion point. Returns the distance bits of what
-    // fell off the end (K itself when every entry is below it; 0xFFFFFFFF for an unused place).
-    __device__ __forceinline__ uint32_t insert_sorted(uint64_t K, uint32_t lane) {
-        const uint32_t last_hi = readlane32(wkey_hi(key[S - 1]), 63);
-        const uint32_t k_hi = wkey_hi(K);
-        const uint32_t lost = last_hi > k_hi ? last_hi : k_hi; // = high word of max(last entry, K)
-#pragma unroll
-        for (int s = S - 1; s >= 0; --s) {
-            uint32_t up_lo = from_prev_lane_or_zero((uint32_t)key[s]);
-            uint32_t up_hi = from_prev_lane_or_zero((uint32_t)(key[s] >> 32));
-            if (s > 0) {
-                const uint64_t carry = readlane64(key[s - 1], 63);
-                if (lane == 0) {
-                    up_lo = (uint32_t)carry;
-                    up_hi = (uint32_t)(carry >> 32);
-                }
-            }
-            const uint64_t up = ((uint64_t)up_hi << 32) | up_lo;
-            const uint64_t t = (up < K) ? K : up;
-            key[s] = (key[s] < K) ? key[s] : t;
-        }
-        return lost;
-    }
-
-    // is node `id` (wave-uniform) in the list, at any of its CAP places? (an unused place reads 0x7FFFFFFF: no node's id)
-    __device__ __forceinline__ bool holds(uint32_t id) const {
-        bool hit = false;
-#pragma unroll
-        for (int s = 0; s < S; ++s) hit = hit || (((uint32_t)key[s]) >> 1) == id;
-        return wave_ballot(hit) != 0;
-    }
     // Lists of 33 / 65 slots (LONG): everything before `fu_lb` is expanded -- a lower bound of the first unexpanded entry's
     // position, kept across expansions (mark_expanded never breaks it; a merge lowers it to the smallest place a
     // candidate took) -- so the search reads the mirror from there, 64 keys at a time, instead of asking every slot.
@@ -184,12 +152,13 @@ struct WalkList : SortedList<S> {
         for (int s = 0; s < S; ++s) c += (uint32_t)__popcll(wave_ballot(wkey_hi(key[s]) < dbits));
         return c;
     }
-    // Reading entry e (wave-uniform index) out of the registers means selecting a register by a run-time
-    // slot. Short lists do it with a tree of uniform branches (two readlanes at the leaf). Long lists
-    // (S >= 8) keep a mirror of the list in LDS -- the scatter space of the bulk merge, which holds exactly
-    // the list after every merge -- and read the entry from there: one broadcast ds_read instead of 4*S
-    // scalar selects. The mirror is kept in step by init / set_first / mark_expanded / merge.
+    // Every list has an image in LDS (`mir`): lists of up to 17 slots merge through it (FastWalker::merge_ranked: CAP keys +
+    // 32 places for what an expansion's candidates push off the end) and it holds exactly the list after every merge and
+    // every flag change; the long lists' bulk merge scatters through it too. Reading entry e (wave-uniform index) out of
+    // the registers means selecting a register by a run-time slot: short lists do it with a tree of uniform branches (two
+    // readlanes at the leaf), lists of S >= 8 read the image: one broadcast ds_read instead of 4*S scalar selects.
     static constexpr bool MIRROR = S >= 8;
+    static constexpr uint32_t IMAGE_KEYS = CAP + (S >= 33 ? 0u : 32u);
     uint64_t* mir;
     template <int LO, int HI>
     __device__ __forceinline__ uint64_t get_rec(uint32_t slot, uint32_t l) const {
@@ -210,24 +179,12 @@ struct WalkList : SortedList<S> {
             return get_rec<0, S>(e >> 6, e & 63u);
         }
     }
-    template <int LO, int HI>
-    __device__ __forceinline__ void mark_rec(uint32_t slot, bool mine) {
-        if constexpr (HI - LO == 1) {
-            if (mine) key[LO] |= 1ull;
-        } else {
-            constexpr int MID = (LO + HI) / 2;
-            if (slot < (uint32_t)MID) mark_rec<LO, MID>(slot, mine);
-            else mark_rec<MID, HI>(slot, mine);
-        }
-    }
     // set the expanded flag of entry pos, whose key is x
     __device__ __forceinline__ void mark_expanded(uint32_t pos, uint64_t x, uint32_t lane) {
-        if constexpr (MIRROR) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) key[s] |= ((uint32_t)s * 64u + lane == pos) ? 1ull : 0ull;
+        for (int s = 0; s < S; ++s) key[s] |= ((uint32_t)s * 64u + lane == pos) ? 1ull : 0ull;
+        if constexpr (MIRROR) {
             if (lane == 0) mir[pos] = x | 1ull;
-        } else {
-            mark_rec<0, S>(pos >> 6, lane == (pos & 63u));
         }
     }
     __device__ __forceinline__ void init_list(uint64_t* mirror, uint32_t lane) {
@@ -236,14 +193,14 @@ struct WalkList : SortedList<S> {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             key[s] = KEY_INF;
-            if constexpr (MIRROR) mir[(uint32_t)s * 64u + lane] = KEY_INF;
+            mir[(uint32_t)s * 64u + lane] = KEY_INF; // the image holds the list from the start
         }
     }
     // the first entry of an empty list
     __device__ __forceinline__ void set_first(uint64_t k0, uint32_t lane) {
         if (lane == 0) {
             key[0] = k0;
-            if constexpr (MIRROR) mir[0] = k0;
+            mir[0] = k0;
         }
     }
     // position of the n-th (n >= 1) expanded real entry, WPOS_NONE when there are fewer
@@ -309,6 +266,7 @@ struct FastWalker {
     static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u * NBI;
     static_assert(F32 || DIM == 0 || DIM == 256 || DIM == 512, "fast int8 rows: 128, 256 or 512 bytes");
     static constexpr uint32_t CAP = 64u * S;
+    static constexpr bool LONG_LIST = S >= 33;
     static constexpr int NT = ROWB ? (int)((ROWB + 255u) / 256u) : 1; // TOUCH: lines of a row per lane of its pair
     static_assert(!F32 || GEN || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
@@ -317,6 +275,7 @@ struct FastWalker {
     uint8_t* lds_q;       // the query (f32 without QREG: read per expansion; i8: staging, shared with the visited table)
     uint64_t* mslot;      // lists with an LDS mirror (S >= 8): CAP keys, the mirror = the scatter space of the bulk merge
     uint32_t* vis_tab;
+    uint32_t* vcache;     // NOVIS, lists of up to 17 slots: ids that entered the list (a direct-mapped cache, see seen_before)
     float qh[QREG ? NB * 16 : 1];
     float qt[(QREG && TU) ? TU * 4 : 1];
     uint4 qi8[F32 ? 1 : 4 * NBI]; // i8: bytes 64h..64h+63 of every 128-byte block of the query
@@ -336,7 +295,7 @@ struct FastWalker {
     bool bail;
     uint32_t theta; // distance bits of list entry max_search-1 (0xFFFFFFFF while the list is shorter): kept by insert()
 #if GRANNE_HIP_PHASE_TIMERS
-    uint64_t pt_b[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_u[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last = 0, pt_t0 = 0;
+    uint64_t pt_b[16] = {}, pt_u[16] = {}, pt_last = 0, pt_t0 = 0;
     uint32_t pt_nb = 0, pt_nu = 0, pt_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool pt_bottom = false;
 #endif
@@ -351,7 +310,8 @@ struct FastWalker {
         g_tu = ((p.dim & 31u) + 3u) / 4u;
         lds_q = smem;
         mslot = reinterpret_cast<uint64_t*>(smem + qb);
-        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + (WalkList<S>::MIRROR ? CAP * 8u : 0u));
+        vcache = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u);
+        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u + (LONG_LIST ? 0u : VCACHE_SLOTS * 4u));
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
         sy = 0.0f;
@@ -487,9 +447,12 @@ struct FastWalker {
             }
             d = angular_from_dot(r);
         } else if constexpr (F32) {
-            float acc[16];
+            // the 16 accumulators of this lane, two to a register pair: v_pk_fma_f32 applies a chunk's 16 fused
+            // multiply-adds in 8 instructions -- each half is the same IEEE fma as the scalar form (math.rs:20-25)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 acc2[8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+            for (int j = 0; j < 8; ++j) acc2[j] = f32x2{0.0f, 0.0f};
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
 #pragma unroll
@@ -502,12 +465,13 @@ struct FastWalker {
                         const float4 qq = *reinterpret_cast<const float4*>(lds_q + b * 128 + h * 64u + k * 16);
                         q0 = qq.x; q1 = qq.y; q2 = qq.z; q3 = qq.w;
                     }
-                    acc[k * 4 + 0] = __builtin_fmaf(rr.v[b][k].x, q0, acc[k * 4 + 0]);
-                    acc[k * 4 + 1] = __builtin_fmaf(rr.v[b][k].y, q1, acc[k * 4 + 1]);
-                    acc[k * 4 + 2] = __builtin_fmaf(rr.v[b][k].z, q2, acc[k * 4 + 2]);
-                    acc[k * 4 + 3] = __builtin_fmaf(rr.v[b][k].w, q3, acc[k * 4 + 3]);
+                    acc2[k * 2 + 0] = __builtin_elementwise_fma(f32x2{rr.v[b][k].x, rr.v[b][k].y}, f32x2{q0, q1}, acc2[k * 2 + 0]);
+                    acc2[k * 2 + 1] = __builtin_elementwise_fma(f32x2{rr.v[b][k].z, rr.v[b][k].w}, f32x2{q2, q3}, acc2[k * 2 + 1]);
                 }
             }
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[2 * j] = acc2[j].x; acc[2 * j + 1] = acc2[j].y; }
             // ordered sum: even lane 0.0 + acc[0] + ... + acc[15]; odd lane continues with its 16
             float s = 0.0f;
 #pragma unroll
@@ -548,52 +512,6 @@ struct FastWalker {
             d = (0.0f <= t) ? t : 0.0f;
         }
         return d;
-    }
-
-    // insert the candidates of the lanes in pm (bulk): every list entry counts the candidates
-    // below it, every candidate its rank in the list plus its rank among the candidates; the keys
-    // are scattered to their final places through LDS and the first CAP read back.
-    __device__ __forceinline__ void merge(uint64_t pm, uint32_t m, bool pass, uint64_t ck, uint32_t ef) {
-        uint32_t above[S]; // list entries: candidates that sort after my key
-#pragma unroll
-        for (int s = 0; s < S; ++s) above[s] = 0;
-        uint32_t mypos = 0;
-        for (uint64_t it = pm; it; it &= it - 1) {
-            const uint32_t src = (uint32_t)__builtin_ctzll(it);
-            const uint64_t K = readlane64(ck, src);
-            uint32_t pos = (uint32_t)__popcll(wave_ballot(pass && ck < K));
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const bool below = L.key[s] < K;
-                above[s] += below ? 1u : 0u;
-                pos += (uint32_t)__popcll(wave_ballot(below));
-            }
-            if (lane == src) mypos = pos;
-        }
-        uint32_t lostd[S]; // dist bits of a real entry pushed off the end, else 0xFFFFFFFF
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const uint32_t newpos = (uint32_t)s * 64u + lane + (m - above[s]);
-            const uint64_t mine = L.key[s];
-            if (newpos < CAP) mslot[newpos] = mine;
-            lostd[s] = (newpos >= CAP) ? wkey_hi(mine) : 0xFFFFFFFFu;
-        }
-        if (pass && mypos < CAP) mslot[mypos] = ck;
-        const uint32_t lostc = (pass && mypos >= CAP) ? wkey_hi(ck) : 0xFFFFFFFFu;
-        asm volatile("" ::: "memory"); // one wave: LDS executes its accesses in program order
-#pragma unroll
-        for (int s = 0; s < S; ++s) L.key[s] = mslot[(uint32_t)s * 64u + lane];
-        asm volatile("" ::: "memory");
-        bool any = lostc != 0xFFFFFFFFu;
-#pragma unroll
-        for (int s = 0; s < S; ++s) any = any || lostd[s] != 0xFFFFFFFFu;
-        if (wave_ballot(any)) {
-            const uint32_t kth = wkey_hi(L.at(ef - 1));
-            bool tie = lostc == kth;
-#pragma unroll
-            for (int s = 0; s < S; ++s) tie = tie || lostd[s] == kth;
-            if (wave_ballot(tie && kth != 0xFFFFFFFFu)) bail = true;
-        }
     }
 
     // ---- lists of 33 / 65 slots (max_search 1025..4096) -----------------------------------------------------------------
@@ -676,94 +594,193 @@ struct FastWalker {
         if (wave_ballot(lost != 0xFFFFFFFFu && lost == theta && theta != 0xFFFFFFFFu)) bail = true;
     }
 
-    // mod.rs:1029 for the candidates of one expansion (`cand` lanes hold a distance): which of them enter the list
-    __device__ __forceinline__ bool filter(bool cand, float d, uint32_t ef) {
-        const uint32_t dbits = __float_as_uint(d);
-        // `res` does not change during an expansion, so neither do the two thresholds:
-        //   theta = dist of entry max_search-1; a candidate beyond it has max_search entries strictly closer: dead;
-        //   worst = res.peek().dist = dist of the max_search-th EXPANDED entry (mod.rs:1029), >= theta.
-        // d <= theta < worst needs no second look; only a candidate that ties with theta can still fail
-        // `d < worst`, and only then is the max_search-th expanded entry looked up.
-        bool pass = cand;
-        if (theta != 0xFFFFFFFFu) {
-            pass = pass && dbits <= theta;
-            if (wave_ballot(pass && dbits == theta)) {
-                const uint32_t w = L.nth_expanded(ef); // res.peek(): the max_search-th popped node
-                if (w != WPOS_NONE) pass = pass && dbits < wkey_hi(L.at(w));
-            }
+    // ---- lists of up to 17 slots: every candidate of an expansion ranked at once, ONE pass through the LDS image -----------
+    // pq.push (mod.rs:1030) of an expansion's candidates and the choice of the node expanded next, without one insert per
+    // candidate. The loop below visits the candidates that passed the filter once each (K = a candidate's key, wave-uniform):
+    //   * the list holds K's node already (a revisit: same node, same distance, so the same key up to the flag) -> it leaves;
+    //   * every list entry above K counts it (`shift`), K's own rank is the number of entries below it;
+    //   * every other candidate above K counts it (`below`);
+    // nothing in the loop waits for a scalar decision except the look-up's branch. Then entry e goes to place e + shift,
+    // candidate c to rank + below, all through one scatter into the image and one read back; what lands on place CAP is
+    // the smallest key pushed off the end (the tie test of the file comment reads its distance, entry max_search-1 is read
+    // from the same image). The candidate with below == 0 is the smallest: it is expanded next iff its rank is at most the
+    // position of the first unexpanded entry y (#{entries < K} <= pos(y)  <=>  K < y) -- known BEFORE the scatter, so its
+    // adjacency row is requested under the merge, and it enters the list with its flag already set.
+    // Without a visited set about half of the candidates that pass the filter are revisits: nodes the list holds already,
+    // found there by rank_one at the price of a loop trip each. A direct-mapped cache of the ids that entered the list
+    // (VCACHE_SLOTS words of LDS, one look-up for all 32 neighbors under the row loads) takes most of them out before the
+    // loop: a hit means "this node entered the list earlier in this walk of the layer", i.e. the reference's visited set
+    // holds it and skips it (mod.rs:1026); a miss (never entered, or evicted by a colliding id) means nothing -- the
+    // candidate goes the exact way. Results do not depend on the cache.
+    __device__ __forceinline__ static uint32_t vcache_slot(uint32_t id) { return (id ^ (id >> 9)) & (VCACHE_SLOTS - 1u); }
+    __device__ __forceinline__ void vcache_reset(uint32_t first_id) {
+        if constexpr (NOVIS && !LONG_LIST) {
+            uint4* t4 = reinterpret_cast<uint4*>(vcache);
+            const uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
+            for (uint32_t i = lane; i < VCACHE_SLOTS / 4u; i += 64) t4[i] = e;
+            asm volatile("" ::: "memory");
+            if (lane == 0) vcache[vcache_slot(first_id)] = first_id;
         }
-        return pass;
     }
 
-    // Without a visited set, lists merged in bulk: of the candidates that passed the filter, drop the ones whose id the
-    // list holds -- all CAP entries, expanded or not -- and the second of two lanes with one id (a row that names a
-    // neighbor twice). (Short lists look a candidate up right before inserting it: insert(), and the next-node decision.)
-    __device__ __forceinline__ uint64_t drop_known(uint64_t pm, bool pass, uint32_t nb) const {
-        for (uint64_t it = pm; it; it &= it - 1) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(it);
-            const uint32_t id = readlane32(nb, j);
-            if (L.holds(id) || wave_ballot(pass && nb == id && lane < j)) pm &= ~(1ull << j);
+    struct Ranked {
+        uint32_t shift[S]; // list entries: candidates that sort before my key
+        uint32_t rankv;    // candidate lanes: entries of the list below my key
+        uint32_t below;    // candidate lanes: candidates below my key
+    };
+
+    // One candidate of the loop below (`it` is not empty). What a lone wavefront pays for (tools/ubench.hip): ~4 clocks
+    // per instruction, scalar ones included; ~20 for a taken branch; and ~16 more whenever a SCALAR instruction consumes
+    // what a VECTOR one produced (a v_cmp's mask, a v_readlane's value) -- the other direction is free. So nothing scalar
+    // here reads a vector result: the scalar chain (which lane is next) runs ahead on its own, the rank is counted by
+    // v_bcnt on the vector side from the compare's mask and lands in the candidate's lane through a select.
+    template <bool TWINS>
+    __device__ __forceinline__ void rank_one(uint64_t& it, uint64_t& passm, const uint32_t ck_lo, const uint32_t ck_hi,
+                                             const uint64_t ck, Ranked& rk) const {
+        const uint32_t j = (uint32_t)__builtin_ctzll(it);
+        const uint64_t bit = 1ull << j;
+        it &= it - 1;
+        const uint32_t k_lo = readlane32(ck_lo, j), k_hi = readlane32(ck_hi, j);
+        const uint64_t K = ((uint64_t)k_hi << 32) | k_lo;
+        if constexpr (TWINS) { // the second lane of a row that names this node twice leaves with this one
+            const uint64_t twins = wave_ballot(ck_lo == k_lo) & it;
+            it &= ~twins;
+            passm &= ~twins;
         }
-        return pm;
+        uint32_t above = 0; // entries above K, counted in every lane
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool g = L.key[s] > K;
+            rk.shift[s] += g ? 1u : 0u;
+            const uint64_t gm = wave_ballot(g);
+            uint32_t g_lo = (uint32_t)gm, g_hi = (uint32_t)(gm >> 32);
+            asm("" : "+v"(g_lo));
+            asm("" : "+v"(g_hi)); // (in vector registers: the counts are v_bcnt's, not s_bcnt1's)
+            above += (uint32_t)__builtin_popcount(g_lo) + (uint32_t)__builtin_popcount(g_hi);
+        }
+        rk.rankv = __builtin_amdgcn_inverse_ballot_w64(bit) ? above : rk.rankv;
+        rk.below += (ck > K) ? 1u : 0u;
     }
 
-    // pq.push (mod.rs:1030) of the lanes in pm. Short lists take the candidates one at a time (insert_sorted:
-    // a dozen vector operations each, nothing scalar in the chain); lists that keep an LDS mirror are merged
-    // in bulk. An entry pushed off the end is dead unless its distance ties with the entry that is number
-    // max_search-1 once all candidates of the expansion are in (then max_search entries are not STRICTLY
-    // closer): the smallest lost distance is compared with that entry once, after the last insert.
-    __device__ __forceinline__ void insert(uint64_t pm, bool pass, uint64_t ck, uint32_t ef) {
-        const uint32_t m = (uint32_t)__popcll(pm);
-        if (m == 0) return;
-        if constexpr (WalkList<S>::MIRROR) {
-            merge(pm, m, pass, ck, ef);
-            theta = wkey_hi(L.at(ef - 1));
-            return;
+    // Two candidates at once (`it` holds at least two): the same operations as two rank_one, written side by side so that
+    // the wait states between a compare and the use of its mask, and between a v_readlane and the use of its value, are
+    // filled by the other candidate's instructions.
+    __device__ __forceinline__ void rank_two(uint64_t& it, const uint32_t ck_lo, const uint32_t ck_hi, const uint64_t ck, Ranked& rk) const {
+        const uint32_t ja = (uint32_t)__builtin_ctzll(it);
+        it &= it - 1;
+        const uint32_t jb = (uint32_t)__builtin_ctzll(it);
+        it &= it - 1;
+        const uint64_t bit_a = 1ull << ja, bit_b = 1ull << jb;
+        const uint32_t a_lo = readlane32(ck_lo, ja), a_hi = readlane32(ck_hi, ja);
+        const uint32_t b_lo = readlane32(ck_lo, jb), b_hi = readlane32(ck_hi, jb);
+        const uint64_t Ka = ((uint64_t)a_hi << 32) | a_lo, Kb = ((uint64_t)b_hi << 32) | b_lo;
+        uint32_t above_a = 0, above_b = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool ga = L.key[s] > Ka, gb = L.key[s] > Kb;
+            const uint64_t gma = wave_ballot(ga), gmb = wave_ballot(gb);
+            uint32_t a0 = (uint32_t)gma, a1 = (uint32_t)(gma >> 32), b0 = (uint32_t)gmb, b1 = (uint32_t)(gmb >> 32);
+            asm("" : "+v"(a0));
+            asm("" : "+v"(b0));
+            asm("" : "+v"(a1));
+            asm("" : "+v"(b1));
+            rk.shift[s] += (ga ? 1u : 0u) + (gb ? 1u : 0u);
+            above_a += (uint32_t)__builtin_popcount(a0) + (uint32_t)__builtin_popcount(a1);
+            above_b += (uint32_t)__builtin_popcount(b0) + (uint32_t)__builtin_popcount(b1);
         }
-        uint32_t lost = 0xFFFFFFFFu;
-        for (uint64_t it = pm; it; it &= it - 1) {
-            const uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(it));
-            if constexpr (NOVIS) { // in the list already (a revisit, or the row names the node twice): not a candidate
-                if (L.holds(wkey_id(K))) continue;
+        rk.rankv = __builtin_amdgcn_inverse_ballot_w64(bit_a) ? above_a : rk.rankv;
+        rk.rankv = __builtin_amdgcn_inverse_ballot_w64(bit_b) ? above_b : rk.rankv;
+        rk.below += ((ck > Ka) ? 1u : 0u) + ((ck > Kb) ? 1u : 0u);
+    }
+
+    // passm: lanes (odd) whose candidate passed the filter; on return, the ones that enter the list, ranked.
+    // The loop ranks every candidate as if the list held none of them. Whether it does is looked up afterwards, for all of
+    // them at once: a node the list holds has the candidate's key up to the flag, so it stands right where the candidate's
+    // rank points -- at entry `rank` when it is expanded (K|1 is the smallest key above K), at `rank - 1` when it is not
+    // (K itself is the largest key not above K). Both are read from the list's image (ids do not depend on the flags, which
+    // the image of a short list does not follow). A hit is rare (the cache of entered ids has taken the revisits out) and
+    // costs a second pass over the remaining candidates.
+    template <bool TWINS>
+    __device__ __forceinline__ uint64_t rank_candidates(uint64_t passm, const uint32_t ck_lo, const uint32_t ck_hi, Ranked& rk) const {
+        const uint64_t ck = ((uint64_t)ck_hi << 32) | ck_lo;
+        const uint32_t* img_lo = reinterpret_cast<const uint32_t*>(mslot);
+        for (;;) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) rk.shift[s] = 0;
+            rk.rankv = 0;
+            rk.below = 0;
+            if (passm == 0) return 0;
+            uint64_t it = passm;
+            if constexpr (TWINS) {
+                while (it) rank_one<true>(it, passm, ck_lo, ck_hi, ck, rk);
+            } else {
+                while (it & (it - 1)) rank_two(it, ck_lo, ck_hi, ck, rk); // two candidates per trip
+                if (it) rank_one<false>(it, passm, ck_lo, ck_hi, ck, rk);
             }
-            const uint32_t l = L.insert_sorted(K, lane);
-            lost = l < lost ? l : lost;
+            rk.rankv = CAP - rk.rankv; // entries below K
+            const uint32_t r0 = rk.rankv < CAP ? rk.rankv : CAP - 1u, r1 = rk.rankv ? rk.rankv - 1u : 0u;
+            const uint32_t e0 = img_lo[2u * r0], e1 = img_lo[2u * r1];
+            const uint32_t me = ck_lo | 1u;
+            const uint64_t known = passm & ((wave_ballot((e0 | 1u) == me) & wave_ballot(rk.rankv < CAP)) | wave_ballot((e1 | 1u) == me));
+            if (known == 0) return passm;
+            passm &= ~known; // in the list already, expanded or not: not a candidate (VisitedNone, wave_prims.h)
         }
-        theta = wkey_hi(L.at(ef - 1));
+    }
+
+    // scatter the list and the candidates in passm to their places in the image, read the list back
+    __device__ __forceinline__ void merge_ranked(const uint64_t passm, const uint64_t ck, const Ranked& rk, const uint32_t ef) {
+        uint64_t* img = mslot;
+#pragma unroll
+        for (int s = 0; s < S; ++s) img[(uint32_t)s * 64u + lane + rk.shift[s]] = L.key[s];
+        if (__builtin_amdgcn_inverse_ballot_w64(passm)) img[rk.rankv + rk.below] = ck;
+        asm volatile("" ::: "memory"); // one wave: LDS executes its accesses in program order
+#pragma unroll
+        for (int s = 0; s < S; ++s) L.key[s] = img[(uint32_t)s * 64u + lane];
+        const uint32_t lost = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(img)[2u * CAP + 1u]);
+        theta = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(img)[2u * (ef - 1u) + 1u]);
+        asm volatile("" ::: "memory");
+        // every place up to CAP + m - 1 was written (a permutation of CAP entries and m candidates), so place CAP holds
+        // the smallest key that fell off the end, 0xFFFFFFFF.. when that is an unused place
         if (lost == theta && theta != 0xFFFFFFFFu) bail = true;
     }
 
-    // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
-    //
-    // One iteration = one expansion: pop, adjacency row, row loads, (an exact visited set under them,) distances, filter,
-    // merge. Two things run ahead of their use:
-    //  * the adjacency row of the list's first unexpanded entry y is fetched during the expansion before it;
-    //  * once the distances are in, the node expanded next is known BEFORE the merge -- the smallest of y and
-    //    the candidates that pass the filter, since merging changes nothing that sorts before that minimum.
-    //    When a candidate wins (half of the expansions at max_search 50) its adjacency row is requested
-    //    right there and arrives under the merge instead of after it.
-    // Measured and dropped (the phase clocks of tools/phase_probe.py say why): a rotated loop that
-    // puts the next node's ROW loads in flight under the merge (twice, rounds 2a and 2b: the bookkeeping costs
-    // what the overlap gives), and a speculative request of y's neighbor rows one expansion early (int8: 6 %
-    // slower per launch -- the lines arrive no sooner than the compute that follows them needs).
-    // The row loads have one site in the loop: two sites would meet in a phi, and the register copies at the
-    // join wait for the data right after issuing it.
-    __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
-                                                 bool d0_known = false, float d0_value = 0.0f) {
+    // mod.rs:1029 for the candidates of one expansion: the lanes of candm whose candidate enters `pq`
+    __device__ __forceinline__ uint64_t filter_mask(const uint64_t candm, const uint32_t dbits, const uint32_t ef) const {
+        // `res` does not change during an expansion, so neither do the two thresholds:
+        //   theta = dist of entry max_search-1 (0xFFFFFFFF while the list is shorter: every distance is below it); a
+        //           candidate beyond it has max_search entries strictly closer: dead;
+        //   worst = res.peek().dist = dist of the max_search-th EXPANDED entry (mod.rs:1029), >= theta.
+        // d <= theta < worst needs no second look; only a candidate that ties with theta can still fail
+        // `d < worst`, and only then is the max_search-th expanded entry looked up.
+        uint64_t passm = candm & wave_ballot(dbits <= theta);
+        const uint64_t tiem = passm & wave_ballot(dbits == theta);
+        if (tiem) {
+            const uint32_t w = L.nth_expanded(ef); // res.peek(): the max_search-th popped node
+            if (w != WPOS_NONE) passm &= ~(tiem & ~wave_ballot(dbits < wkey_hi(L.at(w))));
+        }
+        return passm;
+    }
+
+    // mod.rs:1029 for the candidates of one expansion (`cand` lanes hold a distance): which of them enter the list
+    __device__ __forceinline__ bool filter(bool cand, float d, uint32_t ef) {
+        return __builtin_amdgcn_inverse_ballot_w64(filter_mask(wave_ballot(cand), __float_as_uint(d), ef));
+    }
+
+    // The same walk for the lists of 33 / 65 slots (max_search 1025..4096): the pop searches the image from a cached lower
+    // bound, the candidates are ranked by binary search (rank_long) and placed by place_long. One iteration = one
+    // expansion: pop, adjacency row, row loads, distances, filter, merge; the adjacency row of the list's first unexpanded
+    // entry y is fetched during the expansion before it, and a candidate that sorts before y (then it is expanded next) has
+    // its row requested before the merge.
+    __device__ __forceinline__ void search_layer_long(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
+                                                      bool d0_known, float d0_value) {
+        static_assert(!LONG || (NOVIS && !WIDE && !TOUCH), "lists of 33 / 65 slots: no visited set, 32-id layers");
         PT_RESET();
-        if constexpr (!NOVIS) vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
         L.init_list(mslot, lane);
         __syncthreads();
         const gptr_u32 adjg = (gptr_u32)Ly.adj;
-        const uint32_t W = WIDE ? Ly.width : 32u; // ids per adjacency row on the device: 32, or 64 in a WIDE launch
+        const uint32_t W = 32u;
         uint32_t pre_id = entrypoint, pre_nb; // adjacency row fetched ahead (one id per pair) and whose it is
-
-        // distance to the entry point (mod.rs:1012-1016); the first pop of the loop takes it. On every layer
-        // but the first the entry point is the node the layer above returned as its closest, and its distance
-        // to the same query was evaluated there: the same operations on the same inputs give the same bits, so
-        // the value is reused (the evaluation still counts) and the layer starts one memory round trip earlier.
         pre_nb = adjg[(size_t)entrypoint * W + R]; // get_neighbors(entrypoint): needed right after
-        if constexpr (!NOVIS) vis.insert(entrypoint, lane == 0, p.ovf);
         vis.count = 1;
         st.n_dist += 1;
         if (d0_known) {
@@ -777,9 +794,8 @@ struct FastWalker {
         theta = wkey_hi(L.at(ef - 1));
 
         RowRegs rr;
-        [[maybe_unused]] uint32_t touched[NT] = {};
         PT_WAIT_VM();
-        PT_MARK(7); // layer setup: tables, entry point distance
+        PT_MARK(7); // layer setup: entry point distance
         for (;;) {
             uint32_t pos;
             if (!L.first_unexpanded(pos)) break;          // pq.pop() on an empty queue, mod.rs:1018
@@ -795,22 +811,10 @@ struct FastWalker {
             uint32_t nb;
             if (pre_id == xid) nb = pre_nb;
             else nb = adjg[(size_t)xid * W + R];
-            [[maybe_unused]] uint32_t nb_hi = ID_EMPTY; // WIDE: ids 32..63 of the row, wanted once the first pass is through
-            if constexpr (WIDE) {
-                if (W > 32u) nb_hi = adjg[(size_t)xid * W + 32u + R];
-            }
             PT_MARK(0); // pop, break test, mark
             PT_WAIT_VM();
             PT_MARK(8); // wait for the adjacency row
             PT_COUNT();
-            uint64_t ykey = KEY_INF; // the entry that is first in line (or the candidate that has beaten it): set by pass 0
-            for (uint32_t half = 0; half < (WIDE ? 2u : 1u); ++half) {
-            if constexpr (WIDE) {
-                if (half == 1u) { // the row went through all of its first 32 places: its second 32
-                    nb = nb_hi;
-                    if (wave_ballot(nb != ID_EMPTY) == 0) break;
-                }
-            }
             const uint64_t unused = wave_ballot(nb == ID_EMPTY);
             const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
             st.n_adj += nvalid;
@@ -818,20 +822,152 @@ struct FastWalker {
                 const uint32_t last_id = nvalid ? readlane32(nb, 2u * (nvalid - 1u)) : xid;
                 issue_rows((R < nvalid) ? nb : last_id, rr);
             }
-            if (half == 0u) {
-                // fetch ahead the row of the node that is first in line now; always one load: static wait counts
-                uint32_t ypos = 0;
-                const bool has_y = L.first_unexpanded(ypos);
-                ykey = has_y ? L.at(ypos) : KEY_INF;
-                pre_id = has_y ? wkey_id(ykey) : xid;
+            // fetch ahead the row of the node that is first in line now; always one load: static wait counts
+            uint32_t ypos = 0;
+            const bool has_y = L.first_unexpanded(ypos);
+            const uint64_t ykey = has_y ? L.at(ypos) : KEY_INF;
+            pre_id = has_y ? wkey_id(ykey) : xid;
+            pre_nb = adjg[(size_t)pre_id * W + R];
+            PT_MARK(1); // row loads and the fetch-ahead issued
+            const bool fresh = h == 0u && R < nvalid; // every neighbor is evaluated
+            PT_MARK(2);
+            PT_WAIT_VM();
+            PT_MARK(3); // what is left of the wait for the rows
+            const float d = finish_rows(rr);
+            const uint64_t fm = wave_ballot(fresh);
+            st.n_dist += (uint32_t)__popcll(fm);
+            PT_PIN(d);
+            PT_MARK(4); // distances
+            const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner holds an id
+            bool pass = filter(cand, d, ef);
+            const uint64_t ck = wkey(d, nb);
+            uint32_t lrank = 0;
+            const uint64_t pm = rank_long(pass, ck, lrank); // rank by binary search; known candidates leave in the same search
+            // a candidate that sorts before y is expanded next (the smallest such): request its adjacency row now
+            // (not with 800-byte rows: the walk is bandwidth-bound there and the kernel sits at its register limit)
+            uint64_t beat = (F32 && DIM > 128) ? 0ull : wave_ballot(pass && ck < ykey); // ykey = KEY_INF without y: every passing candidate
+            if (beat) {
+                uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
+                for (;;) { // usually one or two rounds
+                    beat = wave_ballot(pass && ck < K);
+                    if (!beat) break;
+                    K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
+                }
+                pre_id = wkey_id(K);
                 pre_nb = adjg[(size_t)pre_id * W + R];
             }
+            PT_MARK(5); // filter, next-node decision, its adjacency request
+            place_long(pm, pass, ck, lrank, ef);           // pq.push, mod.rs:1029-1031
+            PT_MARK(6); // merge
+            PT_MARK(9);
+            if (bail) return;
+        }
+    }
+
+    // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
+    //
+    // One iteration = one expansion of x, whose key, position and adjacency row the iteration before left behind (x is
+    // flagged = res.push, mod.rs:1023, when it is chosen): row loads from the ids alone -> the first unexpanded entry y and
+    // the fetch-ahead of ITS adjacency row, under the loads -> distances -> filter -> ranks (rank_candidates) -> who is next:
+    // the smallest candidate when it sorts before y (its adjacency row is requested right there), else y, for which the
+    // break test (mod.rs:1019) is taken -- before the merge, which a finished walk does not need -> merge -> flag.
+    // A candidate that wins needs no break test: it passed the filter, so fewer than max_search entries are strictly closer.
+    // The row loads have one site in the loop: two sites would meet in a phi, and the register copies at the
+    // join wait for the data right after issuing it.
+    __device__ __forceinline__ void search_layer(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
+                                                 bool d0_known = false, float d0_value = 0.0f) {
+        if constexpr (LONG) {
+            search_layer_long(Ly, entrypoint, ef, slots, d0_known, d0_value);
+            return;
+        } else {
+        PT_RESET();
+        if constexpr (!NOVIS) vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
+        L.init_list(mslot, lane);
+        __syncthreads();
+        const gptr_u32 adjg = (gptr_u32)Ly.adj;
+        const uint32_t W = WIDE ? Ly.width : 32u; // ids per adjacency row on the device: 32, or 64 in a WIDE launch
+        const bool twin_rows = (Ly.flags & LAYER_TWIN_ROWS) != 0u; // some row of the layer names a neighbor twice (rare: found at upload)
+        // distance to the entry point (mod.rs:1012-1016), the first pop. On every layer but the first the entry point is
+        // the node the layer above returned as its closest, and its distance to the same query was evaluated there: the
+        // same operations on the same inputs give the same bits, so the value is reused (the evaluation still counts)
+        // and the layer starts one memory round trip earlier.
+        uint32_t next_nb = adjg[(size_t)entrypoint * W + R]; // get_neighbors(entrypoint): the first row
+        if constexpr (!NOVIS) vis.insert(entrypoint, lane == 0, p.ovf);
+        vis.count = 1;
+        st.n_dist += 1;
+        uint64_t xkey;
+        if (d0_known) {
+            xkey = wkey(d0_value, entrypoint) | 1ull;
+        } else {
+            RowRegs r0;
+            issue_rows(entrypoint, r0);
+            const float d0 = finish_rows(r0);
+            xkey = readlane64(wkey(d0, entrypoint), 1) | 1ull;
+        }
+        L.set_first(xkey, lane); // popped at once: entry 0, flagged
+        vcache_reset(entrypoint);
+        theta = ef == 1u ? wkey_hi(xkey) : 0xFFFFFFFFu;
+        uint32_t xid = entrypoint;
+
+        RowRegs rr;
+        [[maybe_unused]] uint32_t touched[NT] = {};
+        PT_WAIT_VM();
+        PT_MARK(7); // layer setup: tables, entry point distance
+        for (;;) {
+            st.n_expand += 1;
+            // layer.get_neighbors(x), mod.rs:1025 / 540-552: row prefix until UNUSED, one id per pair. The row was requested
+            // an expansion ago (y's fetch-ahead) or before the merge (a candidate that won): two requests, one register --
+            // taken over HERE, by an instruction the compiler cannot move up to where the second request is issued (a copy
+            // placed there waits for the data right after asking for it)
+            uint32_t nb;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(nb) : "v"(next_nb));
+            [[maybe_unused]] uint32_t nb_hi = ID_EMPTY; // WIDE: ids 32..63 of the row, wanted once the first pass is through
+            if constexpr (WIDE) {
+                if (W > 32u) nb_hi = adjg[(size_t)xid * W + 32u + R];
+            }
+            PT_MARK(0);
+            PT_WAIT_VM();
+            PT_MARK(8); // wait for the adjacency row
+            PT_COUNT();
+            // y: the entry that is first in line now (x is flagged), or the candidate that has beaten it
+            uint64_t ykey = KEY_INF;
+            uint32_t ypos = WPOS_NONE, yid = xid;
+            bool finished = false, have_next = false;
+            for (uint32_t half = 0; half < (WIDE ? 2u : 1u); ++half) {
+            if constexpr (WIDE) {
+                if (half == 1u) nb = nb_hi; // the row went through all of its first 32 places: its second 32
+            }
+            const uint64_t unused = wave_ballot(nb == ID_EMPTY);
+            const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
+            st.n_adj += nvalid;
+            {   // pairs past the row's end re-read its first neighbor (the same lines as pair 0: no traffic of their own; an
+                // empty row: the node itself) -- chosen per lane, nothing scalar waits for a vector result
+                uint32_t fill = readlane32(nb, 0);
+                asm("" : "+v"(fill));
+                fill = fill != ID_EMPTY ? fill : xid;
+                issue_rows(nb != ID_EMPTY ? nb : fill, rr);
+            }
+            if (half == 0u) {
+                // fetch ahead the row of the node that is first in line now; always one load: static wait counts
+                const bool has_y = L.first_unexpanded(ypos);
+                if (has_y) {
+                    ykey = L.at(ypos);
+                    yid = wkey_id(ykey);
+                } else {
+                    ypos = WPOS_NONE;
+                }
+                next_nb = adjg[(size_t)yid * W + R];
+            }
+            [[maybe_unused]] uint32_t cached = ID_EMPTY; // what the cache holds in this neighbor's slot (arrives under the row loads)
+            if constexpr (NOVIS) cached = vcache[vcache_slot(nb)];
+            asm volatile("" ::: "memory"); // the fetch-ahead and the look-up are issued here, not where their results are used
+            __builtin_amdgcn_sched_barrier(0);
             PT_MARK(1); // row loads and the fetch-ahead issued
 
             // visited set under the loads, then the distances (mod.rs:1026-1027)
-            bool fresh;
-            if constexpr (NOVIS) fresh = h == 0u && R < nvalid; // every neighbor is evaluated
-            else fresh = vis.insert(nb, h == 0u && R < nvalid, p.ovf);
+            uint64_t fm; // even lanes whose id is evaluated for the first time (no set: every neighbor)
+            if constexpr (NOVIS) fm = 0x5555555555555555ull & ~unused; // (valid ids come first, mod.rs:540-552)
+            else fm = wave_ballot(vis.insert(nb, h == 0u && R < nvalid, p.ovf));
             PT_MARK(2); // visited set (under the loads)
             PT_WAIT_VM();
             PT_MARK(3); // what is left of the wait for the rows
@@ -840,7 +976,7 @@ struct FastWalker {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(touched[j])); // (arrived before the rows did)
                 // y's adjacency row came in right behind the rows; a pair past its end touches y's own row
-                const uint32_t tid = pre_nb != ID_EMPTY ? pre_nb : pre_id;
+                const uint32_t tid = next_nb != ID_EMPTY ? next_nb : yid;
                 const uint8_t* tb = p.elements + (size_t)tid * ROWB;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
@@ -849,69 +985,88 @@ struct FastWalker {
                 }
                 asm volatile("" ::: "memory");
             }
-            const uint64_t fm = wave_ballot(fresh);
             const uint32_t mf = (uint32_t)__popcll(fm);
             vis.added(mf);
             st.n_dist += mf;
             PT_PIN(d);
             PT_MARK(4); // distances
-            const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner inserted a new id
-            bool pass = filter(cand, d, ef);
-            const uint64_t ck = wkey(d, nb);
-            uint64_t pm = wave_ballot(pass);
-            [[maybe_unused]] uint32_t lrank = 0;
-            if constexpr (NOVIS && LONG) { // long lists: rank by binary search; known candidates leave in the same search
-                pm = rank_long(pass, ck, lrank);
-            } else if constexpr (NOVIS && WalkList<S>::MIRROR) { // bulk merge: the candidates the list holds already leave first
-                pm = drop_known(pm, pass, nb);
-                pass = (pm >> lane) & 1ull;
+            const uint32_t dbits = __float_as_uint(d);
+            uint64_t candm = fm << 1; // odd lanes whose even partner holds a new id
+            if constexpr (NOVIS) candm &= ~wave_ballot(cached == nb); // entered the list before: visited (a pair past the row's end is no candidate anyway)
+            uint64_t passm = filter_mask(candm, dbits, ef);
+            PT_ADD(6, (uint32_t)__popcll(passm));
+            PT_MARK(10); // cache look-up, filter
+            const uint32_t ck_lo = nb << 1;
+            const uint64_t ck = ((uint64_t)dbits << 32) | ck_lo;
+            Ranked rk;
+            passm = twin_rows ? rank_candidates<true>(passm, ck_lo, dbits, rk) : rank_candidates<false>(passm, ck_lo, dbits, rk);
+            if constexpr (NOVIS) {
+                if (__builtin_amdgcn_inverse_ballot_w64(passm)) vcache[vcache_slot(nb)] = nb;
             }
-            // a candidate that sorts before y is expanded next (the smallest such): request its adjacency row now
-            // (not with 800-byte rows: the walk is bandwidth-bound there and the kernel sits at its 168-register limit)
-            uint64_t beat = (F32 && DIM > 128) ? 0ull : wave_ballot(pass && ck < ykey); // ykey = KEY_INF without y: every passing candidate
-            [[maybe_unused]] const bool beat0 = beat != 0;
-            while (beat) {
-                uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
-                for (;;) { // usually one or two rounds
-                    beat = wave_ballot(pass && ck < K);
-                    if (!beat) break;
-                    K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
+            const uint32_t m = (uint32_t)__popcll(passm);
+            PT_MARK(11); // ranks
+            PT_ADD(0, m);
+            PT_ADD(1, m == 0u ? 1u : 0u);
+            PT_ADD(2, (m == 1u || m == 2u) ? 1u : 0u);
+            PT_ADD(3, (m >= 3u && m <= 6u) ? 1u : 0u);
+            PT_ADD(4, m > 6u ? 1u : 0u);
+            // who is next?
+            [[maybe_unused]] uint64_t win_bit = 0; // the lane of a candidate that is expanded next
+            if (m) {
+                // the smallest candidate (nobody below it) wins iff it sorts before y: #{entries < K} <= pos(y)  (no y: 0xFFFFFFFF)
+                const uint64_t wm = passm & wave_ballot(rk.below == 0u) & wave_ballot(rk.rankv <= ypos);
+                if (wm) {
+                    const uint32_t jw = (uint32_t)__builtin_ctzll(wm);
+                    win_bit = wm;
+                    yid = readlane32(nb, jw);
+                    uint32_t yv = yid;
+                    asm("" : "+v"(yv)); // (the address on the vector side: a scalar shift would wait for the v_readlane)
+                    next_nb = adjg[(size_t)yv * W + R]; // requested here, arrives under the merge
+                    ykey = readlane64(ck, jw);
+                    ypos = readlane32(rk.rankv, jw);
+                    PT_ADD(5, 1u);
                 }
-                if constexpr (NOVIS && !WalkList<S>::MIRROR) {
-                    // a revisited node that is in the list (an expanded one sorts before y, always) is no candidate:
-                    // out it goes, the next smallest is looked at
-                    if (L.holds(wkey_id(K))) {
-                        pass = pass && ck != K;
-                        pm = wave_ballot(pass);
-                        beat = wave_ballot(pass && ck < ykey);
-                        continue;
-                    }
+            }
+            bool last = true;
+            if constexpr (WIDE) last = half == 1u || nvalid < 32u || wave_ballot(nb_hi != ID_EMPTY) == 0;
+            if (last) {
+                if (ypos == WPOS_NONE) {
+                    finished = true; // pq.pop() on an empty queue, mod.rs:1018
+                } else if (ypos >= ef && L.count_closer(wkey_hi(ykey)) >= ef) {
+                    // mod.rs:1019-1021. Every entry before y is expanded and at most as far; #{closer} = ypos - #{ties
+                    // before y}, so the count is only taken when ypos alone does not already decide
+                    finished = true;
+                } else {
+                    have_next = true;
                 }
-                pre_id = wkey_id(K);
-                pre_nb = adjg[(size_t)pre_id * W + R];
-                if constexpr (WIDE) ykey = K; // the second pass's candidates have this one to beat
-                break;
             }
-            PT_MARK(5); // filter, next-node decision, its adjacency request
-            {
-                [[maybe_unused]] const uint32_t m_ = (uint32_t)__popcll(pm);
-                PT_ADD(0, m_);
-                PT_ADD(1, m_ == 0u ? 1u : 0u);
-                PT_ADD(2, (m_ == 1u || m_ == 2u) ? 1u : 0u);
-                PT_ADD(3, (m_ >= 3u && m_ <= 6u) ? 1u : 0u);
-                PT_ADD(4, m_ > 6u ? 1u : 0u);
-                PT_ADD(5, beat0 ? 1u : 0u);
+            PT_MARK(5); // filter, ranks, next-node decision, its adjacency request
+            if (finished) break;
+            if constexpr (!WIDE) {
+                // res.push((d, idx)), mod.rs:1023: the node expanded next is flagged on its way through the merge -- a
+                // candidate in its own lane, y where it stands (no candidate sorts before it: it stays there)
+                if (m) {
+                    const uint32_t ck_lo_in = ck_lo | (__builtin_amdgcn_inverse_ballot_w64(win_bit) ? 1u : 0u);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) L.key[s] |= (win_bit == 0 && (uint32_t)s * 64u + lane == ypos) ? 1ull : 0ull;
+                    merge_ranked(passm, ((uint64_t)dbits << 32) | ck_lo_in, rk, ef);
+                } else {
+                    L.mark_expanded(ypos, ykey, lane);
+                }
+            } else {
+                if (m) merge_ranked(passm, ck, rk, ef);
             }
-            if constexpr (NOVIS && LONG) place_long(pm, pass, ck, lrank, ef);
-            else insert(pm, pass, ck, ef);                 // pq.push, mod.rs:1029-1031
-            PT_MARK(6); // insert / merge
+            PT_MARK(6); // merge
             if (!vis.make_room(p.ovf, lane)) bail = true;
             PT_MARK(9); // visited-set housekeeping
             if (bail) return;
-            if constexpr (WIDE) {
-                if (nvalid < 32u) break; // the row ended inside this pass
-            }
+            if (last) break;
             } // passes over the row
+            if (!have_next) break;
+            if constexpr (WIDE) L.mark_expanded(ypos, ykey, lane); // (two passes: flagged where it stands after the last one)
+            xid = yid;
+            PT_MARK(12); // flag
+        }
         }
     }
 };
@@ -997,11 +1152,11 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
 #if GRANNE_HIP_PHASE_TIMERS
         if (lane == 0 && qi < PHASE_QUERIES) {
             uint64_t* o = g_phase + (size_t)qi * PHASE_SLOTS;
-            for (int i = 0; i < 10; ++i) { o[i] = w.pt_b[i]; o[10 + i] = w.pt_u[i]; }
-            o[20] = w.pt_nb; o[21] = w.pt_nu;
-            o[22] = __builtin_amdgcn_s_memtime() - w.pt_t0;
-            for (int i = 0; i < 8; ++i) o[24 + i] = w.pt_cnt[i];
-            o[30] = w.vis.pt_rounds;
+            for (int i = 0; i < 16; ++i) { o[i] = w.pt_b[i]; o[16 + i] = w.pt_u[i]; }
+            o[32] = w.pt_nb; o[33] = w.pt_nu;
+            o[34] = __builtin_amdgcn_s_memtime() - w.pt_t0;
+            for (int i = 0; i < 8; ++i) o[36 + i] = w.pt_cnt[i];
+            o[44] = w.vis.pt_rounds;
         }
 #endif
         if (lane == 0) {
@@ -1049,7 +1204,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S, WIDE)) void fas
 }
 
 __host__ __device__ inline uint32_t fast_lds_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {
-    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (S >= 8u ? 64u * S * 8u : 0u) + visited_slots * 4u;
+    // [query][the list's image][lists of up to 17 slots: the cache of entered ids][visited]
+    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (64u * S + (S >= 33u ? 0u : 32u)) * 8u + (S >= 33u ? 0u : VCACHE_SLOTS * 4u) + visited_slots * 4u;
 }
 
 } // namespace granne_hip

@@ -40,7 +40,7 @@ __device__ __forceinline__ uint64_t make_key(float d, uint32_t id) {
 __device__ __forceinline__ float key_dist(uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); }
 __device__ __forceinline__ uint32_t key_id(uint64_t k) { return (uint32_t)k; }
 
-__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); } // (__ballot takes an int: a 0/1 select and a second compare)
 
 // v_readlane with a wave-uniform lane index
 __device__ __forceinline__ uint32_t readlane32(uint32_t v, uint32_t lane) {

@@ -273,3 +273,17 @@ def test_rows_taken_in_two_passes_equal_two_heaps():
         assert c0[1:] == c1[1:] and c1[0] >= c0[0], (it, c0, c1)
         equal += 1
     assert equal > 300
+
+
+def test_ranked_merge_of_the_short_lists_equals_two_heaps():
+    """walk_fast.h's lists of up to 17 slots (round 5): every candidate of an expansion ranked at once, one scatter through
+    the list's LDS image, the next node chosen (and flagged) before the merge, revisits looked up in the image after the
+    ranks. tools/model_ranked.py replays it lane for lane -- 64 lanes, S slots, candidates in the odd lanes, rows of up to
+    64 ids in two passes, rows that name a neighbor twice, ties -- against the reference's two heaps."""
+    spec = importlib.util.spec_from_file_location("model_ranked", os.path.join(ROOT, "tools", "model_ranked.py"))
+    m = importlib.util.module_from_spec(spec)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    spec.loader.exec_module(m)
+    equal, bailed = m.main(seed=31, rounds=400)
+    assert equal > 300 and bailed > 0

@@ -17,9 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-NAMES = ["pop/mark", "issue rows", "visited", "row wait", "distances", "filter/next", "insert", "layer setup",
-         "adj wait", "make_room"]
-SLOTS = 32
+NAMES = ["top of loop", "issue rows + y", "visited", "row wait", "distances", "decision + adj req", "merge", "layer setup",
+         "adj wait", "make_room", "cache + filter", "rank loop", "flag", "-", "-", "-"]
+SLOTS = 48
 
 
 def main():
@@ -66,23 +66,23 @@ def main():
     rc = L.granne_hip_debug_phases(out.ctypes.data_as(C.c_void_p), a.nq)
     assert rc == 0, rc
     ph = out.astype(np.float64)
-    total = ph[:, 22]
+    total = ph[:, 34]
     order = np.argsort(total)
     groups = [("all walks", order), ("slowest 2 %", order[-max(1, a.nq // 50):])]
     for name, idx in groups:
-        nb, nu = ph[idx, 20].mean(), ph[idx, 21].mean()
+        nb, nu = ph[idx, 32].mean(), ph[idx, 33].mean()
         print("\n== %s: %.0f cycles per walk, %.1f bottom + %.1f upper expansions" % (name, total[idx].mean(), nb, nu))
         print("%-14s %12s %12s %14s %14s" % ("phase", "bottom/walk", "upper/walk", "bottom/expan.", "upper/expan."))
         sb = su = 0.0
-        for i in range(10):
-            b, u = ph[idx, i].mean(), ph[idx, 10 + i].mean()
+        for i in range(13):
+            b, u = ph[idx, i].mean(), ph[idx, 16 + i].mean()
             sb, su = sb + b, su + u
             print("%-14s %12.0f %12.0f %14.1f %14.1f" % (NAMES[i], b, u, b / max(nb, 1e-9), u / max(nu, 1e-9)))
         print("%-14s %12.0f %12.0f %14.1f %14.1f" % ("sum", sb, su, sb / max(nb, 1e-9), su / max(nu, 1e-9)))
-        c = ph[idx, 24:32].mean(axis=0)
+        c = ph[idx, 36:44].mean(axis=0)
         print("bottom layer, per expansion: candidates inserted %.2f | expansions with 0: %.3f, 1-2: %.3f, 3-6: %.3f, >6: %.3f | "
-              "a candidate is expanded next: %.3f | visited probe rounds (front table, all layers) %.2f"
-              % (c[0] / nb, c[1] / nb, c[2] / nb, c[3] / nb, c[4] / nb, c[5] / nb, c[6] / (nb + nu)))
+              "a candidate is expanded next: %.3f | candidates that reach the rank loop %.2f"
+              % (c[0] / nb, c[1] / nb, c[2] / nb, c[3] / nb, c[4] / nb, c[5] / nb, c[6] / nb))
     print("\nslowest walk %.0f cycles, mean %.0f, ratio %.2f" % (total.max(), total.mean(), total.max() / total.mean()))
 
 
