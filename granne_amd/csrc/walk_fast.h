@@ -932,7 +932,6 @@ struct FastWalker {
             // y: the entry that is first in line now (x is flagged), or the candidate that has beaten it
             uint64_t ykey = KEY_INF;
             uint32_t ypos = WPOS_NONE, yid = xid;
-            bool finished = false, have_next = false;
             for (uint32_t half = 0; half < (WIDE ? 2u : 1u); ++half) {
             if constexpr (WIDE) {
                 if (half == 1u) nb = nb_hi; // the row went through all of its first 32 places: its second 32
@@ -1030,18 +1029,12 @@ struct FastWalker {
             bool last = true;
             if constexpr (WIDE) last = half == 1u || nvalid < 32u || wave_ballot(nb_hi != ID_EMPTY) == 0;
             if (last) {
-                if (ypos == WPOS_NONE) {
-                    finished = true; // pq.pop() on an empty queue, mod.rs:1018
-                } else if (ypos >= ef && L.count_closer(wkey_hi(ykey)) >= ef) {
-                    // mod.rs:1019-1021. Every entry before y is expanded and at most as far; #{closer} = ypos - #{ties
-                    // before y}, so the count is only taken when ypos alone does not already decide
-                    finished = true;
-                } else {
-                    have_next = true;
-                }
+                if (ypos == WPOS_NONE) goto layer_done; // pq.pop() on an empty queue, mod.rs:1018
+                // mod.rs:1019-1021. Every entry before y is expanded and at most as far; #{closer} = ypos - #{ties
+                // before y}, so the count is only taken when ypos alone does not already decide
+                if (ypos >= ef && L.count_closer(wkey_hi(ykey)) >= ef) goto layer_done; // (before the merge: a finished walk does not need it)
             }
-            PT_MARK(5); // filter, ranks, next-node decision, its adjacency request
-            if (finished) break;
+            PT_MARK(5); // next-node decision, its adjacency request
             if constexpr (!WIDE) {
                 // res.push((d, idx)), mod.rs:1023: the node expanded next is flagged on its way through the merge -- a
                 // candidate in its own lane, y where it stands (no candidate sorts before it: it stays there)
@@ -1062,11 +1055,11 @@ struct FastWalker {
             if (bail) return;
             if (last) break;
             } // passes over the row
-            if (!have_next) break;
             if constexpr (WIDE) L.mark_expanded(ypos, ykey, lane); // (two passes: flagged where it stands after the last one)
             xid = yid;
             PT_MARK(12); // flag
         }
+    layer_done:;
         }
     }
 };
