@@ -14,9 +14,10 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OVERFLOW, ERR_IO = -1, -2, -3, -4, -5
 
 OPT_VISITED_SLOTS, OPT_FORCE_SLOW, OPT_SLOW_SLOTS, OPT_SLOW_BLOCKS, OPT_OVERFLOW_SLOTS = 1, 2, 3, 4, 5
-OPT_VISITED16, OPT_VISITED16_LG, OPT_LAST_WALKER = 6, 7, 8
+OPT_VISITED16, OPT_VISITED16_LG, OPT_LAST_WALKER, OPT_SEARCH_DEPTH = 6, 7, 8, 9
 WALKER_NONE, WALKER_REGISTER, WALKER_REGISTER_WIDE, WALKER_GENERAL, WALKER_EXACT = 0, 1, 2, 3, 4
-SEARCH_DEPTH = 3  # GRANNE_HIP_SEARCH_DEPTH
+SEARCH_DEPTH = 3  # GRANNE_HIP_SEARCH_DEPTH (the default of OPT_SEARCH_DEPTH)
+SEARCH_DEPTH_MAX = 16  # GRANNE_HIP_SEARCH_DEPTH_MAX
 SHARDED_OPT_DEPTH, SHARDED_OPT_EXCHANGE = 1, 2
 SHARDED_EXCHANGE_PEER, SHARDED_EXCHANGE_RCCL = 0, 1
 
@@ -98,6 +99,7 @@ SIGNATURES = {
     "granne_hip_merge_topk_packed_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, i32, vp]),
     "granne_hip_merge_topk_packed_strided_device": (i32, [vp, u64, vp, u32, u32, u32, vp, vp, vp, i32, vp]),
     "granne_hip_sharded_create": (i32, [C.POINTER(vp), vp, vp, u32]),
+    "granne_hip_sharded_create_grouped": (i32, [C.POINTER(vp), vp, vp, u32, vp]),
     "granne_hip_sharded_destroy": (None, [vp]),
     "granne_hip_sharded_num_shards": (u32, [vp]),
     "granne_hip_sharded_len": (u64, [vp]),

@@ -79,9 +79,12 @@ struct ScratchCache {
         hipStream_t stream;
         uint8_t* p;
         size_t cap;
+        uint64_t last_use;   // `uses` at the block's last launch
+        uint32_t small_runs; // consecutive launches that needed less than a quarter of an oversized block
     };
     std::mutex mu;
     std::vector<Block> blocks;
+    uint64_t uses = 0;
     void free_all() {
         for (auto& b : blocks)
             if (b.p) (void)hipFree(b.p);
@@ -138,7 +141,8 @@ struct granne_hip_index {
         uint64_t seq = 0;
     };
     std::mutex flight_mu;
-    Flight flights[GRANNE_HIP_SEARCH_DEPTH];
+    Flight flights[GRANNE_HIP_SEARCH_DEPTH_MAX];
+    uint32_t depth = GRANNE_HIP_SEARCH_DEPTH; // GRANNE_HIP_OPT_SEARCH_DEPTH
     uint32_t next_flight = 0;
     uint64_t next_seq = 1;
 };
@@ -509,6 +513,15 @@ extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uin
         if (value > 4) return fail(GRANNE_HIP_ERR_INVALID, "the visited-set option must be 0 (auto = none), 1..3 (the exact set) or 4 (none)");
         ix->opt_visited16 = value;
         return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_SEARCH_DEPTH: {
+        if (value < 1 || value > GRANNE_HIP_SEARCH_DEPTH_MAX) return fail(GRANNE_HIP_ERR_INVALID, "search depth must be in [1, %d]", GRANNE_HIP_SEARCH_DEPTH_MAX);
+        std::lock_guard<std::mutex> lk(ix->flight_mu);
+        for (auto& f : ix->flights)
+            if (f.busy) return fail(GRANNE_HIP_ERR_INVALID, "the depth cannot change while a batch is in flight");
+        ix->depth = (uint32_t)value;
+        ix->next_flight = 0;
+        return GRANNE_HIP_OK;
+    }
     case GRANNE_HIP_OPT_VISITED16_LG: // (retired with the bucket tables it sized: accepted, ignored)
         if (value > 12) return fail(GRANNE_HIP_ERR_INVALID, "value out of range");
         ix->opt_visited16_lg = value;
@@ -529,6 +542,7 @@ extern "C" int granne_hip_index_get_option(const granne_hip_index* ix, int optio
     case GRANNE_HIP_OPT_VISITED16: *value = ix->opt_visited16; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_VISITED16_LG: *value = ix->opt_visited16_lg; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_LAST_WALKER: *value = ix->last_walker.load(); return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_SEARCH_DEPTH: *value = ix->depth; return GRANNE_HIP_OK;
     default: return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -727,7 +741,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
     const int vmode = ix->opt_visited16 ? ix->opt_visited16 : knobs().visited;
     const bool none = vmode == 4 || vmode == 0;
     const bool longest = fastS >= 33 || fast_wide(ix); // (lists of 33 / 65 slots, and 64-id layers: instantiated without a set only, whatever the options say)
-    if (fastS >= 1 && !trail && ((none && !ix->opt_visited_slots) || longest) && ix->n_elements < WALK_MAX_ELEMENTS) {
+    if (fastS >= 1 && !trail && ((none && !ix->opt_visited_slots) || longest) && ix->n_elements <= WALK_MAX_ELEMENTS) { // (fast_shape's bound)
         // a launch of a few queries leaves the chip idle: its walkers touch the next node's rows ahead (walk_fast.h, TOUCH)
         const uint32_t touch_max = knobs().touch_max >= 0 ? (uint32_t)knobs().touch_max : 64u;
         const bool touch_shape = fastS == 1 && !fast_generic(ix) && !(ix->dtype == GRANNE_HIP_I8 && ix->row_bytes != 128);
@@ -818,19 +832,37 @@ static int scratch_for(ScratchCache* cache, hipStream_t s, size_t total, uint8_t
     // (the caller holds cache->mu for the enqueue)
     *transient = false;
     ScratchCache::Block* b = nullptr;
+    cache->uses += 1;
     for (auto& x : cache->blocks)
         if (x.stream == s) b = &x;
     if (!b) {
         if (cache->blocks.size() >= SCRATCH_CACHE_STREAMS) {
-            HIP_TRY(hipMallocAsync((void**)out, total, s));
-            HIP_TRY(hipMemsetAsync(*out, 0, SCRATCH_FIXED, s));
-            *transient = true;
-            return GRANNE_HIP_OK;
+            // a stream that has not searched for a long while (destroyed, most likely) gives its place up; while every
+            // cached stream is in use the newcomer takes a block from the stream-ordered allocator for this launch alone
+            ScratchCache::Block* lru = &cache->blocks[0];
+            for (auto& x : cache->blocks)
+                if (x.last_use < lru->last_use) lru = &x;
+            if (cache->uses - lru->last_use > 4 * SCRATCH_CACHE_STREAMS) {
+                if (lru->p) (void)hipFree(lru->p); // (waits for the device: whatever still used the block is over)
+                *lru = {s, nullptr, 0, cache->uses, 0};
+                b = lru;
+            } else {
+                HIP_TRY(hipMallocAsync((void**)out, total, s));
+                HIP_TRY(hipMemsetAsync(*out, 0, SCRATCH_FIXED, s));
+                *transient = true;
+                return GRANNE_HIP_OK;
+            }
+        } else {
+            cache->blocks.push_back({s, nullptr, 0, cache->uses, 0});
+            b = &cache->blocks.back();
         }
-        cache->blocks.push_back({s, nullptr, 0});
-        b = &cache->blocks.back();
     }
-    const bool oversized = b->cap > SCRATCH_SHRINK_ABOVE && total < b->cap / 4; // e.g. after one exact-walker batch
+    b->last_use = cache->uses;
+    // a block left oversized by one exact-walker batch is let go once eight launches in a row needed less than a quarter
+    // of it (not at the first: a stream that alternates the two kinds of batches keeps its block)
+    if (b->cap > SCRATCH_SHRINK_ABOVE && total < b->cap / 4) b->small_runs += 1;
+    else b->small_runs = 0;
+    const bool oversized = b->small_runs >= 8;
     if (b->cap < total || oversized) {
         if (b->p) {
             HIP_TRY(hipStreamSynchronize(s)); // earlier launches on this stream still use the old block
@@ -838,6 +870,7 @@ static int scratch_for(ScratchCache* cache, hipStream_t s, size_t total, uint8_t
             b->p = nullptr;
             b->cap = 0;
         }
+        b->small_runs = 0;
         size_t want = total + (total >> 2); // some headroom: batch sizes vary
         HIP_TRY(hipMalloc((void**)&b->p, want));
         b->cap = want;
@@ -1078,13 +1111,33 @@ extern "C" int granne_hip_search_begin_device(const granne_hip_index* cix, const
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
     std::lock_guard<std::mutex> lk(ix->flight_mu);
-    const uint32_t fi = ix->next_flight;
+    // any flight that is free, looked for from the one after the last begun (tickets may be ended in any order)
+    uint32_t fi = ix->depth;
+    for (uint32_t t = 0; t < ix->depth; ++t) {
+        const uint32_t c = (ix->next_flight + t) % ix->depth;
+        if (!ix->flights[c].busy) {
+            fi = c;
+            break;
+        }
+    }
+    if (fi == ix->depth)
+        return fail(GRANNE_HIP_ERR_INVALID, "%u batches are in flight already (GRANNE_HIP_OPT_SEARCH_DEPTH): end one first", ix->depth);
     auto& F = ix->flights[fi];
-    if (F.busy) return fail(GRANNE_HIP_ERR_INVALID, "%d batches are in flight already: end one first", GRANNE_HIP_SEARCH_DEPTH);
-    if (!F.stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&F.stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&F.ready, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&F.done, hipEventDisableTiming));
+    if (!F.done) { // created together or not at all: a failure leaves the flight as it was
+        hipStream_t st = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (e1) (void)hipEventDestroy(e1);
+            if (e0) (void)hipEventDestroy(e0);
+            if (st) (void)hipStreamDestroy(st);
+            return fail(GRANNE_HIP_ERR_HIP, "a stream for a batch in flight: %s", hipGetErrorString(e));
+        }
+        F.stream = st;
+        F.ready = e0;
+        F.done = e1;
     }
     HIP_TRY(hipEventRecord(F.ready, (hipStream_t)stream));
     HIP_TRY(hipStreamWaitEvent(F.stream, F.ready, 0));
@@ -1098,7 +1151,7 @@ extern "C" int granne_hip_search_begin_device(const granne_hip_index* cix, const
     HIP_TRY(hipEventRecord(F.done, F.stream));
     F.busy = true;
     F.seq = ix->next_seq++;
-    ix->next_flight = (fi + 1) % GRANNE_HIP_SEARCH_DEPTH;
+    ix->next_flight = (fi + 1) % ix->depth;
     *out_ticket = (F.seq << 8) | fi;
     return GRANNE_HIP_OK;
 }
@@ -1108,7 +1161,7 @@ extern "C" int granne_hip_search_end_device(const granne_hip_index* cix, uint64_
     granne_hip_index* ix = const_cast<granne_hip_index*>(cix);
     std::lock_guard<std::mutex> lk(ix->flight_mu);
     const uint32_t fi = (uint32_t)(ticket & 0xFF);
-    if (fi >= GRANNE_HIP_SEARCH_DEPTH || !ix->flights[fi].busy || ix->flights[fi].seq != (ticket >> 8))
+    if (fi >= GRANNE_HIP_SEARCH_DEPTH_MAX || !ix->flights[fi].busy || ix->flights[fi].seq != (ticket >> 8))
         return fail(GRANNE_HIP_ERR_INVALID, "no batch in flight has this ticket");
     DeviceGuard g(ix->device);
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ix->flights[fi].done, 0));

@@ -25,6 +25,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <thread>
 
 // ---- RCCL, bound at run time ------------------------------------------------------------------------------
 struct RcclApi {
@@ -232,8 +233,13 @@ static int sharded_init_slot(granne_hip_sharded* sh, granne_hip_sharded::Slot& L
     return GRANNE_HIP_OK;
 }
 
-extern "C" int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_index* const* shards,
-                                         const uint64_t* id_offsets, uint32_t n_shards) {
+// `groups` (or null): the exchange group of every shard. A group is what the exchange step treats as one device: its
+// first shard fetches the batch's queries for all of them, its results travel to the merge device together (peer copies,
+// or its part of the all-gather), its buffers are released by one event. Null: one group per HIP device, which is what a
+// deployment wants. Several groups on ONE device walk every branch of the multi-device exchange on a single GPU (the
+// tests do; the copies are then device-local); the all-gather needs one group per device (RCCL refuses duplicates).
+extern "C" int granne_hip_sharded_create_grouped(granne_hip_sharded** out, granne_hip_index* const* shards,
+                                                 const uint64_t* id_offsets, uint32_t n_shards, const uint32_t* groups) {
     if (!out) return fail(GRANNE_HIP_ERR_INVALID, "out is null");
     *out = nullptr;
     if (!shards || !id_offsets) return fail(GRANNE_HIP_ERR_INVALID, "null argument");
@@ -242,6 +248,11 @@ extern "C" int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_in
         if (!shards[s]) return fail(GRANNE_HIP_ERR_INVALID, "shard %u is null", s);
         if (shards[s]->dim != shards[0]->dim || shards[s]->dtype != shards[0]->dtype)
             return fail(GRANNE_HIP_ERR_INVALID, "shard %u has another element type than shard 0", s);
+        if (groups)
+            for (uint32_t t = 0; t < s; ++t)
+                if (groups[t] == groups[s] && shards[t]->device != shards[s]->device)
+                    return fail(GRANNE_HIP_ERR_INVALID, "shards %u and %u share exchange group %u but live on devices %d and %d", t, s,
+                                groups[s], shards[t]->device, shards[s]->device);
     }
     granne_hip_sharded* sh = new granne_hip_sharded();
     sh->dim = shards[0]->dim;
@@ -254,7 +265,13 @@ extern "C" int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_in
             S.ix = shards[s];
             S.offset = id_offsets[s];
             uint32_t d = 0;
-            while (d < sh->devices.size() && sh->devices[d].id != S.ix->device) ++d;
+            if (groups) { // the group of an earlier shard with the same label, else a new one
+                uint32_t t = 0;
+                while (t < s && groups[t] != groups[s]) ++t;
+                d = t < s ? sh->shards[t].dev : (uint32_t)sh->devices.size();
+            } else {
+                while (d < sh->devices.size() && sh->devices[d].id != S.ix->device) ++d;
+            }
             if (d == sh->devices.size()) {
                 sh->devices.emplace_back();
                 sh->devices.back().id = S.ix->device;
@@ -302,6 +319,11 @@ extern "C" int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_in
     return GRANNE_HIP_OK;
 }
 
+extern "C" int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_index* const* shards,
+                                         const uint64_t* id_offsets, uint32_t n_shards) {
+    return granne_hip_sharded_create_grouped(out, shards, id_offsets, n_shards, nullptr);
+}
+
 // SURVEY.md 8b's `index_create(..., device_ids, n_devices, partitioned)`: the whole element set in, a searchable
 // partitioned index out. Shard s takes the elements [s * ceil(n / n_shards), ...) -- the split of
 // src/elements/embeddings/parsing.rs:72-98 -- and is built with the GPU builder (GranneBuilder::new(config, shard).build())
@@ -321,27 +343,47 @@ extern "C" int granne_hip_sharded_build(granne_hip_sharded** out, const granne_h
     const uint64_t per = (n_elements + n_shards - 1) / n_shards;
     const uint32_t per_dev = (n_shards + n_devices - 1) / n_devices;
     const size_t row = (size_t)dim * elem_size(dtype);
-    std::vector<granne_hip_index*> ixs;
-    std::vector<uint64_t> offs;
-    int rc = GRANNE_HIP_OK;
-    for (uint32_t s = 0; s < n_shards && rc == GRANNE_HIP_OK; ++s) {
-        const uint64_t lo = std::min(n_elements, (uint64_t)s * per), hi = std::min(n_elements, (uint64_t)(s + 1) * per);
-        granne_hip_builder* b = nullptr;
-        granne_hip_index* ix = nullptr;
-        rc = granne_hip_builder_create(&b, config, (const uint8_t*)elements + lo * row, hi - lo, dim, dtype, device_ids[s / per_dev]);
-        if (rc == GRANNE_HIP_OK) rc = granne_hip_builder_build(b, GRANNE_HIP_BUILD_ALL);
-        if (rc == GRANNE_HIP_OK) rc = granne_hip_builder_get_index(b, &ix);
-        if (b) granne_hip_builder_destroy(b);
-        if (rc == GRANNE_HIP_OK) {
-            ixs.push_back(ix);
-            offs.push_back(lo);
+    // one host thread per entry of device_ids builds that entry's shards one after another: the devices build at the same
+    // time (eight GPUs build the eight shards of configs[4] in the time of one). Entries that name the same device share
+    // it -- their builds interleave on the device, which is what the tests of this path on one GPU do.
+    std::vector<granne_hip_index*> ixs(n_shards, nullptr);
+    std::vector<uint64_t> offs(n_shards, 0);
+    std::vector<uint32_t> groups(n_shards, 0);
+    std::vector<int> rcs(n_devices, GRANNE_HIP_OK);
+    std::vector<std::string> whys(n_devices);
+    auto build_group = [&](uint32_t d) {
+        for (uint32_t s = d * per_dev; s < std::min(n_shards, (d + 1) * per_dev) && rcs[d] == GRANNE_HIP_OK; ++s) {
+            const uint64_t lo = std::min(n_elements, (uint64_t)s * per), hi = std::min(n_elements, (uint64_t)(s + 1) * per);
+            granne_hip_builder* b = nullptr;
+            int rc = granne_hip_builder_create(&b, config, (const uint8_t*)elements + lo * row, hi - lo, dim, dtype, device_ids[d]);
+            if (rc == GRANNE_HIP_OK) rc = granne_hip_builder_build(b, GRANNE_HIP_BUILD_ALL);
+            if (rc == GRANNE_HIP_OK) rc = granne_hip_builder_get_index(b, &ixs[s]);
+            if (rc != GRANNE_HIP_OK) whys[d] = g_last_error; // (the message is the building thread's own)
+            if (b) granne_hip_builder_destroy(b);
+            offs[s] = lo;
+            groups[s] = d;
+            rcs[d] = rc;
         }
+    };
+    if (n_devices == 1) {
+        build_group(0);
+    } else {
+        std::vector<std::thread> workers;
+        for (uint32_t d = 0; d < n_devices; ++d) workers.emplace_back(build_group, d);
+        for (auto& w : workers) w.join();
     }
+    int rc = GRANNE_HIP_OK;
+    for (uint32_t d = 0; d < n_devices && rc == GRANNE_HIP_OK; ++d)
+        if (rcs[d] != GRANNE_HIP_OK) {
+            rc = rcs[d];
+            g_last_error = whys[d];
+        }
     granne_hip_sharded* sh = nullptr;
-    if (rc == GRANNE_HIP_OK) rc = granne_hip_sharded_create(&sh, ixs.data(), offs.data(), n_shards);
+    if (rc == GRANNE_HIP_OK) rc = granne_hip_sharded_create_grouped(&sh, ixs.data(), offs.data(), n_shards, groups.data());
     if (rc != GRANNE_HIP_OK) {
         const std::string why = g_last_error; // (destroying the shards must not lose the message)
-        for (auto* ix : ixs) granne_hip_index_destroy(ix);
+        for (auto* ix : ixs)
+            if (ix) granne_hip_index_destroy(ix);
         g_last_error = why;
         return rc;
     }
@@ -384,7 +426,17 @@ extern "C" int granne_hip_sharded_set_option(granne_hip_sharded* sh, int option,
         sh->next_slot = 0;
         for (auto& L : sh->slots) {
             int rc = sharded_init_slot(sh, L);
-            if (rc) return rc;
+            if (rc) { // a half-built slot never stays behind: back to one slot, or to none (then every begin fails cleanly)
+                for (auto& X : sh->slots) sharded_free_slot(sh, X);
+                sh->depth = 1;
+                sh->slots.assign(1, granne_hip_sharded::Slot());
+                if (sharded_init_slot(sh, sh->slots[0])) {
+                    sharded_free_slot(sh, sh->slots[0]);
+                    sh->slots.clear();
+                    sh->depth = 0;
+                }
+                return rc;
+            }
         }
         return GRANNE_HIP_OK;
     }
@@ -394,6 +446,11 @@ extern "C" int granne_hip_sharded_set_option(granne_hip_sharded* sh, int option,
         if (value == GRANNE_HIP_SHARDED_EXCHANGE_RCCL) {
             if (!sh->uniform)
                 return fail(GRANNE_HIP_ERR_INVALID, "the all-gather needs the shards in device order, the same number on every device");
+            for (size_t a = 0; a < sh->devices.size(); ++a)
+                for (size_t b = a + 1; b < sh->devices.size(); ++b)
+                    if (sh->devices[a].id == sh->devices[b].id)
+                        return fail(GRANNE_HIP_ERR_INVALID, "the all-gather needs one exchange group per device (groups %zu and %zu share device %d)",
+                                    a, b, sh->devices[a].id);
             RcclApi* api = rccl_api();
             if (!api->handle || !api->why.empty())
                 return fail(GRANNE_HIP_ERR_HIP, "RCCL is not available: %s", api->why.c_str());
@@ -449,10 +506,18 @@ static int sharded_begin_locked(granne_hip_sharded* sh, const void* d_queries, u
     using Slot = granne_hip_sharded::Slot;
     const uint32_t G = (uint32_t)sh->shards.size();
     const uint32_t nd = (uint32_t)sh->devices.size();
-    const uint32_t si = sh->next_slot;
-    Slot& L = sh->slots[si];
-    if (L.busy)
+    // any slot that is free, looked for from the one after the last begun (tickets may be ended in any order)
+    uint32_t si = sh->depth;
+    for (uint32_t t = 0; t < sh->depth && t < sh->slots.size(); ++t) {
+        const uint32_t c = (sh->next_slot + t) % sh->depth;
+        if (!sh->slots[c].busy) {
+            si = c;
+            break;
+        }
+    }
+    if (si >= sh->slots.size())
         return fail(GRANNE_HIP_ERR_INVALID, "%u batches are in flight already (GRANNE_HIP_SHARDED_OPT_DEPTH): end one first", sh->depth);
+    Slot& L = sh->slots[si];
     const size_t pb = (size_t)granne_hip_packed_topk_bytes(nq, num_neighbors);
     const size_t stride = pb + SHARD_STATUS_BYTES;
     const size_t qb = (size_t)nq * sh->dim * elem_size(sh->dtype);
@@ -639,24 +704,30 @@ extern "C" int granne_hip_sharded_search_batches(granne_hip_sharded* sh, const v
     const size_t o_c = o_d + (size_t)nq * k * 4;
     const size_t o_st = (o_c + (size_t)nq * 4 + 15) & ~(size_t)15;
     const size_t total = o_st + 16;
-    struct Quiesce { // whatever way this call ends, nothing it enqueued is still running when it returns
-        granne_hip_sharded* sh;
-        bool armed = true;
-        ~Quiesce() {
-            if (!armed) return;
-            sharded_quiesce(sh);
-            std::lock_guard<std::mutex> lk(sh->mu);
-            for (auto& L : sh->slots) L.busy = false;
-        }
-    } quiesce{sh};
-    DeviceGuard g(sh->merge_device);
-    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", sh->merge_device);
     struct Pending {
         uint32_t batch;
         uint32_t io; // which of the handle's host_io sets carries the batch
         uint64_t ticket;
     };
     std::vector<Pending> pending;
+    struct Quiesce { // whatever way this call ends, nothing it enqueued is still running when it returns
+        granne_hip_sharded* sh;
+        std::vector<Pending>* mine;
+        bool armed = true;
+        ~Quiesce() {
+            if (!armed) return;
+            sharded_quiesce(sh);
+            // the places of THIS call's batches become free; batches other threads have begun through the device-pointer
+            // entries keep theirs (their end_device finds the ticket it was given)
+            std::lock_guard<std::mutex> lk(sh->mu);
+            for (const auto& P : *mine) {
+                const uint32_t si = (uint32_t)(P.ticket & 0xFF);
+                if (si < sh->slots.size() && sh->slots[si].busy && sh->slots[si].seq == (P.ticket >> 8)) sh->slots[si].busy = false;
+            }
+        }
+    } quiesce{sh, &pending};
+    DeviceGuard g(sh->merge_device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", sh->merge_device);
     auto finish = [&](const Pending& P) -> int {
         auto& H = sh->host_io[P.io];
         rc = granne_hip_sharded_end_device(sh, P.ticket, sh->io_stream);
@@ -694,9 +765,18 @@ extern "C" int granne_hip_sharded_search_batches(granne_hip_sharded* sh, const v
         HIP_TRY(hipMemcpyAsync(H.d_io, H.h_pin, qb, hipMemcpyHostToDevice, sh->io_stream));
         HIP_TRY(hipMemsetAsync(H.d_io + o_st, 0, 16, sh->io_stream));
         Pending P{b, io, 0};
-        rc = granne_hip_sharded_begin_device(sh, H.d_io, nq, max_search, num_neighbors, (uint64_t*)(H.d_io + o_ids),
-                                             (float*)(H.d_io + o_d), (uint32_t*)(H.d_io + o_c), (uint32_t*)(H.d_io + o_st),
-                                             sh->io_stream, &P.ticket);
+        for (;;) {
+            rc = granne_hip_sharded_begin_device(sh, H.d_io, nq, max_search, num_neighbors, (uint64_t*)(H.d_io + o_ids),
+                                                 (float*)(H.d_io + o_d), (uint32_t*)(H.d_io + o_c), (uint32_t*)(H.d_io + o_st),
+                                                 sh->io_stream, &P.ticket);
+            // every place taken although this call holds fewer than `depth`: other threads have batches in flight through the
+            // device-pointer entries. This call's oldest batch comes home and its place is taken; with none of its own in
+            // flight the error stands (the caller shares the handle's depth with those threads).
+            if (rc != GRANNE_HIP_ERR_INVALID || pending.empty()) break;
+            const int rf = finish(pending.front());
+            if (rf) return rf;
+            pending.erase(pending.begin());
+        }
         if (rc) return rc;
         pending.push_back(P);
     }

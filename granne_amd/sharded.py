@@ -298,9 +298,9 @@ class ShardedGranne:
 class ShardedHost:
     """granne_hip_sharded_* (include/granne_hip.h): the partitioned index as ONE host process drives it -- what a Rust
     host binds. `indexes`: granne_amd.Granne objects (local ids), any devices; `offsets`: the first
-    global id of each. Device calls take raw device pointers (int) on `self.device` (= the first shard's)."""
+    global id of each; `groups`: the exchange group of each (None: one per device). Device calls take raw device pointers (int) on `self.device` (= the first shard's)."""
 
-    def __init__(self, indexes, offsets, depth=None, exchange=None):
+    def __init__(self, indexes, offsets, depth=None, exchange=None, groups=None):
         from ._lib import SHARDED_OPT_DEPTH, SHARDED_OPT_EXCHANGE, check, lib
         self._lib, self._check = lib(), check
         self.indexes = list(indexes)  # borrowed by the handle: kept alive here
@@ -308,7 +308,11 @@ class ShardedHost:
         handles = (C.c_void_p * G)(*[ix._h for ix in self.indexes])
         offs = (C.c_uint64 * G)(*[int(o) for o in offsets])
         self._h = C.c_void_p()
-        check(self._lib.granne_hip_sharded_create(C.byref(self._h), handles, offs, G))
+        if groups is None:
+            check(self._lib.granne_hip_sharded_create(C.byref(self._h), handles, offs, G))
+        else:  # the exchange group of every shard (several on one device: the multi-device exchange on a single GPU)
+            gr = (C.c_uint32 * G)(*[int(g) for g in groups])
+            check(self._lib.granne_hip_sharded_create_grouped(C.byref(self._h), handles, offs, G, gr))
         self.device = int(self._lib.granne_hip_sharded_device(self._h))
         self.dim, self.np_dtype = self.indexes[0].dim, self.indexes[0].np_dtype
         if depth is not None:

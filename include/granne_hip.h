@@ -154,10 +154,13 @@ int granne_hip_search_batches_device(const granne_hip_index* index, uint32_t n_b
 
 /* granne_hip_search_batch_device in two halves, for a host whose batches arrive one at a time: begin orders the
  * search after what `stream` holds, runs it on one of the index's own streams and returns a ticket at once; end
- * makes `stream` wait for that search. Up to GRANNE_HIP_SEARCH_DEPTH batches of an index may be begun and not yet
- * ended (tickets are ended in any order); their walks share the chip. Arguments as granne_hip_search_batch_device;
+ * makes `stream` wait for that search. Up to GRANNE_HIP_OPT_SEARCH_DEPTH batches of an index (default
+ * GRANNE_HIP_SEARCH_DEPTH, at most GRANNE_HIP_SEARCH_DEPTH_MAX) may be begun and not yet ended; tickets are ended in any
+ * order and a begin takes any free place; their walks share the chip. (HIP maps streams onto GPU_MAX_HW_QUEUES = 4
+ * hardware queues unless the process sets that variable before its first HIP call: a depth beyond 3 pays with more.) Arguments as granne_hip_search_batch_device;
  * the buffers of a batch must stay untouched between its begin and the completion of what follows its end.    */
-#define GRANNE_HIP_SEARCH_DEPTH 3 /* HIP maps streams onto 4 hardware queues by default: the caller's + these */
+#define GRANNE_HIP_SEARCH_DEPTH 3      /* the default depth: HIP maps streams onto 4 hardware queues by default, the caller's + these */
+#define GRANNE_HIP_SEARCH_DEPTH_MAX 16 /* GRANNE_HIP_OPT_SEARCH_DEPTH goes up to this */
 int granne_hip_search_begin_device(const granne_hip_index* index, const void* d_queries, uint32_t nq,
                                    uint32_t max_search, uint32_t num_neighbors, uint64_t* d_out_ids,
                                    float* d_out_dists, uint32_t* d_out_counts, uint64_t* d_out_stats,
@@ -318,6 +321,14 @@ int granne_hip_merge_topk_packed_strided_device(const void* d_packed, uint64_t s
 typedef struct granne_hip_sharded granne_hip_sharded;
 int granne_hip_sharded_create(granne_hip_sharded** out, granne_hip_index* const* shards,
                               const uint64_t* id_offsets, uint32_t n_shards);
+/* The same with the EXCHANGE GROUP of every shard spelled out (groups[s]: any labels; NULL = one group per HIP device =
+ * granne_hip_sharded_create). A group is what the exchange step treats as one device: its first shard fetches a batch's
+ * queries for all of them, its results travel to the merge device together, one event releases its buffers. All shards
+ * of a group live on one device; several groups MAY share a device -- every branch of the multi-device exchange then
+ * runs on a single GPU (tests/test_gpu_sharded.py), with device-local copies. The all-gather exchange needs one group
+ * per device. */
+int granne_hip_sharded_create_grouped(granne_hip_sharded** out, granne_hip_index* const* shards,
+                                      const uint64_t* id_offsets, uint32_t n_shards, const uint32_t* groups);
 void granne_hip_sharded_destroy(granne_hip_sharded* sharded);
 uint32_t granne_hip_sharded_num_shards(const granne_hip_sharded* sharded);
 /* shard s of the handle (borrowed) and the first global id it holds */
@@ -437,8 +448,10 @@ void granne_hip_builder_destroy(granne_hip_builder* builder);
 /* SURVEY.md 8b's `index_create(..., device_ids, n_devices, partitioned)` in one call: the whole element set (host rows,
  * prepared like a Vectors file) is split into n_shards id ranges of ceil(n / n_shards) elements
  * (src/elements/embeddings/parsing.rs:72-98), shard s is built with the GPU builder under `config`
- * (GranneBuilder::new(config, shard).build()) on device_ids[s / ceil(n_shards / n_devices)], and the searchable
- * partitioned index is returned. The handle OWNS its shard indexes (granne_hip_sharded_destroy releases them).      */
+ * (GranneBuilder::new(config, shard).build()) on device_ids[s / ceil(n_shards / n_devices)] -- one host thread per entry
+ * of device_ids, so the devices build at the same time -- and the searchable partitioned index is returned; every entry
+ * of device_ids is an exchange group of its own (granne_hip_sharded_create_grouped), also when two name the same device.
+ * The handle OWNS its shard indexes (granne_hip_sharded_destroy releases them).                                       */
 int granne_hip_sharded_build(granne_hip_sharded** out, const granne_hip_build_config* config, const void* elements,
                              uint64_t n_elements, uint32_t dim, int dtype, uint32_t n_shards,
                              const int* device_ids, uint32_t n_devices);
@@ -462,7 +475,9 @@ enum {
                                          reference's count. (Rounds 3a-3 distinguished three forms of the exact set; one
                                          is left.) Lists beyond 1024 keys and 64-id layers always walk without a set */
     GRANNE_HIP_OPT_VISITED16_LG = 7,  /* retired with the bucket tables it sized: accepted (0..12), ignored */
-    GRANNE_HIP_OPT_LAST_WALKER = 8    /* read-only (get_option): which kernel the index's last search launch took */
+    GRANNE_HIP_OPT_LAST_WALKER = 8,   /* read-only (get_option): which kernel the index's last search launch took */
+    GRANNE_HIP_OPT_SEARCH_DEPTH = 9   /* batches that granne_hip_search_begin_device may have in flight: 1..GRANNE_HIP_SEARCH_DEPTH_MAX
+                                         [GRANNE_HIP_SEARCH_DEPTH]; cannot change while one is */
 };
 enum {
     GRANNE_HIP_WALKER_NONE = 0,          /* no search yet */

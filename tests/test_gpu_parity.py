@@ -713,6 +713,55 @@ def test_begin_end_keeps_batches_in_flight_beside_one_stream(ga, oracle):
     torch.cuda.synchronize()
 
 
+def test_search_depth_is_a_run_time_option_and_any_free_place_is_taken(ga, oracle):
+    """GRANNE_HIP_OPT_SEARCH_DEPTH (1..16, default 3): begin takes ANY free place -- begin 0, 1, 2, end 1, begin again works
+    (round 4 went round-robin and refused it) -- the depth cannot change while a batch is in flight, and eight batches in
+    flight return what eight plain calls return."""
+    import torch
+    from granne_amd import _lib
+    rng = np.random.default_rng(2810)
+    el = prep(oracle, random_floats(rng, 3000, 100), True)
+    oix = oracle.build_index(el, num_neighbors=16, max_search=20, reinsert_elements=False, n_threads=0)
+    gix = ga.Granne("angular_int", el, oix.layers)
+    assert gix.get_option(_lib.OPT_SEARCH_DEPTH) == _lib.SEARCH_DEPTH
+    nb, nq = 8, 64
+    q = prep(oracle, random_floats(rng, nb * nq, 100), True)
+    oi, od, oc, _ = oix.search_batch(q, 30, 10)
+    dq = torch.from_numpy(q).cuda()
+    ids = torch.zeros((nb, nq, 10), dtype=torch.int64, device="cuda")
+    ds = torch.zeros((nb, nq, 10), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros((nb, nq), dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+
+    def begin(b):
+        return gix.search_begin_device(dq[b * nq:(b + 1) * nq].data_ptr(), nq, 30, 10, ids[b].data_ptr(), ds[b].data_ptr(),
+                                       cnt[b].data_ptr(), 0, 0, s)
+    t = [begin(0), begin(1), begin(2)]
+    gix.search_end_device(t[1], s)
+    t.append(begin(3))  # the place of batch 1
+    with pytest.raises(ga.GranneHipError):
+        gix.set_option(_lib.OPT_SEARCH_DEPTH, 8)  # not while batches are in flight
+    for k in (0, 2, 3):
+        gix.search_end_device(t[k], s)
+    with pytest.raises(ga.GranneHipError):
+        gix.set_option(_lib.OPT_SEARCH_DEPTH, 0)
+    with pytest.raises(ga.GranneHipError):
+        gix.set_option(_lib.OPT_SEARCH_DEPTH, _lib.SEARCH_DEPTH_MAX + 1)
+    gix.set_option(_lib.OPT_SEARCH_DEPTH, 8)
+    assert gix.get_option(_lib.OPT_SEARCH_DEPTH) == 8
+    ids.zero_()
+    tickets = [begin(b) for b in range(nb)]
+    with pytest.raises(ga.GranneHipError):
+        begin(0)  # a ninth
+    for tk in reversed(tickets):
+        gix.search_end_device(tk, s)
+    got = ids.clone()
+    torch.cuda.synchronize()
+    assert (got.cpu().numpy().reshape(-1, 10).astype(np.uint64) == oi).all()
+    assert ds.cpu().numpy().reshape(-1, 10).tobytes() == od.tobytes()
+    assert (cnt.cpu().numpy().reshape(-1).astype(np.uint32) == oc).all()
+
+
 def test_many_streams_take_transient_scratch_blocks(ga, oracle):
     """An index caches one scratch block per stream for 64 streams; further streams search with a block of the
     stream-ordered allocator (no device-wide synchronisation, nothing discarded) and return the same results."""

@@ -243,3 +243,81 @@ def test_sharded_build_from_the_whole_element_set(oracle, int8):
     w = _want(oixs, q, ef, k, [b[0] for b in bounds])
     assert (cnt == w[2]).all() and (ids == w[0]).all() and ds.tobytes() == w[1].tobytes()
     sh.close()
+
+
+@pytest.mark.parametrize("int8", [False, True])
+@pytest.mark.parametrize("groups", [[0, 0, 1, 1], [0, 1, 2, 3], [0, 1, 1, 1, 2], [0, 0, 0, 1, 1, 2, 2, 2]])
+def test_exchange_groups_walk_the_multi_device_branches_on_one_gpu(oracle, int8, groups):
+    """granne_hip_sharded_create_grouped: every exchange group is what the exchange step treats as a device of its own. With
+    several groups on the ONE GPU of this box the branches a multi-GPU node takes all run -- the first shard of a remote
+    group fetches the batch's queries for its group (the others wait for them), remote results reach the merge device's
+    gather buffer by a copy of their own, a group's buffers are released by its own event -- with two batches in flight,
+    uniform and non-uniform layouts; results against per-shard oracle searches + the numpy merge. (The copies are
+    device-local here; the all-gather exchange is refused for such a layout: RCCL takes every device once.)"""
+    import torch
+    from granne_amd import _lib, sharded
+    G, k, ef, nb, nq = len(groups), 6, 40, 5, 33
+    _, bounds, gixs, oixs = _shards(oracle, int8, G, 95 + G)
+    offsets = [b[0] for b in bounds]
+    sh = sharded.ShardedHost(gixs, offsets, groups=groups)
+    if len(set(groups)) > 1:
+        with pytest.raises(_lib.GranneHipError):
+            sh.set_option(_lib.SHARDED_OPT_EXCHANGE, _lib.SHARDED_EXCHANGE_RCCL)
+    q = _batches(oracle, int8, nb, nq, 9)
+    want = [_want(oixs, q[b], ef, k, offsets) for b in range(nb)]
+    dq = torch.from_numpy(q).cuda()
+    ids = torch.zeros((nb, nq, k), dtype=torch.int64, device="cuda")
+    ds = torch.zeros((nb, nq, k), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros((nb, nq), dtype=torch.int32, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+
+    def check():
+        torch.cuda.synchronize()
+        for b in range(nb):
+            assert (cnt[b].cpu().numpy().astype(np.uint32) == want[b][2]).all()
+            assert (ids[b].cpu().numpy().astype(np.uint64) == want[b][0]).all()
+            assert ds[b].cpu().numpy().tobytes() == want[b][1].tobytes()
+        ids.zero_(), ds.zero_(), cnt.zero_()
+
+    for b in range(nb):
+        sh.search_batch_device(dq[b].data_ptr(), nq, ef, k, ids[b].data_ptr(), ds[b].data_ptr(), cnt[b].data_ptr(), status.data_ptr(), s)
+    check()
+    assert status.tolist() == [0, 0, 0, 0]
+    tickets = []
+    for b in range(nb):  # two in flight: the slots' buffers and events of every group are reused under pipelining
+        tickets.append(sh.begin_device(dq[b].data_ptr(), nq, ef, k, ids[b].data_ptr(), ds[b].data_ptr(), cnt[b].data_ptr(), 0, s))
+        if b >= 1:
+            sh.end_device(tickets[b - 1], s)
+    sh.end_device(tickets[-1], s)
+    check()
+    h_ids, h_ds, h_cnt = sh.search_batches(q, ef, k)
+    for b in range(nb):
+        assert (h_cnt[b] == want[b][2]).all() and (h_ids[b] == want[b][0]).all() and h_ds[b].tobytes() == want[b][1].tobytes()
+    sh.close()
+
+
+def test_sharded_build_builds_the_groups_at_the_same_time(oracle):
+    """granne_hip_sharded_build with several entries in device_ids: one host thread per entry builds that entry's shards
+    (on eight GPUs the eight shards of configs[4] build in the time of one); two entries that name the same device are two
+    exchange groups on it. The shard graphs equal the oracle's builds of the same ranges whatever the interleaving."""
+    from granne_amd import _lib, sharded
+    rng = np.random.default_rng(96)
+    n, shards, k, ef = 4100, 4, 5, 40
+    el = oracle.normalize_f32(random_floats(rng, n, 32))
+    q = oracle.normalize_f32(random_floats(rng, 30, 32))
+    sh = sharded.ShardedHost.build("angular", el, shards, devices=(0, 0), num_neighbors=12, max_search=30)
+    bounds = sharded.shard_bounds(n, shards)
+    assert sh.num_shards() == shards and [sh.shard_offset(s) for s in range(shards)] == [b[0] for b in bounds]
+    oixs = [oracle.build_index(np.ascontiguousarray(el[lo:hi]), num_neighbors=12, max_search=30, n_threads=0, batch_max=65536, batch_div=8)
+            for lo, hi in bounds]
+    for s_ in range(shards):
+        bottom = len(oixs[s_].layers) - 1
+        got, want = sh.shard_layer(s_, bottom), oixs[s_].layers[bottom]
+        assert (got[:, :want.shape[1]] == want).all()
+    with pytest.raises(_lib.GranneHipError):  # two groups on one device: no all-gather
+        sh.set_option(_lib.SHARDED_OPT_EXCHANGE, _lib.SHARDED_EXCHANGE_RCCL)
+    ids, ds, cnt = sh.search_batch(q, ef, k)
+    w = _want(oixs, q, ef, k, [b[0] for b in bounds])
+    assert (cnt == w[2]).all() and (ids == w[0]).all() and ds.tobytes() == w[1].tobytes()
+    sh.close()
