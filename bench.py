@@ -397,24 +397,31 @@ class Bench:
         seq_elapsed = time.perf_counter() - t1
         # one batch per call again, with up to GRANNE_HIP_SEARCH_DEPTH calls in flight beside the ONE caller stream
         # (granne_hip_search_begin_device / _end_device: the index's own streams; default hardware queues)
-        depth_ = _glib.SEARCH_DEPTH
+        def begin_end_run(depth_):
+            index.set_option(_glib.OPT_SEARCH_DEPTH, depth_)
 
-        def begin_end(first, count):
-            tickets = []
-            for i in range(count):
-                b = first + i
-                tickets.append(index.search_begin_device(q_ptr[b], nq, ef, k, i_ptr[b], d_ptr[b], c_ptr[b], s_ptr[b], st_ptr, self.stream))
-                if i >= depth_ - 1:
-                    index.search_end_device(tickets[i - depth_ + 1], self.stream)
-            for tk in tickets[max(0, count - depth_ + 1):]:
-                index.search_end_device(tk, self.stream)
+            def begin_end(first, count):
+                tickets = []
+                for i in range(count):
+                    b = first + i
+                    tickets.append(index.search_begin_device(q_ptr[b], nq, ef, k, i_ptr[b], d_ptr[b], c_ptr[b], s_ptr[b], st_ptr, self.stream))
+                    if i >= depth_ - 1:
+                        index.search_end_device(tickets[i - depth_ + 1], self.stream)
+                for tk in tickets[max(0, count - depth_ + 1):]:
+                    index.search_end_device(tk, self.stream)
 
-        begin_end(0, min(n_batches, 2 * depth_))  # (the index's streams have searched once: their scratch blocks exist)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        begin_end(warmup, steps)
-        torch.cuda.synchronize()
-        be_elapsed = time.perf_counter() - t1
+            begin_end(0, min(n_batches, 2 * depth_))  # (the index's streams have searched once: their scratch blocks exist)
+            torch.cuda.synchronize()
+            t1_ = time.perf_counter()
+            begin_end(warmup, steps)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1_
+
+        be_elapsed = begin_end_run(_glib.SEARCH_DEPTH)  # the default depth (3: with the caller's stream, HIP's four hardware queues)
+        # GRANNE_HIP_OPT_SEARCH_DEPTH = 8: short walks (int8) need more batches in flight to fill the chip (pays fully with
+        # GPU_MAX_HW_QUEUES above HIP's default of 4, which this process does not touch)
+        be8_elapsed = begin_end_run(8)
+        index.set_option(_glib.OPT_SEARCH_DEPTH, _glib.SEARCH_DEPTH)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         kev = [(hip_event(), hip_event()) for _ in range(steps)]
         for i in range(steps):
@@ -476,9 +483,12 @@ class Bench:
             launch_ms, alg_per_launch = mean_ms, alg_per_batch
         return {
             "elapsed": elapsed, "value_local": steps * nq / elapsed, "seq_elapsed": seq_elapsed, "steady": steady,
-            "begin_end": {"value": round(steps * nq / be_elapsed, 1), "ms_per_step": round(be_elapsed / steps * 1e3, 4), "depth": depth_,
-                          "note": "one batch per call, granne_hip_search_begin_device / _end_device: up to %d calls in flight "
-                                  "beside one caller stream (rank-local)" % depth_},
+            "begin_end": {"value": round(steps * nq / be_elapsed, 1), "ms_per_step": round(be_elapsed / steps * 1e3, 4),
+                          "depth": _glib.SEARCH_DEPTH,
+                          "depth8": {"value": round(steps * nq / be8_elapsed, 1), "ms_per_step": round(be8_elapsed / steps * 1e3, 4),
+                                     "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default: 4)")},
+                          "note": "one batch per call, granne_hip_search_begin_device / _end_device: up to `depth` calls in flight "
+                                  "beside one caller stream (rank-local); depth8 = GRANNE_HIP_OPT_SEARCH_DEPTH 8"},
             "ids": ids, "dists": dists, "counts": counts, "status": status, "inflight": inflight, "group": group,
             "calls": len(timed_calls), "slow": slow_n, "spill": spill_n,
             "alg_per_launch": alg_per_launch, "achieved": alg_per_launch / (launch_ms * 1e-3) / 1e9, "launch_ms_mean": launch_ms,
@@ -560,12 +570,15 @@ class Bench:
                                "note": "2 * nq * n * dim flops / wall of the whole operator (HIP events); peak = dense f32 MFMA"})
             else:
                 tiles = (nq + 255) // 256
-                byts = float(tiles) * n * 128
-                timing.update({"kernel": "bf_i8_kernel (v_mfma_i32_32x32x16_i8) + merge + exact re-ranking", "ms": round(ms, 3),
+                byts = float(n) * 128  # the rows ONCE: the tiles of 256 queries of a range run side by side and share them in L2
+                ops = 2.0 * nq * n * 128  # integer multiply-adds the matrix cores execute (rows of 100 padded to K = 128)
+                timing.update({"kernel": "bf_i8_kernel (v_mfma_i32_32x32x32_i8) + merge + exact re-ranking", "ms": round(ms, 3),
                                "value": round(nq / (ms * 1e-3), 1), "value_unit": "queries/s at recall 1.0 (exact scan)",
                                "bound": "hbm", "achieved": round(byts / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(byts / ms / 1e6 / HBM_PEAK_GBPS, 4), "queries": nq, "elements": n, "dim": dim,
-                               "note": "every tile of 256 queries streams the n 128-byte rows once: %d passes" % tiles})
+                               "mfma": {"achieved": round(ops / ms / 1e9, 1), "peak": 3944.0, "unit": "TOP/s", "frac": round(ops / ms / 1e9 / 3944.0, 4)},
+                               "note": "bytes = the n 128-byte rows once (%d query tiles share them in L2); at %d queries per scan the "
+                                       "matrix cores' own time (mfma) is the nearer bound" % (tiles, nq)})
         self._gt_dists = ds.cpu().numpy()
         return ids.cpu().numpy()
 
@@ -1415,6 +1428,8 @@ def _compact_sub(rec):
     for k in ("sequential", "one_batch_calls_in_flight", "steady"):
         if isinstance(rec.get(k), dict):
             c[k] = rec[k].get("value")
+    if isinstance((rec.get("one_batch_calls_in_flight") or {}).get("depth8"), dict):
+        c["one_batch_calls_in_flight_depth8"] = rec["one_batch_calls_in_flight"]["depth8"].get("value")
     cb = rec.get("cpu_baseline")
     if isinstance(cb, dict):
         g = cb.get("gpu_matches_oracle") or {}
@@ -1441,6 +1456,8 @@ def compact_line(out, extras_path=None):
     for k in ("sequential", "one_batch_calls_in_flight", "steady"):
         if isinstance(out.get(k), dict):
             line[k] = _pick(out[k], ("value", "ms_per_step", "depth"))
+            if isinstance(out[k].get("depth8"), dict):
+                line[k]["depth8"] = out[k]["depth8"].get("value")
     if "roofline" in out:
         line["roofline"] = _compact_roofline(out["roofline"])
     if "cpu_baseline" in out:

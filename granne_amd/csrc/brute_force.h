@@ -4,7 +4,7 @@
 // belongs on the matrix cores. It is the recall ground truth of bench.py and an operator of its own
 // (granne_hip_brute_force_device).
 //
-//   scores   v_mfma_f32_32x32x2_f32 (f32 rows) / v_mfma_i32_32x32x16_i8 (int8 rows: exact integer dots). The A operand
+//   scores   v_mfma_f32_32x32x2_f32 (f32 rows) / v_mfma_i32_32x32x32_i8 (int8 rows: exact integer dots). The A operand
 //            is a tile of ELEMENTS staged in LDS, the B operand the wave's 32 QUERIES held in registers for the whole
 //            scan, so that in the 32x32 result a lane owns ONE query (column) and sees 16 elements per block: the
 //            running top-k of that query lives in the lane's registers and is touched only when a score beats its
@@ -28,6 +28,7 @@ namespace granne_hip {
 
 typedef float bf_f32x16 __attribute__((ext_vector_type(16)));
 typedef int bf_i32x16 __attribute__((ext_vector_type(16)));
+typedef int bf_i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t BF_QT = 256;    // queries per block (8 waves x 32: two per SIMD, one scores while the other is checked)
 constexpr uint32_t BF_THREADS = 512;
@@ -44,6 +45,8 @@ struct BruteParams {
     uint64_t* part_ids;      // [ranges][nq][kk]
     float* part_d;           // [ranges][nq][kk]
     uint32_t* part_c;        // [ranges][nq]
+    const float* inv_norm;   // int8: [n] 1 / |x| of every row (made once per index: inv_norm_rows_kernel)
+    const float* tau_in;     // [nq] or null: a score that at least kk elements of the set reach (the priming pass's kk-th best)
 };
 
 // per-lane top list: KK scores descending (a larger dot is a smaller distance), always full length -- the lists are
@@ -72,8 +75,9 @@ struct BfList {
 };
 
 // end of a range: lane l takes the list of lane l + 32 (the other K half's rows of the same query) and writes the joint one
+// `scale`: what a list's scores are multiplied by on the way out (int8 lists hold dot / |x|; the query's 1 / |q| comes here)
 template <int KK>
-__device__ __forceinline__ void bf_write_list(const BruteParams& P, BfList<KK>& L, uint32_t q, bool qlive, uint32_t h) {
+__device__ __forceinline__ void bf_write_list(const BruteParams& P, BfList<KK>& L, uint32_t q, bool qlive, uint32_t h, float scale = 1.0f) {
 #pragma unroll
     for (int i = 0; i < KK; ++i) {
         const float sc = __shfl_xor(L.s[i], 32, 64);
@@ -88,7 +92,8 @@ __device__ __forceinline__ void bf_write_list(const BruteParams& P, BfList<KK>& 
             if ((uint32_t)i < P.kk) {
                 const bool ok = L.id[i] != 0xFFFFFFFFu;
                 P.part_ids[list * P.kk + i] = ok ? (uint64_t)L.id[i] : ~0ull;
-                const float d = 1.0f - L.s[i];
+                const float sc = L.s[i] * scale;
+                const float d = 1.0f - sc;
                 P.part_d[list * P.kk + i] = ok ? (d > 0.0f ? d : 0.0f) : __builtin_inff();
                 cnt += ok ? 1u : 0u;
             }
@@ -97,8 +102,29 @@ __device__ __forceinline__ void bf_write_list(const BruteParams& P, BfList<KK>& 
     }
 }
 
+// The threshold a scan starts from. Every element range used to warm its lists up from nothing -- k ln(n / k) inserts of a
+// 16-deep register list per query and range, under exec masks: 14 of the 18 vector instructions per 64 scores of the
+// round-4 int8 scan (profiles/r4_bruteforce_i8_sq_pmc.csv). A priming pass over the first 1/64 of the rows leaves its
+// kk-th best score per query; no element below it can be among the kk best of the whole set (the sample alone holds kk
+// that reach it), so the scan proper starts there (one ulp below: the sample's own kk-th must pass `>`).
+// the priming pass: the best score of (range, query), the two lanes of a query joined
+__device__ __forceinline__ void bf_write_max(const BruteParams& P, float best, uint32_t q, bool qlive, uint32_t h) {
+    best = __builtin_fmaxf(best, __shfl_xor(best, 32, 64));
+    if (qlive && h == 0u) P.part_d[(size_t)blockIdx.y * P.nq + q] = best;
+}
+
+__device__ __forceinline__ float bf_next_below(float t) {
+    if (!(t > -1.0e38f)) return t;
+    if (t > 0.0f) return __uint_as_float(__float_as_uint(t) - 1u);
+    if (t < 0.0f) return __uint_as_float(__float_as_uint(t) + 1u);
+    return -1.0e-30f;
+}
+__device__ __forceinline__ float bf_start_tau(const BruteParams& P, uint32_t q, bool qlive) {
+    return (P.tau_in && qlive) ? bf_next_below(P.tau_in[q]) : -3.0e38f;
+}
+
 // f32: KH = K entries per half (vector components h*KH .. h*KH+KH-1, zero padded), R = 32-element blocks per tile
-template <int KH, int R>
+template <int KH, int R, bool PRIME = false>
 __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P) {
     extern __shared__ __align__(16) uint8_t smem_bf[];
     constexpr uint32_t ET = 32u * R;        // elements per tile
@@ -119,9 +145,10 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
             qr[t] = (qlive && c < P.dim) ? qp[c] : 0.0f;
         }
     }
-    BfList<BF_KMAX> L;
+    BfList<PRIME ? 1 : BF_KMAX> L;
     L.init();
-    float tau = -3.0e38f; // the list's kk-th score
+    float tau = bf_start_tau(P, q, qlive); // what a score must beat: the list's kk-th, never below the priming pass's
+    [[maybe_unused]] float best = -3.0e38f; // PRIME: the largest score of the range, nothing else
 
     const uint64_t r0 = (uint64_t)blockIdx.y * P.per_range;
     const uint64_t r1 = r0 + P.per_range < P.n ? r0 + P.per_range : P.n;
@@ -173,6 +200,14 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
         const bool whole = e0 + ET <= r1;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            if constexpr (PRIME) { // (rows past the range's end are zero rows: score 0, below every real maximum of this data or equal to it)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                    best = (whole || e < r1) ? __builtin_fmaxf(best, acc[r][v]) : best;
+                }
+                continue;
+            }
             float mx = acc[r][0];
 #pragma unroll
             for (int v = 1; v < 16; ++v) mx = __builtin_fmaxf(mx, acc[r][v]);
@@ -183,18 +218,20 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
                     const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
                     if (sc > tau && (whole || e < r1)) {
                         L.insert(sc, (uint32_t)e);
-                        tau = L.worst();
+                        tau = __builtin_fmaxf(tau, L.worst());
                     }
                 }
             }
         }
     }
-    bf_write_list(P, L, q, qlive, h);
+    if constexpr (PRIME) bf_write_max(P, best, q, qlive, h);
+    else bf_write_list(P, L, q, qlive, h);
 }
 
-// int8: device rows of up to 128 bytes (dims up to 128; the scan refuses longer rows). K = 16 per MFMA: lanes 0-31 carry
-// bytes 0-7 of a 16-byte group, lanes 32-63 bytes 8-15. Score = dot / (|x| |q|) with the exact integer dot.
-template <int R>
+// int8: device rows of up to 128 bytes (dims up to 128; the scan refuses longer rows). K = 32 per MFMA
+// (v_mfma_i32_32x32x32_i8, gfx950): lanes 0-31 carry bytes 0-15 of a 32-byte group, lanes 32-63 bytes 16-31.
+// Score = dot / (|x| |q|) with the exact integer dot.
+template <int R, bool PRIME = false>
 __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) {
     extern __shared__ __align__(16) uint8_t smem_bf[];
     constexpr uint32_t ET = 32u * R;
@@ -205,42 +242,52 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
     const uint32_t col = lane & 31u, h = lane >> 5;
     const uint32_t q = blockIdx.x * BF_QT + wave * 32u + col;
     const bool qlive = q < P.nq;
-    long qr[8]; // bytes 16*g + 8*h .. +7 of the query, g = 0..7
+    bf_i32x4 qr[4]; // bytes 32*g + 16*h .. +15 of the query, g = 0..3 (v_mfma_i32_32x32x32_i8: lanes 0-31 carry K 0-15 of a step, lanes 32-63 K 16-31)
     float qinv = 0.0f;
     {
         const int8_t* qp = reinterpret_cast<const int8_t*>(P.queries) + (size_t)(qlive ? q : 0u) * P.dim;
         int dy = 0;
         for (uint32_t c = 0; c < P.dim; ++c) dy += (int)qp[c] * (int)qp[c];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            unsigned long v = 0;
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const uint32_t c = (uint32_t)g * 16u + h * 8u + (uint32_t)b;
-                const unsigned long byte = (qlive && c < P.dim) ? (unsigned long)(uint8_t)qp[c] : 0ul;
-                v |= byte << (8 * b);
+            for (int w = 0; w < 4; ++w) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t c = (uint32_t)g * 32u + h * 16u + (uint32_t)w * 4u + (uint32_t)b;
+                    const uint32_t byte = (qlive && c < P.dim) ? (uint32_t)(uint8_t)qp[c] : 0u;
+                    v |= byte << (8 * b);
+                }
+                qr[g][w] = (int)v;
             }
-            qr[g] = (long)v;
         }
         qinv = dy > 0 ? 1.0f / __builtin_sqrtf((float)dy) : 0.0f;
     }
-    BfList<BF_KMAX> L;
+    BfList<PRIME ? 1 : BF_KMAX> L; // scores WITHOUT the query's 1 / |q| (one factor per lane: it does not change the order)
     L.init();
-    float tau = -3.0e38f;
+    [[maybe_unused]] float best = -3.0e38f; // PRIME: the largest score of the range, nothing else
+    float tau = bf_start_tau(P, q, qlive);
+    tau = (tau > -1.0e38f && qinv > 0.0f) ? bf_next_below(tau / qinv) : -3.0e38f; // the primed threshold in the lists' unit
     const uint64_t r0 = (uint64_t)blockIdx.y * P.per_range;
     const uint64_t r1 = r0 + P.per_range < P.n ? r0 + P.per_range : P.n;
     // 8 threads per row (16 bytes each; device rows shorter than 128 bytes are zero extended); the tile of the NEXT
-    // step travels to registers while this one is scored; the row's squared norm falls out of the same bytes
+    // step travels to registers while this one is scored. (Round 4 took the rows' norms here, from the same bytes: an
+    // integer sum, three cross-lane adds, a correctly rounded square root and division per row and per QUERY TILE -- 1.5 of
+    // the scan's 8.5 ms for a quantity that belongs to the index.)
     constexpr uint32_t NPF = (ET * 8u + BF_THREADS - 1u) / BF_THREADS;
     const uint32_t row_u4 = P.row_bytes / 16u;
     uint4 pf[NPF];
+    float pfn[NPF]; // the row's 1 / |x| travels with its first 16 bytes
     auto fetch = [&](uint64_t e0) {
 #pragma unroll
         for (uint32_t j = 0; j < NPF; ++j) {
             const uint32_t u = tid + BF_THREADS * j;
             const uint32_t row = u >> 3, c = u & 7u;
             pf[j] = make_uint4(0, 0, 0, 0);
+            pfn[j] = 0.0f;
             if (u < ET * 8u && e0 + row < r1 && c < row_u4) pf[j] = *reinterpret_cast<const uint4*>(P.elements + (e0 + row) * P.row_bytes + c * 16u);
+            if (u < ET * 8u && e0 + row < r1 && c == 0u) pfn[j] = P.inv_norm[e0 + row];
         }
     };
     fetch(r0);
@@ -252,14 +299,7 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
             const uint32_t row = u >> 3, c = u & 7u;
             const uint4 v = pf[j];
             if (u < ET * 8u) *reinterpret_cast<uint4*>(tile + (size_t)row * STRIDE + c * 16u) = v;
-            int dx = dot4_i8(v.x, v.x, 0);
-            dx = dot4_i8(v.y, v.y, dx);
-            dx = dot4_i8(v.z, v.z, dx);
-            dx = dot4_i8(v.w, v.w, dx);
-            dx += __shfl_xor(dx, 1, 64);
-            dx += __shfl_xor(dx, 2, 64);
-            dx += __shfl_xor(dx, 4, 64);
-            if (c == 0 && u < ET * 8u) inv[row] = dx > 0 ? 1.0f / __builtin_sqrtf((float)dx) : 0.0f;
+            if (c == 0u && u < ET * 8u) inv[row] = pfn[j];
         }
         __syncthreads();
         if (e0 + ET < r1) fetch(e0 + ET);
@@ -268,42 +308,107 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[r][v] = 0;
+        // 16 bytes per lane and step: one conflict-free ds_read_b128 down a column of rows. The fragments of step g + 1 are
+        // on their way while the matrix cores take step g (read right before its MFMA, each fragment cost the wave its
+        // LDS latency: 16 waits per tile).
+        bf_i32x4 afrag[2][R];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
+        for (int r = 0; r < R; ++r) afrag[0][r] = *reinterpret_cast<const bf_i32x4*>(tile + (size_t)(r * 32 + col) * STRIDE + h * 16);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const long a = *reinterpret_cast<const long*>(tile + (size_t)(r * 32 + col) * STRIDE + g * 16 + h * 8);
-                acc[r] = __builtin_amdgcn_mfma_i32_32x32x16_i8(a, qr[g], acc[r], 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    afrag[(g + 1) & 1][r] = *reinterpret_cast<const bf_i32x4*>(tile + (size_t)(r * 32 + col) * STRIDE + (g + 1) * 32 + h * 16);
             }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[g & 1][r], qr[g], acc[r], 0, 0, 0);
         }
+        // Almost no block holds a score that beats a lane's threshold: one max over the lane's 16 scores decides for the
+        // wave. (A cheaper test -- the largest integer dot times the largest 1 / |x| of the 16 rows -- does not: the norms of
+        // quantized rows spread by +-10 %, as far as the best scores stand above the bulk, and nearly every block passed it.)
         const bool whole = e0 + ET <= r1;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float sc[16];
-            float mx = -3.0e38f;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) { // elements r*32 + 8*g4 + 4*h + 0..3: their 1/|x| in one read
+            for (int g4 = 0; g4 < 4; ++g4) { // elements r*32 + 8*g4 + 4*h + 0..3: their 1 / |x| in one read
                 const float4 iv = *reinterpret_cast<const float4*>(inv + r * 32 + 8 * g4 + 4 * h);
-                sc[g4 * 4 + 0] = (float)acc[r][g4 * 4 + 0] * iv.x * qinv;
-                sc[g4 * 4 + 1] = (float)acc[r][g4 * 4 + 1] * iv.y * qinv;
-                sc[g4 * 4 + 2] = (float)acc[r][g4 * 4 + 2] * iv.z * qinv;
-                sc[g4 * 4 + 3] = (float)acc[r][g4 * 4 + 3] * iv.w * qinv;
+                sc[g4 * 4 + 0] = (float)acc[r][g4 * 4 + 0] * iv.x;
+                sc[g4 * 4 + 1] = (float)acc[r][g4 * 4 + 1] * iv.y;
+                sc[g4 * 4 + 2] = (float)acc[r][g4 * 4 + 2] * iv.z;
+                sc[g4 * 4 + 3] = (float)acc[r][g4 * 4 + 3] * iv.w;
             }
+            if constexpr (PRIME) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) mx = __builtin_fmaxf(mx, sc[v]);
+                for (int v = 0; v < 16; ++v) {
+                    const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                    best = (whole || e < r1) ? __builtin_fmaxf(best, sc[v]) : best;
+                }
+                continue;
+            }
+            float mx = sc[0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) mx = __builtin_fmaxf(mx, sc[v]);
             if (__ballot(mx > tau)) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
                     if (sc[v] > tau && (whole || e < r1)) {
                         L.insert(sc[v], (uint32_t)e);
-                        tau = L.worst();
+                        tau = __builtin_fmaxf(tau, L.worst());
                     }
                 }
             }
         }
     }
-    bf_write_list(P, L, q, qlive, h);
+    if constexpr (PRIME) bf_write_max(P, best * qinv, q, qlive, h);
+    else bf_write_list(P, L, q, qlive, h, qinv);
+}
+
+// 1 / |x| of every int8 row (0 for a zero row), once per index: eight lanes per 128-byte row
+__global__ void inv_norm_rows_kernel(const uint8_t* __restrict__ elements, uint64_t n, uint32_t row_bytes, float* __restrict__ out) {
+    const uint32_t c = threadIdx.x & 7u, units = row_bytes / 16u;
+    for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < ((n + 31u) & ~31ull); row += ((uint64_t)gridDim.x * blockDim.x) >> 3) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < n && c < units) v = *reinterpret_cast<const uint4*>(elements + row * row_bytes + c * 16u);
+        int dx = dot4_i8(v.x, v.x, 0);
+        dx = dot4_i8(v.y, v.y, dx);
+        dx = dot4_i8(v.z, v.z, dx);
+        dx = dot4_i8(v.w, v.w, dx);
+        dx += __shfl_xor(dx, 1, 64);
+        dx += __shfl_xor(dx, 2, 64);
+        dx += __shfl_xor(dx, 4, 64);
+        if (c == 0u && row < n) out[row] = dx > 0 ? 1.0f / __builtin_sqrtf((float)dx) : 0.0f;
+    }
+}
+
+// The priming pass leaves the best score of each of its `ranges` sub-ranges per query; the kk-th largest of those is a
+// score that kk DIFFERENT elements reach (the maxima of kk sub-ranges), so nothing below it is among the kk best of the
+// whole set: the threshold the scan proper starts from (a few ulps of 1 lower: the exact re-ranking has the last word).
+// Fewer than kk sub-ranges: no threshold.
+__global__ void bf_tau_kernel(const float* __restrict__ maxima, uint32_t ranges, uint32_t nq, uint32_t kk, float* __restrict__ tau) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float top[BF_KMAX];
+#pragma unroll
+    for (int i = 0; i < (int)BF_KMAX; ++i) top[i] = -3.0e38f;
+    for (uint32_t r = 0; r < ranges; ++r) {
+        float v = maxima[(size_t)r * nq + q];
+#pragma unroll
+        for (int i = 0; i < (int)BF_KMAX; ++i) { // descending insert
+            const bool take = v > top[i];
+            const float t = top[i];
+            top[i] = take ? v : t;
+            v = take ? t : v;
+        }
+    }
+    float kth = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < (int)BF_KMAX; ++i)
+        if ((uint32_t)i + 1u == kk) kth = top[i];
+    tau[q] = (ranges >= kk && kth > -1.0e38f) ? kth - 2.0e-6f : -3.0e38f;
 }
 
 // merged candidates [nq][kk] u64 -> u32 ids for dists_kernel (entries beyond the count: UNUSED -> +inf)

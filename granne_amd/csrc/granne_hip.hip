@@ -120,6 +120,9 @@ struct granne_hip_index {
     uint64_t opt_visited16_lg = 0;   // 0 auto, else log2(buckets)
     std::atomic<uint64_t> last_slow_count{0};
     std::atomic<uint64_t> last_walker{0}; // GRANNE_HIP_OPT_LAST_WALKER
+    // the exact scan of int8 rows (brute_force.h): 1 / |x| per row, made at the first scan
+    std::mutex norm_mu;
+    float* d_inv_norm = nullptr;
     // host-pointer searches (granne_hip_search / _search_batch): a stream, a device buffer and a pinned
     // staging buffer per concurrent caller, kept for the life of the index -- the reference's API is one
     // query per call (src/index/mod.rs:140-150), so a call must not pay stream creation and hipMalloc
@@ -198,6 +201,7 @@ static void destroy_index(granne_hip_index* ix) {
     for (auto& L : ix->layers)
         if (L.d_adj) (void)hipFree(L.d_adj);
     if (ix->d_layers) (void)hipFree(ix->d_layers);
+    if (ix->d_inv_norm) (void)hipFree(ix->d_inv_norm);
     for (auto* c : ix->call_free) {
         if (c->stream) (void)hipStreamDestroy(c->stream);
         if (c->d_buf) (void)hipFree(c->d_buf);
@@ -1451,21 +1455,26 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     // element ranges: the lists of up to 64 ranges are merged; a range is a whole number of tiles
     uint32_t R = 4, lds = 0;
     void (*fn)(const BruteParams) = nullptr;
+    void (*fn_prime)(const BruteParams) = nullptr; // the same scan keeping only the best score per (range, query)
     if (ix->dtype == GRANNE_HIP_I8) {
         R = 4;
         fn = bf_i8_kernel<4>;
+        fn_prime = bf_i8_kernel<4, true>;
         lds = 32u * R * (128u + 16u) + 32u * R * 4u;
     } else if (ix->dim <= 104) {
         R = 4;
         fn = bf_f32_kernel<52, 4>;
+        fn_prime = bf_f32_kernel<52, 4, true>;
         lds = 32u * R * (2u * 52u + 4u) * 4u;
     } else if (ix->dim <= 200) {
         R = 2;
         fn = bf_f32_kernel<100, 2>;
+        fn_prime = bf_f32_kernel<100, 2, true>;
         lds = 32u * R * (2u * 100u + 4u) * 4u;
     } else {
         R = 1;
         fn = bf_f32_kernel<128, 1>;
+        fn_prime = bf_f32_kernel<128, 1, true>;
         lds = 32u * R * (2u * 128u + 4u) * 4u;
     }
     const uint64_t tile = 32ull * R;
@@ -1479,7 +1488,8 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     const size_t o_pid = 0, o_pd = o_pid + lists * kk * 8, o_pc = o_pd + lists * kk * 4;
     const size_t o_mid = (o_pc + lists * 4 + 15) & ~(size_t)15, o_md = o_mid + (size_t)nq * kk * 8, o_mc = o_md + (size_t)nq * kk * 4;
     const size_t o_cand = (o_mc + (size_t)nq * 4 + 15) & ~(size_t)15, o_ex = o_cand + (size_t)nq * kk * 4;
-    const size_t total = o_ex + (size_t)nq * kk * 4;
+    const size_t o_tau = (o_ex + (size_t)nq * kk * 4 + 15) & ~(size_t)15;
+    const size_t total = o_tau + (size_t)nq * 4;
     uint8_t* scratch = nullptr;
     HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
     struct Release {
@@ -1488,6 +1498,23 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         ~Release() { (void)hipFreeAsync(p, s); }
     } release{scratch, s};
     BruteParams P;
+    P.inv_norm = nullptr;
+    if (ix->dtype == GRANNE_HIP_I8) {
+        granne_hip_index* mix = const_cast<granne_hip_index*>(ix);
+        std::lock_guard<std::mutex> lk(mix->norm_mu);
+        if (!mix->d_inv_norm) { // (rows do not change under an index: reorder builds new arrays and drops this one)
+            float* dn = nullptr;
+            HIP_TRY(hipMalloc((void**)&dn, (size_t)(n ? n : 1) * 4));
+            hipLaunchKernelGGL(inv_norm_rows_kernel, dim3(grid_for(n * 8, 256)), dim3(256), 0, s, ix->d_elements, n, ix->row_bytes, dn);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                (void)hipFree(dn);
+                return fail(GRANNE_HIP_ERR_HIP, "inv_norm_rows_kernel failed");
+            }
+            mix->d_inv_norm = dn;
+            mix->hbm_bytes += (uint64_t)n * 4;
+        }
+        P.inv_norm = mix->d_inv_norm;
+    }
     P.elements = ix->d_elements;
     P.n = n;
     P.row_bytes = ix->row_bytes;
@@ -1500,10 +1527,30 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     P.part_d = (float*)(scratch + o_pd);
     P.part_c = (uint32_t*)(scratch + o_pc);
     if (lds > 64u * 1024u) HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fn, dim3((nq + BF_QT - 1) / BF_QT, (uint32_t)G), dim3(BF_THREADS), lds, s, P);
-    HIP_TRY(hipGetLastError());
+    P.tau_in = nullptr;
     uint64_t zeros[64];
     memset(zeros, 0, sizeof(zeros)); // the lists hold global ids already
+    if (G >= 32) {
+        // the priming pass (brute_force.h, bf_tau_kernel): the first range alone, cut into up to 64 sub-ranges so that the
+        // whole chip scans it (1/64 of the scan proper, without its lists: the best score per sub-range and query)
+        BruteParams Q = P;
+        Q.n = per_range < n ? per_range : n;
+        uint64_t Gs = (Q.n + tile - 1) / tile;
+        if (Gs > 64) Gs = 64;
+        Q.per_range = ((Q.n + Gs - 1) / Gs + tile - 1) / tile * tile;
+        Gs = (Q.n + Q.per_range - 1) / Q.per_range;
+        if (Gs >= kk) {
+            if (lds > 64u * 1024u) HIP_TRY(hipFuncSetAttribute((const void*)fn_prime, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fn_prime, dim3((nq + BF_QT - 1) / BF_QT, (uint32_t)Gs), dim3(BF_THREADS), lds, s, Q);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(bf_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, (const float*)P.part_d, (uint32_t)Gs, nq, kk,
+                               (float*)(scratch + o_tau));
+            HIP_TRY(hipGetLastError());
+            P.tau_in = (const float*)(scratch + o_tau);
+        }
+    }
+    hipLaunchKernelGGL(fn, dim3((nq + BF_QT - 1) / BF_QT, (uint32_t)G), dim3(BF_THREADS), lds, s, P);
+    HIP_TRY(hipGetLastError());
     int rc = merge_launch((const uint8_t*)P.part_ids, (const uint8_t*)P.part_d, (const uint8_t*)P.part_c, (uint64_t)nq * kk * 8,
                           (uint64_t)nq * kk * 4, (uint64_t)nq * 4, zeros, (uint32_t)G, nq, kk, (uint64_t*)(scratch + o_mid),
                           (float*)(scratch + o_md), (uint32_t*)(scratch + o_mc), ix->device, stream);

@@ -178,6 +178,14 @@ static int apply_order(granne_hip_index* ix, const uint32_t* d_order, ReorderScr
     }
     (void)hipFree(ix->d_elements);
     ix->d_elements = new_el;
+    {   // the rows have moved: the scan's per-row norms are taken again when it next runs
+        std::lock_guard<std::mutex> lk(ix->norm_mu);
+        if (ix->d_inv_norm) {
+            (void)hipFree(ix->d_inv_norm);
+            ix->hbm_bytes -= (uint64_t)ix->n_elements * 4;
+            ix->d_inv_norm = nullptr;
+        }
+    }
     if (ix->d_layers) (void)hipFree(ix->d_layers);
     ix->d_layers = nullptr;
     return finish_layers(ix, s);

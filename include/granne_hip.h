@@ -274,7 +274,7 @@ int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, co
 /* Exact k nearest elements of every query by a scan of ALL elements on the matrix cores: the many-to-many form of
  * ElementContainer::dists (src/elements/mod.rs:35-39, src/elements/dense_vector.rs:157-163) -- the recall ground truth
  * next to the graph walk, and the one contraction-shaped piece of the element side (v_mfma_f32_32x32x2_f32 /
- * v_mfma_i32_32x32x16_i8; granne_amd/csrc/brute_force.h). Candidates are SELECTED by the MFMA score; the returned
+ * v_mfma_i32_32x32x32_i8; granne_amd/csrc/brute_force.h). Candidates are SELECTED by the MFMA score; the returned
  * distances are recomputed in the reference's arithmetic (bit-exact for the returned ids) and the results are ordered
  * ascending by (distance, id). The id set can differ from a scalar scan only between elements whose distances to the
  * query are within the MFMA's rounding (~1e-6) of each other at the boundary of the selection: min(k + 6, 16)
