@@ -663,8 +663,9 @@ static search_fn pick_fast_s(uint32_t S, bool trail, int v16) {
     case 4: return pick_fast_v<DT, DIM, 4>(v16);
     case 8: return v16 >= 3 ? fast_kernel<DT, DIM, 8, false, 3> : fast_kernel<DT, DIM, 8>;
     default:
-        if constexpr (DT == DT_F32 && DIM == 0) {
-            return fast_kernel<DT, DIM, 8>; // not reached: max_search <= 508 there
+        if constexpr ((DT == DT_F32 && DIM == 0) || (DT == DT_I8 && DIM >= 256)) {
+            // streamed f32 dims and int8 rows of 256 / 512 bytes: lists of up to 17 x 64 keys (max_search 1024)
+            return v16 >= 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
         } else {
             // lists of 33 / 65 slots (max_search up to 2048 / 4096) exist without a visited set only: plan_launch sends
             // such a search there whatever the option says (an exact set of ~40 x max_search ids fits no LDS)
@@ -676,7 +677,7 @@ static search_fn pick_fast_s(uint32_t S, bool trail, int v16) {
 }
 // Layers of up to 64 ids per node (graphs with num_neighbors 33..63: the GPU builder makes them, BuildConfig::num_neighbors
 // src/index/mod.rs:242) are walked in two passes of 32 pairs per expansion (FastWalker's WIDE) -- instantiated for lists of
-// up to 4 x 64 keys, without a visited set, not for Granne::reorder's trail walks, and for int8 rows of 128 bytes only.
+// up to 17 x 64 keys, without a visited set, not for Granne::reorder's trail walks, and for int8 rows of 128 bytes only.
 static bool fast_wide(const SearchTarget* ix) { return ix->max_dev_width == 64; }
 static bool fast_shape(const SearchTarget* ix) {
     // (ids: 31 bits. A 2^31-element index needs 275 GB for its bottom layer's 128-byte adjacency rows alone, so the
@@ -689,26 +690,23 @@ static bool fast_shape(const SearchTarget* ix) {
 static bool fast_generic(const SearchTarget* ix) { return ix->dtype == GRANNE_HIP_F32 && ix->dim != 100 && ix->dim != 200; }
 // the longest max_search the register walker is instantiated for, by shape
 static uint32_t fast_max_search(const SearchTarget* ix) {
-    if (fast_wide(ix)) return 252u;                                                        // layers of 64 ids: lists of up to 4 x 64 keys
-    if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128 ? FAST_MAX_SEARCH : 252u; // wide int8 rows: lists of up to 4 x 64 keys
-    return fast_generic(ix) ? 508u : FAST_MAX_SEARCH;                                       // streamed f32 dims: up to 8 x 64 keys
+    if (fast_wide(ix)) return 1024u;                                                        // layers of 64 ids: lists of up to 17 x 64 keys
+    if (ix->dtype == GRANNE_HIP_I8) return ix->row_bytes == 128 ? FAST_MAX_SEARCH : 1024u; // wide int8 rows: lists of up to 17 x 64 keys
+    return fast_generic(ix) ? 1024u : FAST_MAX_SEARCH;                                      // streamed f32 dims: up to 17 x 64 keys
 }
 // int8 rows of 256 / 512 bytes (dims 129..512, e.g. the 200- and 300-d rows of benches/distance_computation.rs:29-39)
 template <int ROWB>
 static search_fn pick_fast_i8_wide(uint32_t S, bool trail, int v16) {
-    if (trail) return fast_kernel<DT_I8, ROWB, 1, true>;
-    switch (S) {
-    case 1: return pick_fast_v<DT_I8, ROWB, 1>(v16);
-    case 2: return pick_fast_v<DT_I8, ROWB, 2>(v16);
-    default: return pick_fast_v<DT_I8, ROWB, 4>(v16);
-    }
+    return pick_fast_s<DT_I8, ROWB>(S, trail, v16);
 }
 template <int DT, int DIM>
 static search_fn pick_fast_wide(uint32_t S) {
     switch (S) {
     case 1: return fast_kernel<DT, DIM, 1, false, 3, true>;
     case 2: return fast_kernel<DT, DIM, 2, false, 3, true>;
-    default: return fast_kernel<DT, DIM, 4, false, 3, true>;
+    case 4: return fast_kernel<DT, DIM, 4, false, 3, true>;
+    case 8: return fast_kernel<DT, DIM, 8, false, 3, true>;
+    default: return fast_kernel<DT, DIM, 17, false, 3, true>;
     }
 }
 static search_fn pick_fast_kernel(const SearchTarget* ix, uint32_t S, bool trail, int v16) {

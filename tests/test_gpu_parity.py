@@ -305,7 +305,7 @@ def test_wide_rows_and_large_degree(ga, oracle):
 @pytest.mark.parametrize("nn", [40, 63])
 def test_layers_of_up_to_64_ids_stay_on_the_register_walker(ga, oracle, case, nn):
     """BuildConfig::num_neighbors beyond 32 (src/index/mod.rs:242-250; the GPU builder takes up to 63): rows of 64 ids on
-    the device, walked by the register walker in two passes per expansion for max_search up to 252."""
+    the device, walked by the register walker in two passes per expansion for max_search up to 1024."""
     from granne_amd import _lib
     int8 = case.startswith("i8")
     dim = {"f32_100": 100, "i8_100": 100, "f32_200": 200, "f32_gen48": 48}[case]
@@ -315,11 +315,12 @@ def test_layers_of_up_to_64_ids_stay_on_the_register_walker(ga, oracle, case, nn
     assert max(int((l != oracle.UNUSED).sum(axis=1).max()) for l in oix.layers) > 32
     gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
     q = prep(oracle, random_floats(rng, 64, dim), int8)
-    for ms in (1, 50, 100, 200, 252):
+    for ms in (1, 50, 100, 200, 252, 300, 600, 1024):  # (round 5: lists of up to 17 x 64 keys for these graphs too)
         assert_same(oix, gix, q, ms, 10, has_exact_set=False)
         assert gix.get_option(_lib.OPT_LAST_WALKER) == _lib.WALKER_REGISTER_WIDE, ms
-        assert gix.last_slow_count() == 0
-    assert_same(oix, gix, q, 300, 10)  # longer lists of such graphs: the exact walker
+        if not int8:
+            assert gix.last_slow_count() == 0
+    assert_same(oix, gix, q[:8], 1100, 10)  # longer lists of such graphs: the exact walker
     assert gix.get_option(_lib.OPT_LAST_WALKER) == _lib.WALKER_EXACT
 
 
@@ -407,6 +408,27 @@ def test_large_max_search_stays_on_the_register_walker(ga, oracle, int8, ms):
         assert gix.last_slow_count() == 0
 
 
+@pytest.mark.parametrize("case", ["f32_96", "f32_300", "f32_768", "i8_200", "i8_300"])
+@pytest.mark.parametrize("ms", [300, 600, 1024])
+def test_every_shape_of_the_register_walker_takes_max_search_1024(ga, oracle, case, ms):
+    """The dims the reference benches besides 100 (benches/distance_computation.rs:29-39: 50 / 300; real embeddings: 96,
+    300, 384, 768) walk on the streamed-dim walker, int8 rows of 129..512 dims on the 256- / 512-byte walkers: round 4 took
+    them to max_search 508 / 252 and dropped to the exact walker beyond (a 20x cliff); they now hold lists of up to
+    17 x 64 keys like the unrolled shapes."""
+    from granne_amd import _lib
+    int8 = case.startswith("i8")
+    dim = int(case.split("_")[1])
+    rng = np.random.default_rng(5100 + dim + ms)
+    el = prep(oracle, random_floats(rng, 3000, dim), int8)
+    oix = oracle.build_index(el, num_neighbors=20, max_search=30, n_threads=4)
+    gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
+    q = prep(oracle, random_floats(rng, 24, dim), int8)
+    assert_same(oix, gix, q, ms, 10)
+    assert gix.get_option(_lib.OPT_LAST_WALKER) == _lib.WALKER_REGISTER
+    if not int8:
+        assert gix.last_slow_count() == 0
+
+
 def test_long_lists_on_200d_rows_and_with_an_exact_set_requested(ga, oracle):
     """max_search 1500 / 4096 on 800-byte rows; the long lists keep no visited set whatever OPT_VISITED16 asks for."""
     from granne_amd import _lib
@@ -425,10 +447,10 @@ def test_long_lists_on_200d_rows_and_with_an_exact_set_requested(ga, oracle):
 
 
 def test_max_search_beyond_the_register_lists(ga, oracle):
-    """max_search above 4096 (above 252 for wide int8 rows, 508 for streamed f32 dims) is the exact global-memory
+    """max_search above 4096 (above 1024 for wide int8 rows and streamed f32 dims) is the exact global-memory
     walker's as a whole batch -- its own launch, one block per query up to 32 x OPT_SLOW_BLOCKS. Same results."""
     rng = np.random.default_rng(41)
-    for int8, dim, ms in [(False, 100, 4500), (True, 100, 4097), (True, 200, 300), (False, 50, 600)]:
+    for int8, dim, ms in [(False, 100, 4500), (True, 100, 4097), (True, 200, 1100), (False, 50, 1025)]:
         el = prep(oracle, random_floats(rng, 5000, dim), int8)
         oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
         gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
