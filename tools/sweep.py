@@ -24,11 +24,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--fast-build", action="store_true", help="max_search 50, no reinsertion (7 s instead of 25 s at 10M)")
     ap.add_argument("--cfg", action="append", default=[])
+    ap.add_argument("--nn", type=int, default=30, help="num_neighbors of the build (33..63: layers of 64 ids on the device)")
     ap.add_argument("--latency", action="store_true", help="also time one query per call through the host-pointer API")
     a = ap.parse_args()
     sys.argv = [sys.argv[0]]
     args = bench.parse()
     args.dtype, args.n, args.dim, args.data = a.dtype, a.n, a.dim, a.data
+    args.num_neighbors = a.nn
     if a.fast_build:
         args.build_max_search, args.build_reinsert = 50, 0
     B = bench.Bench(args)
