@@ -69,6 +69,13 @@ SIGNATURES = {
     "granne_hip_search_batches_device": (i32, [vp, u32, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]),
     "granne_hip_search_begin_device": (i32, [vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, C.POINTER(u64)]),
     "granne_hip_search_end_device": (i32, [vp, u64, vp]),
+    "granne_hip_device_malloc": (i32, [C.POINTER(vp), u64, i32]),
+    "granne_hip_device_free": (i32, [vp, i32]),
+    "granne_hip_copy_to_device": (i32, [vp, vp, u64, i32, vp]),
+    "granne_hip_copy_to_host": (i32, [vp, vp, u64, i32, vp]),
+    "granne_hip_stream_create": (i32, [C.POINTER(vp), i32]),
+    "granne_hip_stream_destroy": (i32, [vp, i32]),
+    "granne_hip_stream_synchronize": (i32, [vp, i32]),
     "granne_hip_event_create": (i32, [vp]),
     "granne_hip_event_destroy": (None, [vp]),
     "granne_hip_event_elapsed_ms": (i32, [vp, vp, vp]),

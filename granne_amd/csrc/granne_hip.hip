@@ -1217,6 +1217,61 @@ extern "C" int granne_hip_debug_phases(uint64_t* out, uint32_t nq) {
 }
 #endif
 
+extern "C" int granne_hip_device_malloc(void** out_ptr, uint64_t bytes, int device_id) {
+    if (!out_ptr) return fail(GRANNE_HIP_ERR_INVALID, "out_ptr is null");
+    *out_ptr = nullptr;
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    HIP_TRY(hipMalloc(out_ptr, bytes ? bytes : 16));
+    return GRANNE_HIP_OK;
+}
+extern "C" int granne_hip_device_free(void* ptr, int device_id) {
+    if (!ptr) return GRANNE_HIP_OK;
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    HIP_TRY(hipFree(ptr));
+    return GRANNE_HIP_OK;
+}
+extern "C" int granne_hip_copy_to_device(void* d_dst, const void* src, uint64_t bytes, int device_id, void* stream) {
+    if (bytes == 0) return GRANNE_HIP_OK;
+    if (!d_dst || !src) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return GRANNE_HIP_OK;
+}
+extern "C" int granne_hip_copy_to_host(void* dst, const void* d_src, uint64_t bytes, int device_id, void* stream) {
+    if (bytes == 0) return GRANNE_HIP_OK;
+    if (!dst || !d_src) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return GRANNE_HIP_OK;
+}
+extern "C" int granne_hip_stream_create(void** out_stream, int device_id) {
+    if (!out_stream) return fail(GRANNE_HIP_ERR_INVALID, "out_stream is null");
+    *out_stream = nullptr;
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out_stream = (void*)s;
+    return GRANNE_HIP_OK;
+}
+extern "C" int granne_hip_stream_destroy(void* stream, int device_id) {
+    if (!stream) return GRANNE_HIP_OK;
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return GRANNE_HIP_OK;
+}
+extern "C" int granne_hip_stream_synchronize(void* stream, int device_id) {
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", device_id);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GRANNE_HIP_OK;
+}
+
 extern "C" int granne_hip_event_create(void** out_event) {
     if (!out_event) return fail(GRANNE_HIP_ERR_INVALID, "out_event is null");
     hipEvent_t e = nullptr;

@@ -182,6 +182,18 @@ int granne_hip_event_create(void** out_event);
 void granne_hip_event_destroy(void* event);
 int granne_hip_event_elapsed_ms(void* before, void* after, float* out_ms);
 
+/* Device memory and streams for a host language without HIP bindings of its own (INTEGRATION.md's safe Rust wrappers of
+ * the _device entry points are built on these): allocate / free on a device, copy host <-> device ordered on a stream
+ * (pageable host memory: the call returns when the copy is staged, the data is there when the stream reaches it), create
+ * / destroy / wait for a hipStream_t (returned as void*: what every `stream` parameter of this header takes). */
+int granne_hip_device_malloc(void** out_ptr, uint64_t bytes, int device_id);
+int granne_hip_device_free(void* ptr, int device_id);
+int granne_hip_copy_to_device(void* d_dst, const void* src, uint64_t bytes, int device_id, void* stream);
+int granne_hip_copy_to_host(void* dst, const void* d_src, uint64_t bytes, int device_id, void* stream);
+int granne_hip_stream_create(void** out_stream, int device_id);
+int granne_hip_stream_destroy(void* stream, int device_id);
+int granne_hip_stream_synchronize(void* stream, int device_id);
+
 /* Granne::search for one query (host pointers); *out_count results written. */
 int granne_hip_search(const granne_hip_index* index, const void* query, uint32_t max_search,
                       uint32_t num_neighbors, uint64_t* out_ids, float* out_dists, uint32_t* out_count);

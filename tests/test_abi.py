@@ -116,3 +116,63 @@ def test_argument_validation_needs_no_device(lib):
     assert lib.granne_hip_sharded_device(None) == -1
     assert lib.granne_hip_sharded_build(None, None, p, 4, 8, 0, 2, None, 1) == _lib.ERR_INVALID
     assert not lib.granne_hip_sharded_shard(None, 0) and lib.granne_hip_sharded_shard_offset(None, 0) == 0
+
+
+def test_rust_wrappers_call_the_entry_points_they_claim():
+    """INTEGRATION.md's src/gpu.rs: the safe wrappers of the device-resident entries (round 5) call exactly the prototype
+    each one names, with the argument count the header declares -- a Rust host reaches search_batches_device / begin / end
+    (and the partitioned equivalents) without writing `unsafe` itself."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_sys", os.path.join(ROOT, "tools", "gen_rust_sys.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    arity = {name: len(params) for name, _ret, params in g.protos()}
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+
+    def body_of(owner, fn):
+        i = doc.index("impl<E: GpuElements> %s<E> {" % owner) if owner else 0
+        j = doc.index("pub fn %s" % fn, i)
+        depth, k = 0, doc.index("{", j)
+        for k in range(k, len(doc)):
+            depth += doc[k] == "{"
+            depth -= doc[k] == "}"
+            if depth == 0:
+                break
+        return doc[j:k + 1]
+
+    def call_args(body, name):
+        i = body.index(name + "(") + len(name) + 1
+        depth, parts, cur = 0, [], ""
+        for ch in body[i:]:
+            if ch in "([{":
+                depth += 1
+            if ch in ")]}":
+                if depth == 0:
+                    break
+                depth -= 1
+            if ch == "," and depth == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        parts.append(cur)
+        return [p for p in (x.strip() for x in parts) if p]
+
+    claims = [("GpuGranne", "search_batch_device", "granne_hip_search_batch_device"),
+              ("GpuGranne", "search_batches_device", "granne_hip_search_batches_device"),
+              ("GpuGranne", "begin<'a>", "granne_hip_search_begin_device"),
+              ("GpuGranne", "set_search_depth", "granne_hip_index_set_option"),
+              ("GpuShardedGranne", "search_batch_device", "granne_hip_sharded_search_batch_device"),
+              ("GpuShardedGranne", "begin<'a>", "granne_hip_sharded_begin_device")]
+    for owner, fn, entry in claims:
+        body = body_of(owner, fn)
+        assert "unsafe { %s(" % entry in body, (owner, fn)
+        assert len(call_args(body, entry)) == arity[entry], (owner, fn, call_args(body, entry), arity[entry])
+    for ty, entry in (("InFlight", "granne_hip_search_end_device"), ("ShardedInFlight", "granne_hip_sharded_end_device")):
+        i = doc.index("impl<'a, E: GpuElements> %s<'a, E> {" % ty)
+        body = doc[i:doc.index("impl<'a, E: GpuElements> Drop for %s" % ty, i)]
+        assert len(call_args(body, entry)) == arity[entry], ty
+    # the public signatures of these wrappers hold no raw pointer and are not `unsafe fn`
+    for owner, fn, _ in claims:
+        sig = body_of(owner, fn).split("{", 1)[0]
+        assert "*mut" not in sig and "*const" not in sig and "unsafe" not in sig, sig
