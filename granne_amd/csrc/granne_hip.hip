@@ -745,7 +745,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
     const bool longest = fastS >= 33 || fast_wide(ix); // (lists of 33 / 65 slots, and 64-id layers: instantiated without a set only, whatever the options say)
     if (fastS >= 1 && !trail && ((none && !ix->opt_visited_slots) || longest) && ix->n_elements <= WALK_MAX_ELEMENTS) { // (fast_shape's bound)
         // a launch of a few queries leaves the chip idle: its walkers touch the next node's rows ahead (walk_fast.h, TOUCH)
-        const uint32_t touch_max = knobs().touch_max >= 0 ? (uint32_t)knobs().touch_max : 64u;
+        const uint32_t touch_max = knobs().touch_max >= 0 ? (uint32_t)knobs().touch_max : 256u; // (round 5: +4 % at 256 queries, -10 % at 1024: profiles/r5_touch.txt)
         const bool touch_shape = fastS == 1 && !fast_generic(ix) && !(ix->dtype == GRANNE_HIP_I8 && ix->row_bytes != 128);
         P.v16 = (touch_shape && nq <= touch_max) ? 4 : 3;
         P.visited_slots = P.upper_slots = 0;
