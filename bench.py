@@ -534,6 +534,10 @@ class Bench:
             "per_query": m["per_query"], "same_as_exact_set_walk": m["same_as_exact_set_walk"],
             "traffic_key": key,
         }
+        if traffic:
+            r["traffic_over_algorithmic"] = round(traffic / max(1.0, m["alg_per_launch"]), 3)
+            r["traffic_note"] = ("HBM bytes per launch from the rocprofv3 PMC passes over this shape (profiles/pmc_traffic.json, taken on "
+                                 "the same kernel sources %s; FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes)" % csrc_sha())
         if note:
             r["traffic_note"] = note
         return r
