@@ -30,6 +30,9 @@ typedef float bf_f32x16 __attribute__((ext_vector_type(16)));
 typedef int bf_i32x16 __attribute__((ext_vector_type(16)));
 typedef int bf_i32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef GRANNE_BF_EXP
+#define GRANNE_BF_EXP 0
+#endif
 constexpr uint32_t BF_QT = 256;    // queries per block (8 waves x 32: two per SIMD, one scores while the other is checked)
 constexpr uint32_t BF_THREADS = 512;
 constexpr uint32_t BF_EXTRA = 6;   // candidates selected beyond k, re-ranked by the exact distance
@@ -46,8 +49,31 @@ struct BruteParams {
     float* part_d;           // [ranges][nq][kk]
     uint32_t* part_c;        // [ranges][nq]
     const float* inv_norm;   // int8: [n] 1 / |x| of every row (made once per index: inv_norm_rows_kernel)
+    const float* inv_gmax;   // int8: [ceil(n / 32)][2] the largest 1 / |x| among the 16 rows a lane half sees of a 32-row block (inv_gmax_kernel)
     const float* tau_in;     // [nq] or null: a score that at least kk elements of the set reach (the priming pass's kk-th best)
+    uint32_t* share_hist;    // [nq][BF_SHARE_BUCKETS] or null: elements seen so far per score bucket, by ALL ranges (BfShare)
 };
+
+// Which (query tile, element range) a block takes. Workgroups go to the 8 XCDs round robin by their linear id, each XCD
+// with an L2 of its own: with the plain (blockIdx.x, blockIdx.y) reading, the 4 query tiles that stream the SAME range sat
+// on 4 different XCDs and every row came from HBM four times (5.1 GB per 1024 x 10M int8 scan, with one 16 KB tile in
+// flight per block: the scan was bound by that latency, not by anything it computes). Here the tiles of a range share
+// an XCD: its rows come from HBM once and from that L2 three times.
+struct BfBlock { uint32_t qt, range; };
+__device__ __forceinline__ BfBlock bf_block() {
+    const uint32_t nqt = gridDim.x, G = gridDim.y;
+    const uint32_t L = blockIdx.y * nqt + blockIdx.x; // dispatch order: x fastest
+    BfBlock b;
+    if ((G & 7u) == 0u) {
+        const uint32_t xcd = L & 7u, slot = L >> 3; // slot: 0 .. nqt * G / 8 - 1 within the XCD
+        b.range = xcd * (G >> 3) + slot / nqt;
+        b.qt = slot % nqt;
+    } else {
+        b.qt = blockIdx.x;
+        b.range = blockIdx.y;
+    }
+    return b;
+}
 
 // per-lane top list: KK scores descending (a larger dot is a smaller distance), always full length -- the lists are
 // cut to k + BF_EXTRA when they are written
@@ -77,7 +103,7 @@ struct BfList {
 // end of a range: lane l takes the list of lane l + 32 (the other K half's rows of the same query) and writes the joint one
 // `scale`: what a list's scores are multiplied by on the way out (int8 lists hold dot / |x|; the query's 1 / |q| comes here)
 template <int KK>
-__device__ __forceinline__ void bf_write_list(const BruteParams& P, BfList<KK>& L, uint32_t q, bool qlive, uint32_t h, float scale = 1.0f) {
+__device__ __forceinline__ void bf_write_list(const BruteParams& P, BfList<KK>& L, uint32_t range, uint32_t q, bool qlive, uint32_t h, float scale = 1.0f) {
 #pragma unroll
     for (int i = 0; i < KK; ++i) {
         const float sc = __shfl_xor(L.s[i], 32, 64);
@@ -85,7 +111,7 @@ __device__ __forceinline__ void bf_write_list(const BruteParams& P, BfList<KK>& 
         if (h == 0u && e != 0xFFFFFFFFu) L.insert(sc, e);
     }
     if (qlive && h == 0u) {
-        const size_t list = (size_t)blockIdx.y * P.nq + q;
+        const size_t list = (size_t)range * P.nq + q;
         uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < KK; ++i) {
@@ -108,9 +134,9 @@ __device__ __forceinline__ void bf_write_list(const BruteParams& P, BfList<KK>& 
 // kk-th best score per query; no element below it can be among the kk best of the whole set (the sample alone holds kk
 // that reach it), so the scan proper starts there (one ulp below: the sample's own kk-th must pass `>`).
 // the priming pass: the best score of (range, query), the two lanes of a query joined
-__device__ __forceinline__ void bf_write_max(const BruteParams& P, float best, uint32_t q, bool qlive, uint32_t h) {
+__device__ __forceinline__ void bf_write_max(const BruteParams& P, float best, uint32_t range, uint32_t q, bool qlive, uint32_t h) {
     best = __builtin_fmaxf(best, __shfl_xor(best, 32, 64));
-    if (qlive && h == 0u) P.part_d[(size_t)blockIdx.y * P.nq + q] = best;
+    if (qlive && h == 0u) P.part_d[(size_t)range * P.nq + q] = best;
 }
 
 __device__ __forceinline__ float bf_next_below(float t) {
@@ -123,8 +149,76 @@ __device__ __forceinline__ float bf_start_tau(const BruteParams& P, uint32_t q, 
     return (P.tau_in && qlive) ? bf_next_below(P.tau_in[q]) : -3.0e38f;
 }
 
+// One threshold per QUERY instead of one per (range, lane). The 64 ranges x 2 lane halves of a query each keep a list of
+// their own, and a list only knows its own rows: over 1/128 of 10M rows its kk-th best sits at ~3.6 sigma of the score
+// distribution where the set's kk-th best sits at ~4.6 -- a quarter of all 32x32 blocks held a score that beat SOME lane's
+// threshold and went through the exec-masked insert chain (2/3 of the int8 scan's time). Every insert is an element
+// nobody else sees, so the inserts of all lists are counted per query in a histogram over score buckets [edge(j),
+// edge(j+1)), edge(j) = base * (1 + j/64), base = the primed threshold: once the buckets from j up hold kk elements,
+// nothing below edge(j) is among the kk best of the set. A wave looks its 32 queries' histograms up after 1, 3, 7, 15, ...
+// tiles (the kk-th best of the rows seen so far moves with the LOGARITHM of their number): the two lanes of a query read
+// half the buckets each and join. Counts that arrive late only leave a threshold lower than
+// it could be; the lists' union still holds the kk best, so the merged result does not depend on timing.
+// (First form: every insert walked the histogram and published the threshold through an atomic max -- 32 dependent
+// agent-scope loads under an exec mask per insert: 3.5 -> 13.9 ms.)
+constexpr int BF_SHARE_BUCKETS = 32;
+struct BfShare {
+    float step;                // base / 64: edge(j) = step * (64 + j); 0 = this lane does not share
+    uint32_t tiles, next_poll; // wave-uniform
+    __device__ __forceinline__ void init(const BruteParams& P, bool qlive, float start) {
+        const bool on = P.share_hist != nullptr && qlive && start > 1.0e-30f && start < 1.0e30f;
+        step = on ? start * (1.0f / 64.0f) : 0.0f;
+        tiles = 0;
+        next_poll = 2; // (counted at the top of a tile: after the first tile has been scored)
+    }
+    __device__ __forceinline__ bool on() const { return step > 0.0f; }
+    __device__ __forceinline__ float edge(int j) const { return step * (float)(64 + j); }
+    // an element with score sc (> base) has just been inserted
+    __device__ __forceinline__ void count(const BruteParams& P, uint32_t q, float sc) {
+        int j = (int)(sc * __builtin_amdgcn_rcpf(step)) - 64;
+        j = j < 0 ? 0 : (j > BF_SHARE_BUCKETS - 1 ? BF_SHARE_BUCKETS - 1 : j);
+        while (j > 0 && sc < edge(j)) --j; // the count of bucket j vouches for sc >= edge(j): never round up into one
+        __hip_atomic_fetch_add(P.share_hist + (size_t)q * BF_SHARE_BUCKETS + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // once per tile, the whole wave: the threshold the counts support (or nothing new). Two rounds of 8 loads per lane,
+    // the upper 16 buckets first: lane h = 1 takes the upper 8 of a round, h = 0 the lower 8, the pair joins.
+    __device__ __forceinline__ float poll(const BruteParams& P, uint32_t q, uint32_t h) {
+        tiles += 1;
+        if (tiles != next_poll) return -3.0e38f;
+        next_poll = tiles * 2u; // the kk-th best of the rows seen so far moves with the logarithm of their number
+        const uint32_t* hist = P.share_hist + (size_t)(on() ? q : 0u) * BF_SHARE_BUCKETS;
+        uint32_t carry = 0;
+        int top = -1;
+#pragma unroll 1
+        for (int round = 1; round >= 0 && __ballot(on() && top < 0); --round) {
+            const int b0 = round * 16 + (int)h * 8;
+            uint32_t c[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                c[i] = on() ? __hip_atomic_load(hist + b0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            uint32_t mine = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mine += c[i];
+            const uint32_t other = (uint32_t)__shfl_xor((int)mine, 32, 64);
+            uint32_t sum = carry + (h == 0u ? other : 0u); // what the buckets above this lane's eight hold
+            int found = -1;
+#pragma unroll
+            for (int i = 7; i >= 0; --i) {
+                sum += c[i];
+                if (found < 0 && sum >= P.kk) found = b0 + i;
+            }
+            const int pair = max(found, __shfl_xor(found, 32, 64));
+            if (top < 0) top = pair;
+            carry += mine + other;
+        }
+        return (on() && top > 0) ? bf_next_below(edge(top)) : -3.0e38f; // scores must beat it strictly: edge(top) itself passes
+    }
+};
+
 // f32: KH = K entries per half (vector components h*KH .. h*KH+KH-1, zero padded), R = 32-element blocks per tile
-template <int KH, int R, bool PRIME = false>
+// (the shared threshold is compiled out of the f32 scan: it is MFMA-bound -- 0.76 of the f32 matrix peak -- and at 245-252
+// registers the histogram's few more cost it spills: 17.1 -> 18.0 ms with it)
+template <int KH, int R, bool PRIME = false, bool SHARE = false>
 __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P) {
     extern __shared__ __align__(16) uint8_t smem_bf[];
     constexpr uint32_t ET = 32u * R;        // elements per tile
@@ -132,7 +226,8 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
     float* tile = reinterpret_cast<float*>(smem_bf);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, h = lane >> 5;
-    const uint32_t q = blockIdx.x * BF_QT + wave * 32u + col;
+    const BfBlock blk = bf_block();
+    const uint32_t q = blk.qt * BF_QT + wave * 32u + col;
     const bool qlive = q < P.nq;
 
     // the lane's half of its query, in registers for the whole scan
@@ -149,8 +244,10 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
     L.init();
     float tau = bf_start_tau(P, q, qlive); // what a score must beat: the list's kk-th, never below the priming pass's
     [[maybe_unused]] float best = -3.0e38f; // PRIME: the largest score of the range, nothing else
+    [[maybe_unused]] BfShare share;
+    if constexpr (!PRIME && SHARE) share.init(P, qlive, tau);
 
-    const uint64_t r0 = (uint64_t)blockIdx.y * P.per_range;
+    const uint64_t r0 = (uint64_t)blk.range * P.per_range;
     const uint64_t r1 = r0 + P.per_range < P.n ? r0 + P.per_range : P.n;
     const uint32_t row_f4 = P.row_bytes / 16u; // float4 units per device row (rows are zero padded to 16 bytes)
     // The tile of the NEXT step travels from HBM to registers while the matrix cores work on this one
@@ -171,6 +268,9 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
     fetch(r0);
     for (uint64_t e0 = r0; e0 < r1; e0 += ET) {
         __syncthreads(); // the previous tile has been consumed
+        if constexpr (!PRIME && SHARE) {
+            if (P.share_hist) tau = __builtin_fmaxf(tau, share.poll(P, q, h));
+        }
 #pragma unroll
         for (uint32_t j = 0; j < NPF; ++j) {
             const uint32_t u = tid + BF_THREADS * j;
@@ -219,13 +319,16 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
                     if (sc > tau && (whole || e < r1)) {
                         L.insert(sc, (uint32_t)e);
                         tau = __builtin_fmaxf(tau, L.worst());
+                        if constexpr (SHARE) {
+                            if (share.on()) share.count(P, q, sc);
+                        }
                     }
                 }
             }
         }
     }
-    if constexpr (PRIME) bf_write_max(P, best, q, qlive, h);
-    else bf_write_list(P, L, q, qlive, h);
+    if constexpr (PRIME) bf_write_max(P, best, blk.range, q, qlive, h);
+    else bf_write_list(P, L, blk.range, q, qlive, h);
 }
 
 // int8: device rows of up to 128 bytes (dims up to 128; the scan refuses longer rows). K = 32 per MFMA
@@ -238,16 +341,20 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
     constexpr uint32_t STRIDE = 128u + 16u; // bytes per LDS row: an odd number of 16-byte units
     uint8_t* tile = smem_bf;
     float* inv = reinterpret_cast<float*>(smem_bf + (size_t)ET * STRIDE); // [ET] 1 / |x|
+    float* gm = inv + ET;                                                   // [2][R] inv_gmax of the tile's blocks, by lane half
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, h = lane >> 5;
-    const uint32_t q = blockIdx.x * BF_QT + wave * 32u + col;
+    const BfBlock blk = bf_block();
+    const uint32_t q = blk.qt * BF_QT + wave * 32u + col;
     const bool qlive = q < P.nq;
     bf_i32x4 qr[4]; // bytes 32*g + 16*h .. +15 of the query, g = 0..3 (v_mfma_i32_32x32x32_i8: lanes 0-31 carry K 0-15 of a step, lanes 32-63 K 16-31)
     float qinv = 0.0f;
     {
-        const int8_t* qp = reinterpret_cast<const int8_t*>(P.queries) + (size_t)(qlive ? q : 0u) * P.dim;
+        // (every byte read unconditionally at a clamped index, then selected: 64 loads in flight instead of 64 round trips;
+        // |q|^2 from the packed words -- the byte-by-byte forms cost each block ~60 us before its first tile)
+        const uint8_t* qp = P.queries + (size_t)(qlive ? q : 0u) * P.dim;
+        const uint32_t last = P.dim - 1u;
         int dy = 0;
-        for (uint32_t c = 0; c < P.dim; ++c) dy += (int)qp[c] * (int)qp[c];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -256,12 +363,15 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t c = (uint32_t)g * 32u + h * 16u + (uint32_t)w * 4u + (uint32_t)b;
-                    const uint32_t byte = (qlive && c < P.dim) ? (uint32_t)(uint8_t)qp[c] : 0u;
-                    v |= byte << (8 * b);
+                    const uint32_t raw = qp[c < last ? c : last];
+                    const uint32_t keep = (qlive && c < P.dim) ? 0xFFu : 0u; // (a mask, not a select: a select pulls the load under a branch)
+                    v |= (raw & keep) << (8 * b);
                 }
                 qr[g][w] = (int)v;
+                dy = dot4_i8(v, v, dy);
             }
         }
+        dy += __shfl_xor(dy, 32, 64); // the other half of the vector
         qinv = dy > 0 ? 1.0f / __builtin_sqrtf((float)dy) : 0.0f;
     }
     BfList<PRIME ? 1 : BF_KMAX> L; // scores WITHOUT the query's 1 / |q| (one factor per lane: it does not change the order)
@@ -269,7 +379,9 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
     [[maybe_unused]] float best = -3.0e38f; // PRIME: the largest score of the range, nothing else
     float tau = bf_start_tau(P, q, qlive);
     tau = (tau > -1.0e38f && qinv > 0.0f) ? bf_next_below(tau / qinv) : -3.0e38f; // the primed threshold in the lists' unit
-    const uint64_t r0 = (uint64_t)blockIdx.y * P.per_range;
+    [[maybe_unused]] BfShare share; // (every lane of a query derives the same `tau` here: one histogram scale per query)
+    if constexpr (!PRIME) share.init(P, qlive, tau);
+    const uint64_t r0 = (uint64_t)blk.range * P.per_range;
     const uint64_t r1 = r0 + P.per_range < P.n ? r0 + P.per_range : P.n;
     // 8 threads per row (16 bytes each; device rows shorter than 128 bytes are zero extended); the tile of the NEXT
     // step travels to registers while this one is scored. (Round 4 took the rows' norms here, from the same bytes: an
@@ -279,7 +391,11 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
     const uint32_t row_u4 = P.row_bytes / 16u;
     uint4 pf[NPF];
     float pfn[NPF]; // the row's 1 / |x| travels with its first 16 bytes
+    [[maybe_unused]] float pfg = 0.0f; // threads 0 .. 2R-1: inv_gmax of block tid / 2, half tid & 1
     auto fetch = [&](uint64_t e0) {
+        if constexpr (!PRIME) {
+            if (tid < 2u * R) pfg = e0 + 32u * (tid >> 1) < r1 ? P.inv_gmax[((e0 >> 5) + (tid >> 1)) * 2u + (tid & 1u)] : 0.0f;
+        }
 #pragma unroll
         for (uint32_t j = 0; j < NPF; ++j) {
             const uint32_t u = tid + BF_THREADS * j;
@@ -293,6 +409,9 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
     fetch(r0);
     for (uint64_t e0 = r0; e0 < r1; e0 += ET) {
         __syncthreads();
+        if constexpr (!PRIME) {
+            if (P.share_hist) tau = __builtin_fmaxf(tau, share.poll(P, q, h));
+        }
 #pragma unroll
         for (uint32_t j = 0; j < NPF; ++j) {
             const uint32_t u = tid + BF_THREADS * j;
@@ -301,36 +420,64 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
             if (u < ET * 8u) *reinterpret_cast<uint4*>(tile + (size_t)row * STRIDE + c * 16u) = v;
             if (c == 0u && u < ET * 8u) inv[row] = pfn[j];
         }
+        if constexpr (!PRIME) {
+            if (tid < 2u * R) gm[(tid & 1u) * R + (tid >> 1)] = pfg;
+        }
         __syncthreads();
+#if GRANNE_BF_EXP != 1 // (diagnostic builds, tools/build_variant.sh: 1 = no row traffic after the first tile, 2 = no matrix work, 3 = no fragment reads)
         if (e0 + ET < r1) fetch(e0 + ET);
+#endif
         bf_i32x16 acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[r][v] = 0;
-        // 16 bytes per lane and step: one conflict-free ds_read_b128 down a column of rows. The fragments of step g + 1 are
-        // on their way while the matrix cores take step g (read right before its MFMA, each fragment cost the wave its
-        // LDS latency: 16 waits per tile).
+        // 16 bytes per lane and step: one conflict-free ds_read_b128 down a column of rows. The R fragments of step g + 1 are
+        // on their way while the matrix cores take the R independent products of step g. The scheduler is held to that
+        // order: left alone it sank every read to just before its MFMA and paired the two MFMAs of one accumulator back to
+        // back -- 16 LDS latencies and 8 dependent-issue stalls per tile and wave, 4,900 clocks per tile where the matrix
+        // cores need ~1,000 (rocprofv3: 2.5 ms of the 2.9 ms scan).
         bf_i32x4 afrag[2][R];
+#if GRANNE_BF_EXP == 2
+        if (tid == 0xFFFFu)
+#endif
+        {
 #pragma unroll
         for (int r = 0; r < R; ++r) afrag[0][r] = *reinterpret_cast<const bf_i32x4*>(tile + (size_t)(r * 32 + col) * STRIDE + h * 16);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (g + 1 < 4) {
+            if (g + 1 < 4 && (GRANNE_BF_EXP != 3)) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     afrag[(g + 1) & 1][r] = *reinterpret_cast<const bf_i32x4*>(tile + (size_t)(r * 32 + col) * STRIDE + (g + 1) * 32 + h * 16);
             }
-            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[g & 1][r], qr[g], acc[r], 0, 0, 0);
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[GRANNE_BF_EXP == 3 ? 0 : (g & 1)][r], qr[g], acc[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // Almost no block holds a score that beats a lane's threshold: one max over the lane's 16 scores decides for the
-        // wave. (A cheaper test -- the largest integer dot times the largest 1 / |x| of the 16 rows -- does not: the norms of
-        // quantized rows spread by +-10 %, as far as the best scores stand above the bulk, and nearly every block passed it.)
+        }
+        // Almost no block holds a score that beats a lane's threshold, and with the queries' shared threshold (BfShare) that
+        // threshold is sharp: the largest integer dot of the lane's 16 rows times the largest 1 / |x| among them (per index:
+        // inv_gmax) bounds every score of the block from above -- 8 v_max3_i32, one conversion, one product per block
+        // instead of 16 + 16 + 8 and four LDS reads. The float scores are made only where the bound passes. (The norms of
+        // quantized rows spread by +-10 %, so the bound sits ~0.35 sigma of the score distribution below the scores: with
+        // thresholds per (range, lane), at 3.3-3.7 sigma, nearly every block passed it -- round 4's finding; at 4.6 one in
+        // a hundred does.) Negative dots: their scores are <= 0 <= the bound (max with 0).
         const bool whole = e0 + ET <= r1;
+        [[maybe_unused]] float gmv[R];
+        if constexpr (!PRIME) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) gmv[r] = gm[h * R + r];
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            if constexpr (!PRIME) {
+                int im = 0;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) im = max(im, acc[r][v]);
+                if (!__ballot((float)im * gmv[r] > tau)) continue;
+            }
             float sc[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) { // elements r*32 + 8*g4 + 4*h + 0..3: their 1 / |x| in one read
@@ -348,23 +495,19 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
                 }
                 continue;
             }
-            float mx = sc[0];
 #pragma unroll
-            for (int v = 1; v < 16; ++v) mx = __builtin_fmaxf(mx, sc[v]);
-            if (__ballot(mx > tau)) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
-                    if (sc[v] > tau && (whole || e < r1)) {
-                        L.insert(sc[v], (uint32_t)e);
-                        tau = __builtin_fmaxf(tau, L.worst());
-                    }
+            for (int v = 0; v < 16; ++v) {
+                const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                if (sc[v] > tau && (whole || e < r1)) {
+                    L.insert(sc[v], (uint32_t)e);
+                    tau = __builtin_fmaxf(tau, L.worst());
+                    if (share.on()) share.count(P, q, sc[v]);
                 }
             }
         }
     }
-    if constexpr (PRIME) bf_write_max(P, best * qinv, q, qlive, h);
-    else bf_write_list(P, L, q, qlive, h, qinv);
+    if constexpr (PRIME) bf_write_max(P, best * qinv, blk.range, q, qlive, h);
+    else bf_write_list(P, L, blk.range, q, qlive, h, qinv);
 }
 
 // 1 / |x| of every int8 row (0 for a zero row), once per index: eight lanes per 128-byte row
@@ -381,6 +524,23 @@ __global__ void inv_norm_rows_kernel(const uint8_t* __restrict__ elements, uint6
         dx += __shfl_xor(dx, 2, 64);
         dx += __shfl_xor(dx, 4, 64);
         if (c == 0u && row < n) out[row] = dx > 0 ? 1.0f / __builtin_sqrtf((float)dx) : 0.0f;
+    }
+}
+
+// the largest 1 / |x| among the 16 rows that lane half h of a wave sees of the 32-row block b (rows 32b + 8g + 4h + 0..3,
+// g = 0..3: the 32x32 MFMA result's row order); rows past the end count 0
+__global__ void inv_gmax_kernel(const float* __restrict__ inv_norm, uint64_t n, float* __restrict__ out) {
+    const uint64_t total = ((n + 31u) >> 5) * 2u; // (block, half) pairs
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = t >> 1;
+        const uint32_t h = (uint32_t)(t & 1u);
+        float m = 0.0f;
+        for (uint32_t g = 0; g < 4; ++g)
+            for (uint32_t i = 0; i < 4; ++i) {
+                const uint64_t row = b * 32u + 8u * g + 4u * h + i;
+                if (row < n) m = __builtin_fmaxf(m, inv_norm[row]);
+            }
+        out[t] = m;
     }
 }
 

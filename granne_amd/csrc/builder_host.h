@@ -240,11 +240,14 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     const BuildKernels K = pick_build_kernels(b->dtype, b->dim);
     // (apply / final_prune only ever see cap + 1 candidates: their arrays keep the minimum size)
     const uint32_t cand_cap = build_cand_cap(max_search);
-    const uint32_t lds = build_lds_bytes(lrow, cap, cand_cap);
-    const uint32_t lds_rows = build_lds_bytes_rows(lrow, cap, cand_cap); // apply / final_prune (<= lds)
-    if (lds > 160u * 1024u)
-        return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the GPU builder: select_neighbors stages %u candidate rows "
-                    "of %u bytes in LDS (%u bytes, a CU has 163840)", cap + 1, lrow, lds);
+    // long rows stage fewer candidates per gather round (same results, more rounds): 32 up to 640-d f32, 16 at 768-d
+    const uint32_t chunk = build_chunk_for(lrow, cap, cand_cap, 160u * 1024u);
+    if (chunk == 0)
+        return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the GPU builder: select_neighbors stages %u selected and at "
+                    "least 4 candidate rows of %u bytes in LDS (%u bytes, a CU has 163840)", cap + 1, lrow,
+                    build_lds_bytes(lrow, cap, cand_cap, 4));
+    const uint32_t lds = build_lds_bytes(lrow, cap, cand_cap, chunk);
+    const uint32_t lds_rows = build_lds_bytes_rows(lrow, cap, cand_cap, chunk); // apply / final_prune (<= lds)
     if (lds > 64u * 1024u) {
         HIP_TRY(hipFuncSetAttribute((const void*)K.select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)K.apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -290,6 +293,7 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     P.n_seg = S.counters;
     P.selected = S.selected;
     P.cand_cap = cand_cap;
+    P.chunk = chunk;
     HIP_TRY(hipMemsetAsync(S.selected, 0, layer_len ? layer_len : 1, s)); // nothing is known about the rows of a pass
 
     const bool debug = getenv("GRANNE_HIP_DEBUG") != nullptr;

@@ -32,7 +32,7 @@ constexpr int OP_KEY_BITS = 61;
 constexpr uint32_t BUILD_MAX_NEIGHBORS = 63; // one lane per neighbor, +1 for the extra candidate
 constexpr uint32_t BUILD_MAX_CAND = 1024;    // search candidates per element: max_search up to the register walker's longest list
 constexpr uint32_t BUILD_MIN_CAND_CAP = 256; // the candidate arrays' LDS size follows the build's max_search from here up
-constexpr uint32_t BUILD_CHUNK = 32;         // candidate rows staged per gather round
+constexpr uint32_t BUILD_CHUNK = 32;         // candidate rows staged per gather round (BuildParams.chunk: fewer when rows are long)
 constexpr float EPS100 = 100.0f * 1.1920929e-07f; // 100.0 * f32::EPSILON (mod.rs:813, 829)
 
 struct BuildParams {
@@ -60,12 +60,14 @@ struct BuildParams {
     uint32_t* n_seg;
     uint8_t* selected;             // [layer_len]: 1 = the row is the untouched output of select_neighbors (see apply_kernel)
     uint32_t cand_cap;             // entries of the candidate arrays in LDS (>= max_search, >= cap + 1; a multiple of 64)
+    uint32_t chunk;                // candidate rows staged per gather round: BUILD_CHUNK, or 16 / 8 / 4 when rows are long
+                                   // (build_chunk_for); what is computed does not depend on it, only how many rounds it takes
 };
 
 // LDS carve-up shared by the three kernels
 struct BuildLds {
     uint8_t* qrow;    // [lrow]
-    uint8_t* chunk;   // [BUILD_CHUNK][lrow]
+    uint8_t* chunk;   // [P.chunk][lrow]
     uint8_t* selrows; // [cap][lrow]
     uint32_t* cid;    // [cand_cap]
     float* cd;        // [cand_cap]
@@ -80,17 +82,25 @@ __host__ __device__ inline uint32_t build_cand_cap(uint32_t max_search) {
     const uint32_t c = (max_search + 63u) & ~63u;
     return c < BUILD_MIN_CAND_CAP ? BUILD_MIN_CAND_CAP : c;
 }
-__host__ __device__ inline uint32_t build_lds_bytes(uint32_t lrow, uint32_t cap, uint32_t cand_cap) {
+__host__ __device__ inline uint32_t build_lds_bytes(uint32_t lrow, uint32_t cap, uint32_t cand_cap, uint32_t chunk = BUILD_CHUNK) {
     // the pairwise matrix shares the selected-rows stage when that is large enough
-    return lrow * (1 + BUILD_CHUNK + cap) + (lrow * cap < PAIR_BYTES ? PAIR_BYTES : 0u) + cand_cap * 8 + 64 * 4 * 4;
+    return lrow * (1 + chunk + cap) + (lrow * cap < PAIR_BYTES ? PAIR_BYTES : 0u) + cand_cap * 8 + 64 * 4 * 4;
+}
+// the largest chunk stage with which select_neighbors' LDS fits a CU (0: not even 4 rows do). 100-d f32 rows take
+// the full 32; 768-d f32 rows (3 KB) take 16; the selected-rows stage (cap rows) is what bounds the dimension:
+// about 1150-d f32 / 4600-d int8 at 30 neighbors
+__host__ __device__ inline uint32_t build_chunk_for(uint32_t lrow, uint32_t cap, uint32_t cand_cap, uint32_t lds_max) {
+    for (uint32_t c = BUILD_CHUNK; c >= 4u; c >>= 1)
+        if (build_lds_bytes(lrow, cap, cand_cap, c) <= lds_max) return c;
+    return 0u;
 }
 // apply_kernel / final_prune_kernel only ever limit a row of at most cap + 1 candidates: while that is one chunk
 // (select_neighbors_pairs) the selected-rows stage is never touched and is left out -- 21 KB instead of 29 KB per
 // wave at 100-d f32, seven waves per CU instead of five
-__host__ __device__ inline bool build_lds_compact(uint32_t cap) { return cap + 1u <= BUILD_CHUNK; }
-__host__ __device__ inline uint32_t build_lds_bytes_rows(uint32_t lrow, uint32_t cap, uint32_t cand_cap) {
-    if (!build_lds_compact(cap)) return build_lds_bytes(lrow, cap, cand_cap);
-    return lrow * (1 + BUILD_CHUNK) + PAIR_BYTES + cand_cap * 8 + 64 * 4 * 4;
+__host__ __device__ inline bool build_lds_compact(uint32_t cap, uint32_t chunk = BUILD_CHUNK) { return cap + 1u <= chunk; }
+__host__ __device__ inline uint32_t build_lds_bytes_rows(uint32_t lrow, uint32_t cap, uint32_t cand_cap, uint32_t chunk = BUILD_CHUNK) {
+    if (!build_lds_compact(cap, chunk)) return build_lds_bytes(lrow, cap, cand_cap, chunk);
+    return lrow * (1 + chunk) + PAIR_BYTES + cand_cap * 8 + 64 * 4 * 4;
 }
 
 template <int DT, int DIM>
@@ -104,10 +114,10 @@ struct RowWork {
         lane = threadIdx.x;
         L.qrow = smem;
         L.chunk = smem + p.lrow;
-        L.selrows = L.chunk + (size_t)BUILD_CHUNK * p.lrow;
+        L.selrows = L.chunk + (size_t)p.chunk * p.lrow;
         uint8_t* a = L.selrows + (size_t)p.cap * p.lrow;
         L.pair = reinterpret_cast<float*>(L.selrows);
-        if (rows_only && build_lds_compact(p.cap)) {
+        if (rows_only && build_lds_compact(p.cap, p.chunk)) {
             a = L.selrows + PAIR_BYTES;
         } else if (p.lrow * p.cap < PAIR_BYTES) {
             L.pair = reinterpret_cast<float*>(a);
@@ -135,7 +145,7 @@ struct RowWork {
         for (uint32_t u = lane; u < row16; u += 64)
             *reinterpret_cast<uint4*>(dst + (size_t)u * 16) = *reinterpret_cast<const uint4*>(src + (size_t)u * 16);
     }
-    // gather rows ids[0..n) (n <= BUILD_CHUNK, ids in LDS) into the chunk stage
+    // gather rows ids[0..n) (n <= P.chunk, ids in LDS) into the chunk stage
     __device__ __forceinline__ void gather_chunk(const uint32_t* ids, uint32_t n) {
         const uint32_t row16 = P.row_bytes >> 4;
         const uint32_t lrow16 = P.lrow >> 4;
@@ -199,8 +209,8 @@ struct RowWork {
             return n;
         }
         uint32_t nsel = 0;
-        for (uint32_t c0 = 0; c0 < n && nsel < max_neighbors; c0 += BUILD_CHUNK) {
-            const uint32_t cn = min(BUILD_CHUNK, n - c0);
+        for (uint32_t c0 = 0; c0 < n && nsel < max_neighbors; c0 += P.chunk) {
+            const uint32_t cn = min(P.chunk, n - c0);
             __syncthreads();
             gather_chunk(L.cid + c0, cn);
             __syncthreads();
@@ -227,7 +237,7 @@ struct RowWork {
         return nsel;
     }
 
-    // select_neighbors (mod.rs:849-883) for n <= BUILD_CHUNK candidates whose rows already sit in the
+    // select_neighbors (mod.rs:849-883) for n <= P.chunk candidates whose rows already sit in the
     // chunk stage (candidate j in chunk[slot[j]]): the distances the reference evaluates one
     // candidate at a time -- dist(selected, candidate j) -- are a pure function of the pair, so all
     // n(n-1)/2 of them are computed first, 64 pairs at a time, and the selection loop only compares.
@@ -294,9 +304,9 @@ struct RowWork {
         __syncthreads();
         if (lane < n) L.cid[lane] = id; // unsorted for now: gather source
         __syncthreads();
-        const bool one_chunk = n <= BUILD_CHUNK;
-        for (uint32_t c0 = 0; c0 < n; c0 += BUILD_CHUNK) {
-            const uint32_t cn = min(BUILD_CHUNK, n - c0);
+        const bool one_chunk = n <= P.chunk;
+        for (uint32_t c0 = 0; c0 < n; c0 += P.chunk) {
+            const uint32_t cn = min(P.chunk, n - c0);
             gather_chunk(L.cid + c0, cn);
             __syncthreads();
             if (lane >= c0 && lane < c0 + cn && lane < c)
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(64) void apply_kernel(const BuildParams P) {
                     // num_neighbors = node.len(), :916-917. A full row that select_neighbors produced takes the
                     // one-candidate form of the same computation
                     uint32_t nc = 0xFFFFFFFFu;
-                    if (selected && c == P.cap && c + 1u <= BUILD_CHUNK) nc = w.add_one_to_selected(c, other, d, P.cap);
+                    if (selected && c == P.cap && c + 1u <= P.chunk) nc = w.add_one_to_selected(c, other, d, P.cap);
                     if (nc == 0xFFFFFFFFu) nc = w.add_and_limit(c, true, other, d, P.cap);
                     c = nc;
                     selected = true;

@@ -1513,7 +1513,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         R = 4;
         fn = bf_i8_kernel<4>;
         fn_prime = bf_i8_kernel<4, true>;
-        lds = 32u * R * (128u + 16u) + 32u * R * 4u;
+        lds = 32u * R * (128u + 16u) + 32u * R * 4u + 2u * R * 4u;
     } else if (ix->dim <= 104) {
         R = 4;
         fn = bf_f32_kernel<52, 4>;
@@ -1542,7 +1542,9 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     const size_t o_mid = (o_pc + lists * 4 + 15) & ~(size_t)15, o_md = o_mid + (size_t)nq * kk * 8, o_mc = o_md + (size_t)nq * kk * 4;
     const size_t o_cand = (o_mc + (size_t)nq * 4 + 15) & ~(size_t)15, o_ex = o_cand + (size_t)nq * kk * 4;
     const size_t o_tau = (o_ex + (size_t)nq * kk * 4 + 15) & ~(size_t)15;
-    const size_t total = o_tau + (size_t)nq * 4;
+    const size_t o_share = (o_tau + (size_t)nq * 4 + 15) & ~(size_t)15; // what the ranges of a query have seen, per score bucket
+    const size_t share_bytes = (size_t)nq * BF_SHARE_BUCKETS * 4;
+    const size_t total = o_share + share_bytes;
     uint8_t* scratch = nullptr;
     HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
     struct Release {
@@ -1552,13 +1554,16 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     } release{scratch, s};
     BruteParams P;
     P.inv_norm = nullptr;
+    P.inv_gmax = nullptr;
+    const uint64_t n_pad = (n + 31u) & ~31ull; // inv_norm [n_pad], then inv_gmax [n_pad / 32][2]
     if (ix->dtype == GRANNE_HIP_I8) {
         granne_hip_index* mix = const_cast<granne_hip_index*>(ix);
         std::lock_guard<std::mutex> lk(mix->norm_mu);
         if (!mix->d_inv_norm) { // (rows do not change under an index: reorder builds new arrays and drops this one)
             float* dn = nullptr;
-            HIP_TRY(hipMalloc((void**)&dn, (size_t)(n ? n : 1) * 4));
+            HIP_TRY(hipMalloc((void**)&dn, (size_t)(n_pad + n_pad / 16 + 1) * 4));
             hipLaunchKernelGGL(inv_norm_rows_kernel, dim3(grid_for(n * 8, 256)), dim3(256), 0, s, ix->d_elements, n, ix->row_bytes, dn);
+            hipLaunchKernelGGL(inv_gmax_kernel, dim3(grid_for(n_pad / 16 + 1, 256)), dim3(256), 0, s, (const float*)dn, n, dn + n_pad);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
                 (void)hipFree(dn);
                 return fail(GRANNE_HIP_ERR_HIP, "inv_norm_rows_kernel failed");
@@ -1567,6 +1572,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
             mix->hbm_bytes += (uint64_t)n * 4;
         }
         P.inv_norm = mix->d_inv_norm;
+        P.inv_gmax = mix->d_inv_norm + n_pad;
     }
     P.elements = ix->d_elements;
     P.n = n;
@@ -1581,6 +1587,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     P.part_c = (uint32_t*)(scratch + o_pc);
     if (lds > 64u * 1024u) HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     P.tau_in = nullptr;
+    P.share_hist = nullptr;
     uint64_t zeros[64];
     memset(zeros, 0, sizeof(zeros)); // the lists hold global ids already
     if (G >= 32) {
@@ -1600,6 +1607,9 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
                                (float*)(scratch + o_tau));
             HIP_TRY(hipGetLastError());
             P.tau_in = (const float*)(scratch + o_tau);
+            // the ranges of a query tell each other what they have seen (brute_force.h, BfShare)
+            HIP_TRY(hipMemsetAsync(scratch + o_share, 0, share_bytes, s));
+            P.share_hist = (uint32_t*)(scratch + o_share);
         }
     }
     hipLaunchKernelGGL(fn, dim3((nq + BF_QT - 1) / BF_QT, (uint32_t)G), dim3(BF_THREADS), lds, s, P);

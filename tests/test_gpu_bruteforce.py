@@ -53,6 +53,39 @@ def test_brute_force_matches_a_scalar_scan(oracle, int8, dim, n):
             assert abs(float(ds[qi, j]) - float(want_d[qi, j])) <= TOL
 
 
+@pytest.mark.parametrize("int8,dim,n,nq", [(True, 100, 300_000, 300), (False, 100, 300_000, 70), (False, 200, 150_000, 40),
+                                           (True, 64, 1_000_000, 520)])
+def test_primed_scan_with_the_shared_threshold_matches_the_scalar_scan(oracle, int8, dim, n, nq):
+    """Sets large enough for the priming pass and the per-query threshold that the ranges share (brute_force.h, BfShare):
+    the result is the oracle's scan whatever order the ranges publish in -- run twice, identical."""
+    import granne_amd
+    rng = np.random.default_rng(n + dim)
+    raw = random_floats(rng, n, dim)
+    el = oracle.quantize(raw) if int8 else oracle.normalize_f32(raw)
+    rq = random_floats(rng, nq, dim)
+    q = oracle.quantize(rq) if int8 else oracle.normalize_f32(rq)
+    q[5] = el[n - 3]
+    q[6] = 0  # a zero query: every distance the clamp's
+    ix = granne_amd.Granne("angular_int" if int8 else "angular", el, [])
+    oix = oracle.Index(el, [])
+    for k in (10, 16, 1):
+        ids, ds, cnt = ix.brute_force(q, k)
+        ids2, ds2, cnt2 = ix.brute_force(q, k)
+        assert (ids == ids2).all() and ds.tobytes() == ds2.tobytes() and (cnt == cnt2).all()
+        _, want_i, want_d = oix.scan_topk(q, k)
+        assert (cnt == k).all()
+        live = np.ones(nq, bool)
+        live[6] = False
+        assert np.abs(ds[live] - want_d[live]).max() <= TOL
+        same = ids[live] == want_i[live]
+        assert same.mean() > 0.98
+        for qi, j in zip(*np.nonzero(~same)):
+            assert abs(float(ds[live][qi, j]) - float(want_d[live][qi, j])) <= TOL
+        for qi in (0, 5, nq - 1):  # the reference's distances for the returned ids
+            got = np.array([oracle.dist(el[int(e)], q[qi]) for e in ids[qi]], np.float32)
+            assert got.tobytes() == ds[qi].tobytes()
+
+
 def test_brute_force_small_and_ragged(oracle):
     import granne_amd
     from granne_amd import GranneHipError

@@ -149,6 +149,39 @@ def test_append_then_build(ga, oracle):
         assert (b.get_layer(l) == want).all()
 
 
+@pytest.mark.parametrize("n,dim,int8,nn,ms", [
+    (700, 768, False, 30, 40),    # 3 KB rows: 16 candidate rows per gather round instead of 32
+    (500, 1024, False, 30, 40),   # 4 KB rows: 4 per round
+    (600, 3000, True, 30, 40),    # int8 rows of the same length
+    (500, 768, False, 40, 60),    # 64-id rows: more selected rows on the stage, 8 per round
+])
+def test_long_rows_stage_fewer_candidates_per_round(ga, oracle, n, dim, int8, nn, ms):
+    """builder_kernels.h build_chunk_for: the result does not depend on the chunk. Points of low intrinsic dimension so that
+    select_neighbors rejects and add_and_limit_neighbors really prunes (random 768-d points never do)."""
+    rng = np.random.default_rng(dim + n)
+    low = rng.standard_normal((n, 5)).astype(np.float32)
+    raw = low @ rng.standard_normal((5, dim)).astype(np.float32) + 0.01 * rng.standard_normal((n, dim)).astype(np.float32)
+    el = prep(oracle, raw, int8)
+    b = ga.GranneBuilder("angular_int" if int8 else "angular", el, num_neighbors=nn, max_search=ms,
+                         reinsert_elements=True, batch_max=128, batch_div=8)
+    b.build()
+    oix = oracle.build_index(el, num_neighbors=nn, max_search=ms, reinsert_elements=True, batch_max=128,
+                             batch_div=8, n_threads=0)
+    assert b.num_layers() == len(oix.layers)
+    for l, want in enumerate(oix.layers):
+        got = b.get_layer(l)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (l, bad[:5], got[bad[:1]], want[bad[:1]])
+    full = (oix.layers[-1] != 0xFFFFFFFF).sum(axis=1)
+    assert full.min() < nn, "nothing was pruned: the case does not exercise select_neighbors"
+
+
+def test_rows_too_long_for_the_select_stage_are_refused(ga):
+    el = np.ones((64, 1536), np.float32)
+    with pytest.raises(ga.GranneHipError, match="dimension too large"):
+        ga.GranneBuilder("angular", el, num_neighbors=30).build()
+
+
 def test_invalid_configs(ga):
     el = np.zeros((10, 8), np.float32)
     with pytest.raises(ga.GranneHipError):
