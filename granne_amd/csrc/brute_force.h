@@ -33,6 +33,10 @@ typedef int bf_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef GRANNE_BF_EXP
 #define GRANNE_BF_EXP 0
 #endif
+#ifndef GRANNE_BF_SUB
+#define GRANNE_BF_SUB 2
+#endif
+constexpr uint32_t BF_I8_SUB = GRANNE_BF_SUB; // int8 scan: tiles per staging round (bf_i8_kernel)
 constexpr uint32_t BF_QT = 256;    // queries per block (8 waves x 32: two per SIMD, one scores while the other is checked)
 constexpr uint32_t BF_THREADS = 512;
 constexpr uint32_t BF_EXTRA = 6;   // candidates selected beyond k, re-ranked by the exact distance
@@ -337,11 +341,13 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
 template <int R, bool PRIME = false>
 __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) {
     extern __shared__ __align__(16) uint8_t smem_bf[];
-    constexpr uint32_t ET = 32u * R;
+    constexpr uint32_t ET = 32u * R;        // rows per tile: what one pass of the matrix cores scores
+    constexpr uint32_t SUB = BF_I8_SUB;     // tiles per stage: what travels HBM -> registers -> LDS between two barriers
+    constexpr uint32_t ST = ET * SUB;
     constexpr uint32_t STRIDE = 128u + 16u; // bytes per LDS row: an odd number of 16-byte units
     uint8_t* tile = smem_bf;
-    float* inv = reinterpret_cast<float*>(smem_bf + (size_t)ET * STRIDE); // [ET] 1 / |x|
-    float* gm = inv + ET;                                                   // [2][R] inv_gmax of the tile's blocks, by lane half
+    float* inv = reinterpret_cast<float*>(smem_bf + (size_t)ST * STRIDE); // [ST] 1 / |x|
+    float* gm = inv + ST;                                                   // [SUB][2][R] inv_gmax of the tiles' blocks, by lane half
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, h = lane >> 5;
     const BfBlock blk = bf_block();
@@ -387,46 +393,70 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
     // step travels to registers while this one is scored. (Round 4 took the rows' norms here, from the same bytes: an
     // integer sum, three cross-lane adds, a correctly rounded square root and division per row and per QUERY TILE -- 1.5 of
     // the scan's 8.5 ms for a quantity that belongs to the index.)
-    constexpr uint32_t NPF = (ET * 8u + BF_THREADS - 1u) / BF_THREADS;
+    constexpr uint32_t NPF = (ST * 8u + BF_THREADS - 1u) / BF_THREADS;
     const uint32_t row_u4 = P.row_bytes / 16u;
     uint4 pf[NPF];
     float pfn[NPF]; // the row's 1 / |x| travels with its first 16 bytes
-    [[maybe_unused]] float pfg = 0.0f; // threads 0 .. 2R-1: inv_gmax of block tid / 2, half tid & 1
+    [[maybe_unused]] float pfg = 0.0f; // threads 0 .. 2 R SUB - 1: inv_gmax of the stage's block tid / 2, half tid & 1
+    // (a stage wholly inside the range -- all but the last -- loads without per-row bounds: one uniform base, 32-bit
+    // offsets; the guarded form's 64-bit address products and zero selects were a third of the instructions of a stage)
+    static_assert((ST * 8u) % BF_THREADS == 0u, "every thread carries NPF units of a stage");
+    const uint32_t my_row = tid >> 3, my_c = tid & 7u; // unit j: row my_row + 64 j, 16-byte column my_c
+    const bool col_live = my_c < row_u4;
     auto fetch = [&](uint64_t e0) {
         if constexpr (!PRIME) {
-            if (tid < 2u * R) pfg = e0 + 32u * (tid >> 1) < r1 ? P.inv_gmax[((e0 >> 5) + (tid >> 1)) * 2u + (tid & 1u)] : 0.0f;
+            if (tid < 2u * R * SUB) pfg = e0 + 32u * (tid >> 1) < r1 ? P.inv_gmax[((e0 >> 5) + (tid >> 1)) * 2u + (tid & 1u)] : 0.0f;
         }
+        const uint8_t* base = P.elements + e0 * P.row_bytes;
+        const float* nbase = P.inv_norm + e0;
+        if (e0 + ST <= r1) {
 #pragma unroll
-        for (uint32_t j = 0; j < NPF; ++j) {
-            const uint32_t u = tid + BF_THREADS * j;
-            const uint32_t row = u >> 3, c = u & 7u;
-            pf[j] = make_uint4(0, 0, 0, 0);
-            pfn[j] = 0.0f;
-            if (u < ET * 8u && e0 + row < r1 && c < row_u4) pf[j] = *reinterpret_cast<const uint4*>(P.elements + (e0 + row) * P.row_bytes + c * 16u);
-            if (u < ET * 8u && e0 + row < r1 && c == 0u) pfn[j] = P.inv_norm[e0 + row];
+            for (uint32_t j = 0; j < NPF; ++j) {
+                const uint32_t row = my_row + (BF_THREADS / 8u) * j;
+                pf[j] = make_uint4(0, 0, 0, 0);
+                pfn[j] = 0.0f;
+                if (col_live) pf[j] = *reinterpret_cast<const uint4*>(base + row * P.row_bytes + my_c * 16u);
+                if (my_c == 0u) pfn[j] = nbase[row];
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < NPF; ++j) {
+                const uint32_t row = my_row + (BF_THREADS / 8u) * j;
+                pf[j] = make_uint4(0, 0, 0, 0);
+                pfn[j] = 0.0f;
+                if (e0 + row < r1 && col_live) pf[j] = *reinterpret_cast<const uint4*>(base + row * P.row_bytes + my_c * 16u);
+                if (e0 + row < r1 && my_c == 0u) pfn[j] = nbase[row];
+            }
         }
     };
     fetch(r0);
-    for (uint64_t e0 = r0; e0 < r1; e0 += ET) {
+    for (uint64_t e0 = r0; e0 < r1; e0 += ST) {
         __syncthreads();
         if constexpr (!PRIME) {
             if (P.share_hist) tau = __builtin_fmaxf(tau, share.poll(P, q, h));
         }
 #pragma unroll
         for (uint32_t j = 0; j < NPF; ++j) {
-            const uint32_t u = tid + BF_THREADS * j;
-            const uint32_t row = u >> 3, c = u & 7u;
-            const uint4 v = pf[j];
-            if (u < ET * 8u) *reinterpret_cast<uint4*>(tile + (size_t)row * STRIDE + c * 16u) = v;
-            if (c == 0u && u < ET * 8u) inv[row] = pfn[j];
+            const uint32_t row = my_row + (BF_THREADS / 8u) * j;
+            *reinterpret_cast<uint4*>(tile + (size_t)row * STRIDE + my_c * 16u) = pf[j];
+            if (my_c == 0u) inv[row] = pfn[j];
         }
         if constexpr (!PRIME) {
-            if (tid < 2u * R) gm[(tid & 1u) * R + (tid >> 1)] = pfg;
+            if (tid < 2u * R * SUB) gm[((tid >> 1) / R) * 2u * R + (tid & 1u) * R + (tid >> 1) % R] = pfg;
         }
         __syncthreads();
 #if GRANNE_BF_EXP != 1 // (diagnostic builds, tools/build_variant.sh: 1 = no row traffic after the first tile, 2 = no matrix work, 3 = no fragment reads)
-        if (e0 + ET < r1) fetch(e0 + ET);
+        if (e0 + ST < r1) fetch(e0 + ST);
 #endif
+        // (one stage of SUB tiles per pair of barriers: with one tile the block's load round trip -- ~0.9 us of every 2 us
+        // tile, nothing of it hidden by the matrix work between the same two barriers -- was paid per 128 rows)
+#pragma unroll 1
+        for (uint32_t sub = 0; sub < SUB; ++sub) {
+        const uint64_t es = e0 + (uint64_t)sub * ET;
+        if (es >= r1) break;
+        const uint8_t* tile_s = tile + (size_t)sub * ET * STRIDE;
+        const float* inv_s = inv + sub * ET;
+        const float* gm_s = gm + sub * 2u * R;
         bf_i32x16 acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -443,13 +473,13 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
 #endif
         {
 #pragma unroll
-        for (int r = 0; r < R; ++r) afrag[0][r] = *reinterpret_cast<const bf_i32x4*>(tile + (size_t)(r * 32 + col) * STRIDE + h * 16);
+        for (int r = 0; r < R; ++r) afrag[0][r] = *reinterpret_cast<const bf_i32x4*>(tile_s + (size_t)(r * 32 + col) * STRIDE + h * 16);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g + 1 < 4 && (GRANNE_BF_EXP != 3)) {
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    afrag[(g + 1) & 1][r] = *reinterpret_cast<const bf_i32x4*>(tile + (size_t)(r * 32 + col) * STRIDE + (g + 1) * 32 + h * 16);
+                    afrag[(g + 1) & 1][r] = *reinterpret_cast<const bf_i32x4*>(tile_s + (size_t)(r * 32 + col) * STRIDE + (g + 1) * 32 + h * 16);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -464,11 +494,11 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
         // quantized rows spread by +-10 %, so the bound sits ~0.35 sigma of the score distribution below the scores: with
         // thresholds per (range, lane), at 3.3-3.7 sigma, nearly every block passed it -- round 4's finding; at 4.6 one in
         // a hundred does.) Negative dots: their scores are <= 0 <= the bound (max with 0).
-        const bool whole = e0 + ET <= r1;
+        const bool whole = es + ET <= r1;
         [[maybe_unused]] float gmv[R];
         if constexpr (!PRIME) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) gmv[r] = gm[h * R + r];
+            for (int r = 0; r < R; ++r) gmv[r] = gm_s[h * R + r];
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -481,7 +511,7 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
             float sc[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) { // elements r*32 + 8*g4 + 4*h + 0..3: their 1 / |x| in one read
-                const float4 iv = *reinterpret_cast<const float4*>(inv + r * 32 + 8 * g4 + 4 * h);
+                const float4 iv = *reinterpret_cast<const float4*>(inv_s + r * 32 + 8 * g4 + 4 * h);
                 sc[g4 * 4 + 0] = (float)acc[r][g4 * 4 + 0] * iv.x;
                 sc[g4 * 4 + 1] = (float)acc[r][g4 * 4 + 1] * iv.y;
                 sc[g4 * 4 + 2] = (float)acc[r][g4 * 4 + 2] * iv.z;
@@ -490,14 +520,14 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
             if constexpr (PRIME) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                    const uint64_t e = es + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
                     best = (whole || e < r1) ? __builtin_fmaxf(best, sc[v]) : best;
                 }
                 continue;
             }
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                const uint64_t e = es + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
                 if (sc[v] > tau && (whole || e < r1)) {
                     L.insert(sc[v], (uint32_t)e);
                     tau = __builtin_fmaxf(tau, L.worst());
@@ -505,6 +535,7 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
                 }
             }
         }
+        } // sub
     }
     if constexpr (PRIME) bf_write_max(P, best * qinv, blk.range, q, qlive, h);
     else bf_write_list(P, L, blk.range, q, qlive, h, qinv);

@@ -1513,7 +1513,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         R = 4;
         fn = bf_i8_kernel<4>;
         fn_prime = bf_i8_kernel<4, true>;
-        lds = 32u * R * (128u + 16u) + 32u * R * 4u + 2u * R * 4u;
+        lds = BF_I8_SUB * (32u * R * (128u + 16u) + 32u * R * 4u + 2u * R * 4u);
     } else if (ix->dim <= 104) {
         R = 4;
         fn = bf_f32_kernel<52, 4>;
