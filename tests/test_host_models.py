@@ -287,3 +287,77 @@ def test_ranked_merge_of_the_short_lists_equals_two_heaps():
     spec.loader.exec_module(m)
     equal, bailed = m.main(seed=31, rounds=400)
     assert equal > 300 and bailed > 0
+
+
+def test_threshold_shared_through_a_score_histogram_never_passes_the_kth_best():
+    """brute_force.h BfShare: the 128 lists of a query (64 ranges x 2 lane halves) count their inserts per score bucket;
+    whoever looks the histogram up takes the highest bucket edge that kk counted elements reach. Replayed in float32 with
+    the device's bucket arithmetic, lists scanning in a random interleaving and polling on the doubling schedule: at every
+    moment the threshold is at most the kk-th best of the whole set, so the union of the lists ends with the kk best -- in
+    whatever order the lists ran. (The device takes the reciprocal approximately: the downward fix-up of the bucket is
+    what the argument rests on, so the model perturbs the estimate by +-1.)"""
+    f32 = np.float32
+    BUCKETS = 32
+
+    def edge(step, j):
+        return f32(step * f32(64 + j))
+
+    def next_below(t):
+        return np.nextafter(f32(t), f32(-np.inf), dtype=f32)
+
+    rnd = random.Random(5)
+    for trial in range(60):
+        kk = rnd.choice([1, 7, 16])
+        n_lists = rnd.choice([2, 8, 128])
+        per_list = rnd.choice([40, 300, 2000])
+        tie_heavy = trial % 3 == 0
+        rng = np.random.default_rng(trial)
+        scores = rng.normal(0.0, 0.1, (n_lists, per_list)).astype(f32)
+        if tie_heavy:
+            scores = (np.round(scores * 40) / 40).astype(f32)
+        flat = np.sort(scores.ravel())[::-1]
+        kth = flat[kk - 1]
+        # the primed threshold: any score that kk elements reach (here: a low quantile of the top), one ulp below
+        base = next_below(flat[min(len(flat) - 1, kk * rnd.choice([1, 4, 40]))])
+        if not base > 0:
+            continue
+        step = f32(base * f32(1.0 / 64.0))
+        hist = np.zeros(BUCKETS, np.int64)
+        tau = [f32(base)] * n_lists
+        kept = [[] for _ in range(n_lists)]        # every list keeps its own 16 best, like the register lists
+        pos = [0] * n_lists
+        tiles = [0] * n_lists
+        next_poll = [2] * n_lists
+        TILE = 16
+        live = list(range(n_lists))
+        while live:
+            s = rnd.choice(live)
+            tiles[s] += 1
+            if tiles[s] == next_poll[s]:           # BfShare::poll
+                next_poll[s] = tiles[s] * 2
+                total, top = 0, -1
+                for b in range(BUCKETS - 1, -1, -1):
+                    total += int(hist[b])
+                    if total >= kk:
+                        top = b
+                        break
+                if top > 0:
+                    tau[s] = max(tau[s], next_below(edge(step, top)))
+            assert tau[s] <= kth, (trial, tau[s], kth)
+            for sc in scores[s, pos[s]:pos[s] + TILE]:
+                if sc > tau[s]:
+                    kept[s].append(sc)
+                    kept[s] = sorted(kept[s], reverse=True)[:16]
+                    if len(kept[s]) == 16:
+                        tau[s] = max(tau[s], kept[s][-1])
+                    j = int(f32(sc) * f32(1.0 / step)) - 64 + rnd.choice([-1, 0, 0, 1])  # BfShare::count
+                    j = max(0, min(BUCKETS - 1, j))
+                    while j > 0 and sc < edge(step, j):
+                        j -= 1
+                    assert sc >= edge(step, j) or j == 0
+                    hist[j] += 1
+            pos[s] += TILE
+            if pos[s] >= per_list:
+                live.remove(s)
+        union = np.sort(np.array([x for l in kept for x in l], f32))[::-1]
+        assert len(union) >= kk and (union[:kk] == flat[:kk]).all(), trial
