@@ -35,7 +35,8 @@ Rank 0 prints ONE JSON line. Besides the contract fields it carries
   c5_shard      one shard of configs[4] (125M x 100-d int8, batch 4096, ef 200), measured the same way
   partitioned   (WORLD_SIZE > 1 only) C2's 10M points split into WORLD_SIZE id ranges, one per rank: every rank
                 searches the SAME batches, ONE all_gather_into_tensor of the packed per-shard top-k (RCCL) per
-                batch, merge kernel; pipelined two batches deep
+                batch, merge kernel; pipelined two batches deep. Taken AFTER the contract line is printed (a collective
+                one rank fails to reach must not cost the run its headline): bench_extras.json and stderr carry it
   latency_nq1   one query per call through the host-pointer API (the reference's own call shape)
   steady        the same K steps repeated back to back for >= 0.5 s (the contract's K-step window is a few ms)
 """
@@ -120,6 +121,8 @@ def parse():
                          "--c5-elements 125000000 and adds ~110 s: build 80 s)")
     ap.add_argument("--c4-elements", type=int, default=12_500_000, help="elements of the c4_shard sub-record (0 = skip)")
     ap.add_argument("--no-partitioned", action="store_true", help="WORLD_SIZE > 1: skip the partitioned sub-record")
+    ap.add_argument("--partitioned-timeout", type=int, default=240,
+                    help="WORLD_SIZE > 1: seconds the partitioned sub-record (taken after the line is printed) may take per rank")
     ap.add_argument("--force-partitioned", action="store_true", help="take the partitioned sub-record with one rank too (tests)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--sweep-ef", default="50,100,200,400,800,1600,2048,4096", help="ef values of ef_sweep ('' = skip)")
@@ -908,8 +911,10 @@ def run_replica(B, args):
         "kernel_sources_sha": csrc_sha(),
     }
 
-    # ---- N > 1: the partitioned exchange over RCCL, as a sub-record (all ranks take part) ---------------
-    if (world > 1 or args.force_partitioned) and not args.no_partitioned:
+    # ---- the partitioned exchange over RCCL as a sub-record: with ONE rank (--force-partitioned) here, in the line; with
+    # N > 1 ranks only after the line is out (main, partitioned_after_the_line) -- a collective that one rank fails to
+    # reach must not cost the run its headline
+    if world == 1 and args.force_partitioned and not args.no_partitioned:
         out["partitioned"] = partitioned_record(B, args, n, dim, args.dtype, nq, ef, k, args.steps, args.warmup, 1,
                                                 seed_base=SEED + 100)
 
@@ -1536,6 +1541,32 @@ def self_launch(args, argv):
     os.execvpe(cmd[0], cmd, env)
 
 
+def partitioned_after_the_line(B, args, out):
+    """N > 1, replica mode: the partitioned sub-record (every rank one id range of the 10M points, one exchange per batch),
+    taken AFTER rank 0 has printed the contract line. It goes to bench_extras.json and stderr. Every rank arms a watchdog: a
+    rank that fails leaves the others inside a collective, and those leave with their own alarm instead of an RCCL timeout."""
+    import signal
+
+    def give_up(signum, frame):
+        log("partitioned sub-record: no result after %d s on rank %d, leaving it out" % (args.partitioned_timeout, B.rank))
+        os._exit(0)
+
+    signal.signal(signal.SIGALRM, give_up)
+    signal.alarm(int(args.partitioned_timeout))
+    try:
+        rec = partitioned_record(B, args, args.n, args.dim, args.dtype, args.batch, args.ef, args.k, args.steps, args.warmup, 1,
+                                 seed_base=SEED + 100)
+    except Exception as e:  # noqa: BLE001 -- whatever it is, the line is out already
+        log("partitioned sub-record failed on rank %d: %r" % (B.rank, e))
+        sys.stderr.flush()
+        os._exit(0)
+    signal.alarm(0)
+    if B.rank == 0:
+        out["partitioned"] = rec
+        write_extras(out)
+        log("partitioned: " + json.dumps(_finite(_compact_sub(rec)), allow_nan=False))
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1553,6 +1584,8 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(_finite(out), allow_nan=False) if args.full_line else compact_line(out, extras), flush=True)
         os.dup2(2, 1)
+    if args.mode == "replica" and B.world > 1 and not args.no_partitioned:
+        partitioned_after_the_line(B, args, out)
     if B.use_dist:
         B.dist.barrier()
         B.dist.destroy_process_group()
