@@ -14,7 +14,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OVERFLOW, ERR_IO = -1, -2, -3, -4, -5
 
 OPT_VISITED_SLOTS, OPT_FORCE_SLOW, OPT_SLOW_SLOTS, OPT_SLOW_BLOCKS, OPT_OVERFLOW_SLOTS = 1, 2, 3, 4, 5
-OPT_VISITED16, OPT_VISITED16_LG, OPT_LAST_WALKER, OPT_SEARCH_DEPTH = 6, 7, 8, 9
+OPT_VISITED16, OPT_VISITED16_LG, OPT_LAST_WALKER, OPT_SEARCH_DEPTH, OPT_INLINE_TAILS = 6, 7, 8, 9, 10
 WALKER_NONE, WALKER_REGISTER, WALKER_REGISTER_WIDE, WALKER_GENERAL, WALKER_EXACT = 0, 1, 2, 3, 4
 SEARCH_DEPTH = 3  # GRANNE_HIP_SEARCH_DEPTH (the default of OPT_SEARCH_DEPTH)
 SEARCH_DEPTH_MAX = 16  # GRANNE_HIP_SEARCH_DEPTH_MAX
@@ -96,6 +96,8 @@ SIGNATURES = {
     "granne_hip_write_index_file": (i32, [C.c_char_p, u32, vp, vp, vp]),
     "granne_hip_write_elements_file": (i32, [C.c_char_p, vp, u64, u32, i32]),
     "granne_hip_index_save": (i32, [vp, C.c_char_p, C.c_char_p]),
+    "granne_hip_index_encode": (i32, [vp, C.POINTER(vp), C.POINTER(u64)]),
+    "granne_hip_bytes_free": (None, [vp]),
     "granne_hip_index_file_info": (i32, [vp, u64, C.POINTER(u32), vp, vp, u32]),
     "granne_hip_index_file_decode_layer": (i32, [vp, u64, u32, vp, vp]),
     "granne_hip_brute_force_device": (i32, [vp, vp, u32, u32, vp, vp, vp, vp]),

@@ -43,9 +43,9 @@ constexpr uint32_t BF_EXTRA = 6;   // candidates selected beyond k, re-ranked by
 constexpr uint32_t BF_KMAX = 16;   // longest per-lane list (k + BF_EXTRA <= BF_KMAX)
 
 struct BruteParams {
-    const uint8_t* elements; // device rows: [n][row_bytes]
+    const uint8_t* elements; // device rows: row_bytes of (zero padded) data every row_stride bytes
     uint64_t n;
-    uint32_t row_bytes, dim;
+    uint32_t row_bytes, row_stride, dim;
     const uint8_t* queries;  // dense [nq][dim]
     uint32_t nq, kk;         // kk = k + BF_EXTRA entries per list
     uint64_t per_range;      // elements per range (a multiple of the tile)
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
             const uint32_t row = u / UNITS, c4 = u - row * UNITS;
             pf[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (u < ET * UNITS && e0 + row < r1 && c4 < row_f4)
-                pf[j] = *reinterpret_cast<const float4*>(P.elements + (e0 + row) * P.row_bytes + c4 * 16u);
+                pf[j] = *reinterpret_cast<const float4*>(P.elements + (e0 + row) * P.row_stride + c4 * 16u);
         }
     };
     fetch(r0);

@@ -22,7 +22,7 @@ struct granne_hip_builder {
     uint32_t dim = 0;
     int dtype = 0;
     uint64_t n_elements = 0;
-    uint32_t row_bytes = 0;
+    uint32_t row_bytes = 0, row_stride = 0; // data bytes of a device row; bytes from one row to the next
     uint8_t* d_elements = nullptr;
     uint32_t W = 32; // device row width
     std::vector<BuilderLayer> layers;
@@ -99,6 +99,7 @@ extern "C" int granne_hip_builder_create_device(granne_hip_builder** out, const 
     b->dtype = dtype;
     b->n_elements = n_elements;
     b->row_bytes = device_row_bytes(dim, dtype);
+    b->row_stride = device_row_stride(dim, dtype);
     b->W = (cfg->num_neighbors + 31u) & ~31u;
     // reuse the index's element upload (re-layout to the padded device rows)
     granne_hip_index tmp;
@@ -107,6 +108,7 @@ extern "C" int granne_hip_builder_create_device(granne_hip_builder** out, const 
     tmp.dtype = dtype;
     tmp.n_elements = n_elements;
     tmp.row_bytes = b->row_bytes;
+    tmp.row_stride = b->row_stride;
     rc = upload_elements_from_device(&tmp, d_elements, (hipStream_t)stream);
     if (rc == 0 && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = fail(GRANNE_HIP_ERR_HIP, "sync failed");
     b->d_elements = tmp.d_elements;
@@ -151,7 +153,7 @@ extern "C" int granne_hip_builder_append(granne_hip_builder* b, const void* elem
     DeviceGuard g(b->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", b->device);
     const size_t dense = (size_t)b->dim * elem_size(b->dtype);
-    const size_t old_bytes = (size_t)b->n_elements * b->row_bytes, add_bytes = (size_t)n_new * b->row_bytes;
+    const size_t old_bytes = (size_t)b->n_elements * b->row_stride, add_bytes = (size_t)n_new * b->row_stride;
     uint8_t* grown = nullptr;
     void* staged = nullptr;
     auto body = [&]() -> int {
@@ -159,12 +161,12 @@ extern "C" int granne_hip_builder_append(granne_hip_builder* b, const void* elem
         HIP_TRY(hipMalloc(&staged, n_new * dense));
         HIP_TRY(hipMemcpy(staged, elements, n_new * dense, hipMemcpyHostToDevice));
         if (old_bytes) HIP_TRY(hipMemcpyAsync(grown, b->d_elements, old_bytes, hipMemcpyDeviceToDevice, nullptr));
-        if (dense == b->row_bytes) {
+        if (dense == b->row_stride) {
             HIP_TRY(hipMemcpyAsync(grown + old_bytes, staged, add_bytes, hipMemcpyDeviceToDevice, nullptr));
         } else {
-            const uint64_t units = n_new * (b->row_bytes / 16);
+            const uint64_t units = n_new * (b->row_stride / 16);
             hipLaunchKernelGGL(relayout_rows_kernel, dim3(grid_for(units, 256)), dim3(256), 0, nullptr,
-                               (const uint8_t*)staged, grown + old_bytes, n_new, (uint32_t)dense, b->row_bytes);
+                               (const uint8_t*)staged, grown + old_bytes, n_new, (uint32_t)dense, b->row_stride);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipDeviceSynchronize());
@@ -261,6 +263,7 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     T.dim = b->dim;
     T.dtype = b->dtype;
     T.row_bytes = b->row_bytes;
+    T.row_stride = b->row_stride;
     T.d_layers = S.d_layers;
     T.n_layers = last + 1;
     T.max_dev_width = b->W;
@@ -274,6 +277,7 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     BuildParams P;
     P.elements = b->d_elements;
     P.row_bytes = b->row_bytes;
+    P.row_stride = b->row_stride;
     P.dim = b->dim;
     P.lrow = lrow;
     P.adj = L.d_adj;
@@ -315,7 +319,7 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
         const int64_t step = reinsert ? -1 : 1;
 
         // phase A: entry search through the previous layers + search_for_neighbors on this layer
-        int rc = search_launch(&T, b->d_elements + (size_t)first * b->row_bytes, step * (int64_t)b->row_bytes, (uint32_t)B,
+        int rc = search_launch(&T, b->d_elements + (size_t)first * b->row_stride, step * (int64_t)b->row_stride, (uint32_t)B,
                                max_search, max_search, S.s_ids, S.s_dists, S.s_counts, nullptr, S.counters + 1, s,
                                nullptr);
         if (rc) return rc;
@@ -507,8 +511,9 @@ extern "C" int granne_hip_builder_get_index(const granne_hip_builder* b, granne_
     ix->dtype = b->dtype;
     ix->n_elements = b->n_elements;
     ix->row_bytes = b->row_bytes;
+    ix->row_stride = b->row_stride;
     auto body = [&]() -> int {
-        size_t eb = (size_t)b->n_elements * b->row_bytes;
+        size_t eb = (size_t)b->n_elements * b->row_stride;
         HIP_TRY(hipMalloc((void**)&ix->d_elements, eb ? eb : 16));
         ix->hbm_bytes += eb;
         if (eb) HIP_TRY(hipMemcpy(ix->d_elements, b->d_elements, eb, hipMemcpyDeviceToDevice));

@@ -37,7 +37,7 @@ constexpr float EPS100 = 100.0f * 1.1920929e-07f; // 100.0 * f32::EPSILON (mod.r
 
 struct BuildParams {
     const uint8_t* elements;
-    uint32_t row_bytes, dim, lrow; // lrow: LDS row stride (odd multiple of 16 bytes)
+    uint32_t row_bytes, row_stride, dim, lrow; // row_stride: bytes between rows in HBM; lrow: LDS row stride (odd multiple of 16 bytes)
     uint32_t* adj;                 // the layer being built: [len][W]
     uint32_t W;                    // device row width
     uint32_t cap;                  // logical row capacity = BuildConfig.num_neighbors (node.len())
@@ -135,7 +135,7 @@ struct RowWork {
     // copy one element row into LDS (zero padded device row)
     __device__ __forceinline__ void load_row(uint8_t* dst, uint32_t id) {
         const uint32_t row16 = P.row_bytes >> 4;
-        const uint8_t* src = P.elements + (size_t)id * P.row_bytes;
+        const uint8_t* src = P.elements + (size_t)id * P.row_stride;
         for (uint32_t u = lane; u < row16; u += 64)
             *reinterpret_cast<uint4*>(dst + (size_t)u * 16) = *reinterpret_cast<const uint4*>(src + (size_t)u * 16);
     }
@@ -161,7 +161,7 @@ struct RowWork {
         if constexpr (DIM > 0 && DT == DT_F32) row = fc / (uint32_t)(DIM / 4);                            \
         else row = fc / row16;                                                                            \
         uint32_t part = fc - row * row16;                                                                 \
-        V = *reinterpret_cast<const uint4*>(P.elements + (size_t)ids[row] * P.row_bytes + (size_t)part * 16); \
+        V = *reinterpret_cast<const uint4*>(P.elements + (size_t)ids[row] * P.row_stride + (size_t)part * 16); \
         D = f < total ? (row * lrow16 + part) * 16u : 0xFFFFFFFFu;                                        \
     }
             GRANNE_BGATHER(0, v0, d0)

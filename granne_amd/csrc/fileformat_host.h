@@ -401,33 +401,60 @@ extern "C" int granne_hip_write_elements_file(const char* path, const void* elem
     return GRANNE_HIP_OK;
 }
 
+// the index file's bytes of a device-resident index (downloads the layers, encodes them)
+static int encode_device_index(const granne_hip_index* ix, std::vector<uint8_t>* buf) {
+    std::vector<std::vector<uint32_t>> rows(ix->layers.size());
+    std::vector<uint64_t> lens(ix->layers.size());
+    std::vector<const uint32_t*> ptrs(ix->layers.size());
+    std::vector<uint32_t> widths(ix->layers.size());
+    for (size_t l = 0; l < ix->layers.size(); ++l) {
+        const LayerHost& L = ix->layers[l];
+        rows[l].resize((size_t)L.len * L.dev_width);
+        if (!rows[l].empty())
+            HIP_TRY(hipMemcpy(rows[l].data(), L.d_adj, rows[l].size() * 4, hipMemcpyDeviceToHost));
+        lens[l] = L.len;
+        ptrs[l] = rows[l].data();
+        widths[l] = L.dev_width;
+    }
+    if (granne_file::encode_index((uint32_t)rows.size(), lens.data(), ptrs.data(), widths.data(), buf))
+        return fail(GRANNE_HIP_ERR_IO, "index does not fit the file format");
+    return GRANNE_HIP_OK;
+}
+
+extern "C" int granne_hip_index_encode(const granne_hip_index* ix, void** out_bytes, uint64_t* out_len) {
+    if (!ix || !out_bytes || !out_len) return fail(GRANNE_HIP_ERR_INVALID, "null argument");
+    *out_bytes = nullptr;
+    *out_len = 0;
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+    std::vector<uint8_t> buf;
+    int rc = encode_device_index(ix, &buf);
+    if (rc) return rc;
+    void* p = malloc(buf.size() ? buf.size() : 1);
+    if (!p) return fail(GRANNE_HIP_ERR_IO, "out of host memory (%zu bytes)", buf.size());
+    memcpy(p, buf.data(), buf.size());
+    *out_bytes = p;
+    *out_len = buf.size();
+    return GRANNE_HIP_OK;
+}
+extern "C" void granne_hip_bytes_free(void* bytes) { free(bytes); }
+
 // Index::write_index / write_elements for a device-resident index (downloads, then writes)
 extern "C" int granne_hip_index_save(const granne_hip_index* ix, const char* index_path, const char* elements_path) {
     if (!ix) return fail(GRANNE_HIP_ERR_INVALID, "index is null");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
     if (index_path) {
-        std::vector<std::vector<uint32_t>> rows(ix->layers.size());
-        std::vector<uint64_t> lens(ix->layers.size());
-        std::vector<const uint32_t*> ptrs(ix->layers.size());
-        std::vector<uint32_t> widths(ix->layers.size());
-        for (size_t l = 0; l < ix->layers.size(); ++l) {
-            const LayerHost& L = ix->layers[l];
-            rows[l].resize((size_t)L.len * L.dev_width);
-            if (!rows[l].empty())
-                HIP_TRY(hipMemcpy(rows[l].data(), L.d_adj, rows[l].size() * 4, hipMemcpyDeviceToHost));
-            lens[l] = L.len;
-            ptrs[l] = rows[l].data();
-            widths[l] = L.dev_width;
-        }
-        int rc = granne_hip_write_index_file(index_path, (uint32_t)rows.size(), lens.data(), ptrs.data(), widths.data());
+        std::vector<uint8_t> buf;
+        int rc = encode_device_index(ix, &buf);
         if (rc) return rc;
+        if (!granne_file::write_file(index_path, buf.data(), buf.size(), nullptr, 0)) return fail(GRANNE_HIP_ERR_IO, "Could not write %s", index_path);
     }
     if (elements_path) {
         size_t dense = (size_t)ix->dim * elem_size(ix->dtype);
         std::vector<uint8_t> el((size_t)ix->n_elements * dense);
         if (!el.empty())
-            HIP_TRY(hipMemcpy2D(el.data(), dense, ix->d_elements, ix->row_bytes, dense, ix->n_elements, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy2D(el.data(), dense, ix->d_elements, ix->row_stride, dense, ix->n_elements, hipMemcpyDeviceToHost));
         return granne_hip_write_elements_file(elements_path, el.data(), ix->n_elements, ix->dim, ix->dtype);
     }
     return GRANNE_HIP_OK;

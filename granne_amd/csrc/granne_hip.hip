@@ -70,6 +70,28 @@ extern "C" int granne_hip_device_count(int* out_count) {
     return GRANNE_HIP_OK;
 }
 
+// experiment knobs, read once per process
+struct EnvKnobs {
+    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, tail_blocks = -1, touch_max = -1, inline_tails = 1;
+    EnvKnobs() {
+        auto geti = [](const char* name, int dflt) {
+            const char* e = getenv(name);
+            return e ? atoi(e) : dflt;
+        };
+        visited_cap = geti("GRANNE_HIP_VISITED_CAP", 0);
+        front_eighths = geti("GRANNE_HIP_FRONT_EIGHTHS", 0);
+        maxc = geti("GRANNE_HIP_MAXC", 0);
+        lds_pad = geti("GRANNE_HIP_LDS_PAD", 0);
+        visited = geti("GRANNE_HIP_VISITED", 0); // GRANNE_HIP_OPT_VISITED16's values, where the option says auto
+        inline_tails = geti("GRANNE_HIP_INLINE_TAILS", 1); // 0: no index keeps LayerDev::adjx (experiments: the layout before round 6)
+        touch_max = geti("GRANNE_HIP_TOUCH_MAX", -1); // launches of up to this many queries touch rows ahead (-1: default)
+    }
+};
+static const EnvKnobs& knobs() {
+    static const EnvKnobs k;
+    return k;
+}
+
 // ------------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------------
@@ -97,6 +119,8 @@ struct LayerHost {
     uint32_t width = 0;     // caller's row width
     uint32_t dev_width = 0; // multiple of 32
     uint32_t* d_adj = nullptr;
+    uint8_t* d_adjx = nullptr; // the register walker's copy: ids + the neighbors' row tails (LayerDev::adjx), or null
+    uint32_t adjx_stride = 0;
 };
 
 struct granne_hip_index {
@@ -104,7 +128,8 @@ struct granne_hip_index {
     uint32_t dim = 0;
     int dtype = 0;
     uint64_t n_elements = 0;
-    uint32_t row_bytes = 0; // device stride
+    uint32_t row_bytes = 0;  // data bytes of a device row (zero padded to 16)
+    uint32_t row_stride = 0; // bytes from one device row to the next
     uint8_t* d_elements = nullptr;
     std::vector<LayerHost> layers;
     LayerDev* d_layers = nullptr;
@@ -118,6 +143,7 @@ struct granne_hip_index {
     uint64_t opt_overflow_slots = 0; // 0 auto, 1 off, else slots per overflow table
     uint64_t opt_visited16 = 0;      // 0 auto, 1 off, 2 always the 20-bit entries (tests)
     uint64_t opt_visited16_lg = 0;   // 0 auto, else log2(buckets)
+    uint64_t opt_inline_tails = 1;   // GRANNE_HIP_OPT_INLINE_TAILS: keep LayerDev::adjx for the shapes that have one
     std::atomic<uint64_t> last_slow_count{0};
     std::atomic<uint64_t> last_walker{0}; // GRANNE_HIP_OPT_LAST_WALKER
     // the exact scan of int8 rows (brute_force.h): 1 / |x| per row, made at the first scan
@@ -167,6 +193,26 @@ static uint32_t device_row_bytes(uint32_t dim, int dtype) {
     return (dim + 1023u) & ~1023u;
 }
 
+// Bytes from one device row to the next. f32 rows of 256 bytes and more start on a 128-byte line: the register walker
+// reads a row's 32-float chunks as whole lines, and when the layers carry the neighbors' tails next to their ids
+// (LayerDev::adjx) that is all it reads of a row -- a 100-d row is three lines, not the four a 400-byte stride touches.
+static uint32_t device_row_stride(uint32_t dim, int dtype) {
+    const uint32_t rb = device_row_bytes(dim, dtype);
+    if (dtype == GRANNE_HIP_F32 && rb >= 256u) return (rb + 127u) & ~127u;
+    return rb;
+}
+// 16-byte units of a row's tail (the dim % 32 last floats) that LayerDev::adjx carries per neighbor; 0: the shape has no
+// such copy. The unrolled f32 walkers (dims 100 and 200) read it; their layers are 32 ids wide.
+static uint32_t inline_tail_units(uint32_t dim, int dtype) {
+    if (dtype != GRANNE_HIP_F32 || (dim != 100u && dim != 200u)) return 0u;
+    return (dim % 32u) / 4u;
+}
+// the scan's per-row norms: inv_norm [n_pad], then inv_gmax [n_pad / 32][2] (brute_force.h)
+static inline uint64_t inv_norm_bytes(uint64_t n) {
+    const uint64_t n_pad = (n + 31u) & ~31ull;
+    return (n_pad + n_pad / 16 + 1) * 4;
+}
+
 static int grid_for(uint64_t work, int block) {
     uint64_t g = (work + block - 1) / block;
     if (g > 256ull * 32) g = 256ull * 32;
@@ -198,8 +244,10 @@ static void destroy_index(granne_hip_index* ix) {
     if (!ix) return;
     DeviceGuard g(ix->device);
     if (ix->d_elements) (void)hipFree(ix->d_elements);
-    for (auto& L : ix->layers)
+    for (auto& L : ix->layers) {
         if (L.d_adj) (void)hipFree(L.d_adj);
+        if (L.d_adjx) (void)hipFree(L.d_adjx);
+    }
     if (ix->d_layers) (void)hipFree(ix->d_layers);
     if (ix->d_inv_norm) (void)hipFree(ix->d_inv_norm);
     for (auto* c : ix->call_free) {
@@ -222,16 +270,44 @@ static void destroy_index(granne_hip_index* ix) {
 static int upload_elements_from_device(granne_hip_index* ix, const void* d_src, hipStream_t s) {
     uint64_t n = ix->n_elements;
     uint32_t dense = ix->dim * elem_size(ix->dtype);
-    size_t bytes = (size_t)n * ix->row_bytes;
+    size_t bytes = (size_t)n * ix->row_stride;
     HIP_TRY(hipMalloc((void**)&ix->d_elements, bytes ? bytes : 16));
     ix->hbm_bytes += bytes;
     if (n == 0) return GRANNE_HIP_OK;
-    if (dense == ix->row_bytes) {
+    if (dense == ix->row_stride) {
         HIP_TRY(hipMemcpyAsync(ix->d_elements, d_src, bytes, hipMemcpyDeviceToDevice, s));
     } else {
-        uint64_t units = n * (ix->row_bytes / 16);
+        uint64_t units = n * (ix->row_stride / 16);
         hipLaunchKernelGGL(relayout_rows_kernel, dim3(grid_for(units, 256)), dim3(256), 0, s, (const uint8_t*)d_src,
-                           ix->d_elements, n, dense, ix->row_bytes);
+                           ix->d_elements, n, dense, ix->row_stride);
+        HIP_TRY(hipGetLastError());
+    }
+    return GRANNE_HIP_OK;
+}
+
+// (Re)makes the register walker's copies of the layers (LayerDev::adjx) -- or drops them when the option is off or the
+// shape has none. The layers and the elements are final when this runs (finish_layers).
+static int make_inline_tails(granne_hip_index* ix, hipStream_t s) {
+    for (auto& L : ix->layers) {
+        if (L.d_adjx) {
+            (void)hipFree(L.d_adjx);
+            ix->hbm_bytes -= (uint64_t)L.len * L.adjx_stride;
+            L.d_adjx = nullptr;
+            L.adjx_stride = 0;
+        }
+    }
+    const uint32_t tu = inline_tail_units(ix->dim, ix->dtype);
+    if (!tu || !ix->opt_inline_tails || !knobs().inline_tails) return GRANNE_HIP_OK;
+    for (auto& L : ix->layers)
+        if (L.dev_width != 32u) return GRANNE_HIP_OK; // layers of up to 64 ids (WIDE) read their tails from the rows
+    for (auto& L : ix->layers) {
+        L.adjx_stride = 128u + 32u * tu * 16u;
+        const size_t bytes = (size_t)L.len * L.adjx_stride;
+        HIP_TRY(hipMalloc((void**)&L.d_adjx, bytes ? bytes : 16));
+        ix->hbm_bytes += bytes;
+        if (L.len)
+            hipLaunchKernelGGL(inline_tails_kernel, dim3(grid_for(L.len * 32u * (1u + tu), 256)), dim3(256), 0, s, L.d_adj,
+                               L.len, ix->d_elements, ix->row_stride, (ix->dim / 32u) * 128u, tu, L.d_adjx, L.adjx_stride);
         HIP_TRY(hipGetLastError());
     }
     return GRANNE_HIP_OK;
@@ -240,6 +316,10 @@ static int upload_elements_from_device(granne_hip_index* ix, const void* d_src, 
 static int finish_layers(granne_hip_index* ix, hipStream_t s) {
     std::vector<LayerDev> h(ix->layers.size());
     ix->max_dev_width = 32;
+    {
+        int r = make_inline_tails(ix, s);
+        if (r) return r;
+    }
     // rows that name a neighbor twice (LAYER_TWIN_ROWS, walk_fast.h): looked for once, here, on the device rows
     uint32_t* d_found = nullptr;
     std::vector<uint32_t> found(h.size(), 0u);
@@ -255,6 +335,9 @@ static int finish_layers(granne_hip_index* ix, hipStream_t s) {
         h[l].len = ix->layers[l].len;
         h[l].width = ix->layers[l].dev_width;
         h[l].flags = 0;
+        h[l].adjx = ix->layers[l].d_adjx;
+        h[l].adjx_stride = ix->layers[l].adjx_stride;
+        h[l].reserved = 0;
         if (ix->layers[l].dev_width > ix->max_dev_width) ix->max_dev_width = ix->layers[l].dev_width;
         if (h[l].len && h[l].width <= 64)
             hipLaunchKernelGGL(twin_rows_kernel, dim3(grid_for(h[l].len * 64, 256)), dim3(256), 0, s, h[l].adj, h[l].len,
@@ -269,6 +352,8 @@ static int finish_layers(granne_hip_index* ix, hipStream_t s) {
             if (found[l]) h[l].flags |= LAYER_TWIN_ROWS;
     }
     size_t bytes = sizeof(LayerDev) * (h.size() ? h.size() : 1);
+    if (ix->d_layers) (void)hipFree(ix->d_layers);
+    ix->d_layers = nullptr;
     HIP_TRY(hipMalloc((void**)&ix->d_layers, bytes));
     if (!h.empty()) HIP_TRY(hipMemcpyAsync(ix->d_layers, h.data(), sizeof(LayerDev) * h.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -313,6 +398,7 @@ extern "C" int granne_hip_index_create_device(granne_hip_index** out, const void
     ix->dtype = dtype;
     ix->n_elements = n_elements;
     ix->row_bytes = device_row_bytes(dim, dtype);
+    ix->row_stride = device_row_stride(dim, dtype);
     rc = upload_elements_from_device(ix, d_elements, s);
     uint32_t* d_bad = nullptr; // neighbor ids outside their layer (the file loader checks the same on the host)
     if (rc == 0 && hipMalloc((void**)&d_bad, 4) != hipSuccess) rc = fail(GRANNE_HIP_ERR_HIP, "hipMalloc failed");
@@ -391,6 +477,7 @@ extern "C" int granne_hip_index_create_csr(granne_hip_index** out, const void* e
     ix->dtype = dtype;
     ix->n_elements = n_elements;
     ix->row_bytes = device_row_bytes(dim, dtype);
+    ix->row_stride = device_row_stride(dim, dtype);
     void* d_el = nullptr;
     size_t el_bytes = (size_t)n_elements * dim * elem_size(dtype);
     auto body = [&]() -> int {
@@ -480,7 +567,7 @@ extern "C" int granne_hip_index_get_element(const granne_hip_index* ix, uint64_t
     if (!ix || !out) return fail(GRANNE_HIP_ERR_INVALID, "null argument");
     if (idx >= ix->n_elements) return fail(GRANNE_HIP_ERR_INVALID, "element index out of range");
     DeviceGuard g(ix->device);
-    HIP_TRY(hipMemcpy(out, ix->d_elements + idx * ix->row_bytes, (size_t)ix->dim * elem_size(ix->dtype),
+    HIP_TRY(hipMemcpy(out, ix->d_elements + idx * ix->row_stride, (size_t)ix->dim * elem_size(ix->dtype),
                       hipMemcpyDeviceToHost));
     return GRANNE_HIP_OK;
 }
@@ -526,6 +613,14 @@ extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uin
         ix->next_flight = 0;
         return GRANNE_HIP_OK;
     }
+    case GRANNE_HIP_OPT_INLINE_TAILS: {
+        if (value > 1) return fail(GRANNE_HIP_ERR_INVALID, "the inline-tails option is 0 or 1");
+        DeviceGuard g(ix->device);
+        if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
+        HIP_TRY(hipDeviceSynchronize()); // (searches in flight read the copy and the layer table this replaces)
+        ix->opt_inline_tails = value;
+        return finish_layers(ix, nullptr);
+    }
     case GRANNE_HIP_OPT_VISITED16_LG: // (retired with the bucket tables it sized: accepted, ignored)
         if (value > 12) return fail(GRANNE_HIP_ERR_INVALID, "value out of range");
         ix->opt_visited16_lg = value;
@@ -547,6 +642,7 @@ extern "C" int granne_hip_index_get_option(const granne_hip_index* ix, int optio
     case GRANNE_HIP_OPT_VISITED16_LG: *value = ix->opt_visited16_lg; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_LAST_WALKER: *value = ix->last_walker.load(); return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_SEARCH_DEPTH: *value = ix->depth; return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_INLINE_TAILS: *value = (!ix->layers.empty() && ix->layers.back().d_adjx) ? 1 : 0; return GRANNE_HIP_OK;
     default: return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -565,7 +661,7 @@ struct SearchTarget {
     uint64_t n_elements;
     uint32_t dim;
     int dtype;
-    uint32_t row_bytes;
+    uint32_t row_bytes, row_stride;
     const LayerDev* d_layers;
     uint32_t n_layers;
     uint32_t max_dev_width;
@@ -583,6 +679,7 @@ static SearchTarget target_of(const granne_hip_index* ix) {
     T.dim = ix->dim;
     T.dtype = ix->dtype;
     T.row_bytes = ix->row_bytes;
+    T.row_stride = ix->row_stride;
     T.d_layers = ix->d_layers;
     T.n_layers = (uint32_t)ix->layers.size();
     T.max_dev_width = ix->max_dev_width;
@@ -600,26 +697,6 @@ static SearchTarget target_of(const granne_hip_index* ix) {
 
 typedef void (*search_fn)(const SlowParams);
 
-// experiment knobs, read once per process
-struct EnvKnobs {
-    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, tail_blocks = -1, touch_max = -1;
-    EnvKnobs() {
-        auto geti = [](const char* name, int dflt) {
-            const char* e = getenv(name);
-            return e ? atoi(e) : dflt;
-        };
-        visited_cap = geti("GRANNE_HIP_VISITED_CAP", 0);
-        front_eighths = geti("GRANNE_HIP_FRONT_EIGHTHS", 0);
-        maxc = geti("GRANNE_HIP_MAXC", 0);
-        lds_pad = geti("GRANNE_HIP_LDS_PAD", 0);
-        visited = geti("GRANNE_HIP_VISITED", 0); // GRANNE_HIP_OPT_VISITED16's values, where the option says auto
-        touch_max = geti("GRANNE_HIP_TOUCH_MAX", -1); // launches of up to this many queries touch rows ahead (-1: default)
-    }
-};
-static const EnvKnobs& knobs() {
-    static const EnvKnobs k;
-    return k;
-}
 
 template <int DT, int DIM>
 static search_fn pick_s(uint32_t ef) {
@@ -992,6 +1069,7 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     p.n_elements = ix->n_elements;
     p.dim = ix->dim;
     p.row_bytes = ix->row_bytes;
+    p.row_stride = ix->row_stride;
     p.layers = ix->d_layers;
     p.n_layers = ix->n_layers;
     p.queries = (const uint8_t*)d_queries;
@@ -1463,11 +1541,11 @@ static int dists_launch(const granne_hip_index* ix, const void* d_queries, const
     if (blocks > 256u * 64u) blocks = 256u * 64u;
     if (ix->dtype == GRANNE_HIP_F32)
         hipLaunchKernelGGL(dists_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, ix->d_elements,
-                           ix->n_elements, ix->row_bytes, ix->dim, (const uint8_t*)d_queries, d_qidx, m, d_ids, n_pairs,
+                           ix->n_elements, ix->row_bytes, ix->row_stride, ix->dim, (const uint8_t*)d_queries, d_qidx, m, d_ids, n_pairs,
                            d_out, st);
     else
         hipLaunchKernelGGL(dists_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, ix->d_elements,
-                           ix->n_elements, ix->row_bytes, ix->dim, (const uint8_t*)d_queries, d_qidx, m, d_ids, n_pairs,
+                           ix->n_elements, ix->row_bytes, ix->row_stride, ix->dim, (const uint8_t*)d_queries, d_qidx, m, d_ids, n_pairs,
                            d_out, st);
     HIP_TRY(hipGetLastError());
     return GRANNE_HIP_OK;
@@ -1561,15 +1639,15 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         std::lock_guard<std::mutex> lk(mix->norm_mu);
         if (!mix->d_inv_norm) { // (rows do not change under an index: reorder builds new arrays and drops this one)
             float* dn = nullptr;
-            HIP_TRY(hipMalloc((void**)&dn, (size_t)(n_pad + n_pad / 16 + 1) * 4));
-            hipLaunchKernelGGL(inv_norm_rows_kernel, dim3(grid_for(n * 8, 256)), dim3(256), 0, s, ix->d_elements, n, ix->row_bytes, dn);
+            HIP_TRY(hipMalloc((void**)&dn, (size_t)inv_norm_bytes(n)));
+            hipLaunchKernelGGL(inv_norm_rows_kernel, dim3(grid_for(n * 8, 256)), dim3(256), 0, s, ix->d_elements, n, ix->row_stride, dn);
             hipLaunchKernelGGL(inv_gmax_kernel, dim3(grid_for(n_pad / 16 + 1, 256)), dim3(256), 0, s, (const float*)dn, n, dn + n_pad);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
                 (void)hipFree(dn);
                 return fail(GRANNE_HIP_ERR_HIP, "inv_norm_rows_kernel failed");
             }
             mix->d_inv_norm = dn;
-            mix->hbm_bytes += (uint64_t)n * 4;
+            mix->hbm_bytes += inv_norm_bytes(n);
         }
         P.inv_norm = mix->d_inv_norm;
         P.inv_gmax = mix->d_inv_norm + n_pad;
@@ -1577,6 +1655,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     P.elements = ix->d_elements;
     P.n = n;
     P.row_bytes = ix->row_bytes;
+    P.row_stride = ix->row_stride;
     P.dim = ix->dim;
     P.queries = (const uint8_t*)d_queries;
     P.nq = nq;

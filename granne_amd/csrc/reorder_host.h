@@ -50,7 +50,7 @@ __global__ void widen_u32_kernel(const uint32_t* __restrict__ src, uint64_t n, u
 
 // new_rows[i] = rows[order[i]], 16 bytes per lane
 __global__ void permute_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                    const uint32_t* __restrict__ order, uint64_t n, uint32_t row_bytes) {
+                                    const uint32_t* __restrict__ order, uint64_t n, uint32_t row_bytes /* the stride: padding travels too */) {
     const uint32_t units = row_bytes >> 4;
     const uint64_t total = n * units;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
@@ -157,11 +157,11 @@ static int apply_order(granne_hip_index* ix, const uint32_t* d_order, ReorderScr
                                d_rev, L.len, L.dev_width);
             HIP_TRY(hipGetLastError());
         }
-        size_t el_bytes = (size_t)n * ix->row_bytes;
+        size_t el_bytes = (size_t)n * ix->row_stride;
         HIP_TRY(hipMalloc((void**)&new_el, el_bytes ? el_bytes : 16));
         if (n) {
-            hipLaunchKernelGGL(permute_rows_kernel, dim3(grid_for(n * (ix->row_bytes >> 4), 256)), dim3(256), 0, s,
-                               ix->d_elements, new_el, d_order, n, ix->row_bytes);
+            hipLaunchKernelGGL(permute_rows_kernel, dim3(grid_for(n * (ix->row_stride >> 4), 256)), dim3(256), 0, s,
+                               ix->d_elements, new_el, d_order, n, ix->row_stride);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipStreamSynchronize(s));
@@ -182,13 +182,11 @@ static int apply_order(granne_hip_index* ix, const uint32_t* d_order, ReorderScr
         std::lock_guard<std::mutex> lk(ix->norm_mu);
         if (ix->d_inv_norm) {
             (void)hipFree(ix->d_inv_norm);
-            ix->hbm_bytes -= (uint64_t)ix->n_elements * 4;
+            ix->hbm_bytes -= inv_norm_bytes(ix->n_elements);
             ix->d_inv_norm = nullptr;
         }
     }
-    if (ix->d_layers) (void)hipFree(ix->d_layers);
-    ix->d_layers = nullptr;
-    return finish_layers(ix, s);
+    return finish_layers(ix, s); // (the walkers' copies of the layers, LayerDev::adjx, are made again there)
 }
 
 static int reorder_precheck(granne_hip_index* ix) {
@@ -251,7 +249,7 @@ extern "C" int granne_hip_index_reorder(granne_hip_index* ix, uint64_t* out_orde
             const uint64_t m = hi - lo;
             if (m == 0) continue;
             // find_entrypoint_trail for every idx in [lo, hi); the element rows are the queries
-            int r = search_launch(&T, ix->d_elements + (size_t)lo * ix->row_bytes, (int64_t)ix->row_bytes, (uint32_t)m, 1, 1,
+            int r = search_launch(&T, ix->d_elements + (size_t)lo * ix->row_stride, (int64_t)ix->row_stride, (uint32_t)m, 1, 1,
                                   nullptr, nullptr, nullptr, nullptr, d_overflow, s, nullptr, d_trail, layer);
             if (r) return r;
             // (eps, idx) ascending: LSD over the column pairs, starting from idx order

@@ -35,6 +35,14 @@ struct LayerDev {
     uint64_t len;
     uint32_t width;      // device row width (multiple of 32 -> rows are 128-byte aligned)
     uint32_t flags;      // LAYER_*
+    // The register walker's own copy of the layer (walk_fast.h, f32 rows with a tail: 100-d, 200-d): node i's 32 ids
+    // FOLLOWED BY the tails (the dim % 32 last floats) of those 32 neighbors' element rows, adjx_stride bytes per node
+    // (128 + 32 * tail bytes: whole 128-byte lines). An expansion then reads whole lines only: the neighbors' 32-float
+    // chunks from their rows (rows start on a line), the tails from here, next to the ids. Null: no such copy (a
+    // builder's layers in the making, every other shape) -- the tails are read from the rows themselves.
+    const uint8_t* adjx;
+    uint32_t adjx_stride;
+    uint32_t reserved;
 };
 constexpr uint32_t LAYER_TWIN_ROWS = 1u; // some row names a neighbor twice (no builder of the reference makes such rows; a foreign file may hold them)
 
@@ -52,7 +60,8 @@ struct SearchParams {
     const uint8_t* elements; // device layout: [n][row_bytes], zero padded
     uint64_t n_elements;
     uint32_t dim;
-    uint32_t row_bytes;      // multiple of 16
+    uint32_t row_bytes;      // bytes of a row's data, zero padded: multiple of 16
+    uint32_t row_stride;     // bytes from one row to the next (>= row_bytes; f32 rows of 256 bytes and more start on a 128-byte line)
     const LayerDev* layers;
     uint32_t n_layers;
     const uint8_t* queries;  // query i starts at queries + i * q_stride (dim scalars each)
@@ -226,7 +235,7 @@ struct Walker {
         else row = fc / row16;                                                                       \
         uint32_t part = fc - row * row16;                                                            \
         uint32_t id = cand[g0 + row];                                                                \
-        V = *reinterpret_cast<const uint4*>(p.elements + (size_t)id * p.row_bytes + (size_t)part * 16); \
+        V = *reinterpret_cast<const uint4*>(p.elements + (size_t)id * p.row_stride + (size_t)part * 16); \
         D = f < total ? (row * lrow16 + part) * 16u : 0xFFFFFFFFu;                                   \
     }
                     GRANNE_GATHER(0, v0, d0)
@@ -269,7 +278,7 @@ struct Walker {
                 uint32_t ci = c0 + rip;
                 int r = 0, dx = 0;
                 if (ci < m) {
-                    const uint8_t* row = p.elements + (size_t)cand[ci] * p.row_bytes;
+                    const uint8_t* row = p.elements + (size_t)cand[ci] * p.row_stride;
                     for (uint32_t u = sub; u < row16; u += lpr) {
                         uint4 x = *reinterpret_cast<const uint4*>(row + (size_t)u * 16);
                         uint4 y = *reinterpret_cast<const uint4*>(lds_q + (size_t)u * 16);

@@ -97,7 +97,7 @@ __device__ inline void gheap_replace_max(uint64_t* h, uint32_t n, uint64_t k) { 
 
 template <int DT>
 __device__ inline float slow_dist(const SearchParams& p, const uint8_t* lds_q, uint32_t id, int dy) {
-    const uint8_t* row = p.elements + (size_t)id * p.row_bytes;
+    const uint8_t* row = p.elements + (size_t)id * p.row_stride;
     if constexpr (DT == DT_F32) {
         float r = dot_f32_exact_rt(reinterpret_cast<const float*>(row), reinterpret_cast<const float*>(lds_q), p.dim);
         return angular_from_dot(r);

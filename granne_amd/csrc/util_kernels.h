@@ -29,6 +29,30 @@ __global__ void relayout_rows_kernel(const uint8_t* __restrict__ src, uint8_t* _
     }
 }
 
+// LayerDev::adjx of one layer (search_kernel.h): node i's 32 ids, then the tails of those neighbors' element rows
+// (`tu` 16-byte units each, found `body_bytes` into a row; zeros where the row has no neighbor). One 16-byte unit of
+// the copy per thread: units 0..7 of a node are its ids, the next 32 * tu its tails.
+__global__ void inline_tails_kernel(const uint32_t* __restrict__ adj, uint64_t len, const uint8_t* __restrict__ elements,
+                                    uint32_t row_stride, uint32_t body_bytes, uint32_t tu, uint8_t* __restrict__ adjx,
+                                    uint32_t adjx_stride) {
+    const uint32_t units = adjx_stride >> 4;
+    const uint64_t total = len * units;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t node = t / units;
+        const uint32_t u = (uint32_t)(t - node * units);
+        uint4 v;
+        if (u < 8u) {
+            v = *reinterpret_cast<const uint4*>(adj + node * 32u + u * 4u);
+        } else {
+            const uint32_t slot = (u - 8u) / tu, part = (u - 8u) - slot * tu;
+            const uint32_t id = adj[node * 32u + slot];
+            v = make_uint4(0, 0, 0, 0);
+            if (id != 0xFFFFFFFFu) v = *reinterpret_cast<const uint4*>(elements + (size_t)id * row_stride + body_bytes + part * 16u);
+        }
+        *reinterpret_cast<uint4*>(adjx + node * adjx_stride + (size_t)u * 16u) = v;
+    }
+}
+
 // fixed-width adjacency [len][w] -> [len][W] (W >= w), UNUSED padded
 __global__ void relayout_adj_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t len,
                                     uint32_t w, uint32_t W) {
@@ -175,7 +199,7 @@ __device__ __forceinline__ float lane_shr1(float v) { // value of lane-1 (within
 
 template <int DT>
 __global__ __launch_bounds__(256) void dists_kernel(const uint8_t* __restrict__ elements, uint64_t n_elements,
-                                                    uint32_t row_bytes, uint32_t dim,
+                                                    uint32_t row_bytes, uint32_t row_stride, uint32_t dim,
                                                     const uint8_t* __restrict__ queries,
                                                     const uint32_t* __restrict__ qidx, uint32_t m,
                                                     const uint32_t* __restrict__ ids, uint64_t n_pairs,
@@ -192,7 +216,7 @@ __global__ __launch_bounds__(256) void dists_kernel(const uint8_t* __restrict__ 
         const uint32_t id = ids[tc];
         const bool valid = id < n_elements;
         const uint64_t qi = qidx ? qidx[tc] : tc / m;
-        const uint8_t* row = elements + (uint64_t)(valid ? id : 0u) * row_bytes;
+        const uint8_t* row = elements + (uint64_t)(valid ? id : 0u) * row_stride;
         float d;
         if constexpr (DT == 0) {
             const float* q = reinterpret_cast<const float*>(queries) + qi * dim;

@@ -264,6 +264,13 @@ struct FastWalker {
     static constexpr bool QREG = F32 && fast_query_in_regs(false, GEN, (uint32_t)DIM, (uint32_t)S);
     static constexpr int NBI = F32 ? 1 : (DIM ? DIM / 128 : 1); // int8: 128-byte blocks per row (DIM = row bytes; 0 = 128)
     static constexpr uint32_t ROWB = F32 ? (uint32_t)DIM * 4u : 128u * NBI;
+    // bytes from one row to the next (device_row_stride, granne_hip.hip): f32 rows of 256 bytes and more start on a line
+    static constexpr uint32_t RSTRIDE = (F32 && ROWB >= 256u) ? ((ROWB + 127u) & ~127u) : ROWB;
+    // XT: the shape whose layers may carry the neighbors' tails next to their ids (LayerDev::adjx): the unrolled f32 dims
+    // with a tail, layers of 32 ids. Then an expansion reads the 32-float chunks of a neighbor from its row (whole lines)
+    // and its tail from the expanded node's own record, XTAILB bytes per neighbor slot behind the 32 ids.
+    static constexpr bool XT = F32 && !GEN && TU > 0 && !WIDE;
+    static constexpr uint32_t XTAILB = (uint32_t)TU * 16u;
     static_assert(F32 || DIM == 0 || DIM == 256 || DIM == 512, "fast int8 rows: 128, 256 or 512 bytes");
     static constexpr uint32_t CAP = 64u * S;
     static constexpr bool LONG_LIST = S >= 33;
@@ -379,9 +386,11 @@ struct FastWalker {
     }
 
     // Issue every load of the rows idl (lanes of a pair pass the same idl). Nothing is waited for.
-    __device__ __forceinline__ void issue_rows(uint32_t idl, RowRegs& rr) {
+    // tails: where this lane's row keeps its tail when that is not the row itself (XT: the expanded node's record in
+    // LayerDev::adjx; null = the row).
+    __device__ __forceinline__ void issue_rows(uint32_t idl, RowRegs& rr, [[maybe_unused]] const uint8_t* tails = nullptr) {
         if constexpr (GEN) {
-            rr.row = p.elements + (size_t)idl * p.row_bytes;
+            rr.row = p.elements + (size_t)idl * p.row_stride;
             if (g_nbk) load_group(rr, 0u); // (dims below 32 have no full chunk: the row is its tail)
             // the tail (dim % 32 floats, zero padded to 16-byte units) is read by every lane, used by the odd one
             const uint8_t* tailp = rr.row + (size_t)g_nbk * 128u;
@@ -389,16 +398,25 @@ struct FastWalker {
             for (int u = 0; u < 8; ++u)
                 if ((uint32_t)u < g_tu) rr.vt[u] = *reinterpret_cast<const float4*>(tailp + u * 16);
         } else if constexpr (F32) {
-            const uint8_t* row = p.elements + (size_t)idl * ROWB;
+            const uint8_t* row = p.elements + (size_t)idl * RSTRIDE;
             const uint8_t* e = row + h * 64u;
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) rr.v[b][k] = *reinterpret_cast<const float4*>(e + b * 128 + k * 16);
+            if constexpr (XT) {
+                const uint8_t* tp = tails ? tails : row + NB * 128;
 #pragma unroll
-            for (int u = 0; u < TU; ++u) rr.vt[u] = *reinterpret_cast<const float4*>(row + NB * 128 + u * 16);
+                for (int u = 0; u < TU; ++u) {
+                    const uint4 t = load_global_u4((gptr_u32)(tp + u * 16));
+                    rr.vt[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < TU; ++u) rr.vt[u] = *reinterpret_cast<const float4*>(row + NB * 128 + u * 16);
+            }
         } else {
-            const uint8_t* e = p.elements + (size_t)idl * ROWB + h * 64u;
+            const uint8_t* e = p.elements + (size_t)idl * RSTRIDE + h * 64u;
 #pragma unroll
             for (int b = 0; b < NBI; ++b)
 #pragma unroll
@@ -777,8 +795,9 @@ struct FastWalker {
         PT_RESET();
         L.init_list(mslot, lane);
         __syncthreads();
-        const gptr_u32 adjg = (gptr_u32)Ly.adj;
-        const uint32_t W = 32u;
+        [[maybe_unused]] const uint8_t* const adjx = XT ? Ly.adjx : nullptr; // ids + the neighbors' tails (LayerDev::adjx), or null
+        const gptr_u32 adjg = (XT && adjx) ? (gptr_u32)adjx : (gptr_u32)Ly.adj;
+        const uint32_t W = (XT && adjx) ? Ly.adjx_stride / 4u : 32u; // u32 from one node's ids to the next's
         uint32_t pre_id = entrypoint, pre_nb; // adjacency row fetched ahead (one id per pair) and whose it is
         pre_nb = adjg[(size_t)entrypoint * W + R]; // get_neighbors(entrypoint): needed right after
         vis.count = 1;
@@ -820,7 +839,11 @@ struct FastWalker {
             st.n_adj += nvalid;
             {   // lanes beyond the row re-read its last neighbor (an empty row: the node itself)
                 const uint32_t last_id = nvalid ? readlane32(nb, 2u * (nvalid - 1u)) : xid;
-                issue_rows((R < nvalid) ? nb : last_id, rr);
+                const uint8_t* tails = nullptr;
+                if constexpr (XT) {
+                    if (adjx) tails = adjx + (size_t)xid * Ly.adjx_stride + 128u + ((R < nvalid) ? R : 0u) * XTAILB;
+                }
+                issue_rows((R < nvalid) ? nb : last_id, rr, tails);
             }
             // fetch ahead the row of the node that is first in line now; always one load: static wait counts
             uint32_t ypos = 0;
@@ -884,8 +907,10 @@ struct FastWalker {
         if constexpr (!NOVIS) vis.reset(vis_tab, slots, lane, ef > 1u ? p.front_eighths : 7u);
         L.init_list(mslot, lane);
         __syncthreads();
-        const gptr_u32 adjg = (gptr_u32)Ly.adj;
-        const uint32_t W = WIDE ? Ly.width : 32u; // ids per adjacency row on the device: 32, or 64 in a WIDE launch
+        [[maybe_unused]] const uint8_t* const adjx = XT ? Ly.adjx : nullptr; // ids + the neighbors' tails (LayerDev::adjx), or null
+        const gptr_u32 adjg = (XT && adjx) ? (gptr_u32)adjx : (gptr_u32)Ly.adj;
+        // u32 from one node's ids to the next's: 32, 64 in a WIDE launch, a record of LayerDev::adjx
+        const uint32_t W = WIDE ? Ly.width : (XT && adjx) ? Ly.adjx_stride / 4u : 32u;
         const bool twin_rows = (Ly.flags & LAYER_TWIN_ROWS) != 0u; // some row of the layer names a neighbor twice (rare: found at upload)
         // distance to the entry point (mod.rs:1012-1016), the first pop. On every layer but the first the entry point is
         // the node the layer above returned as its closest, and its distance to the same query was evaluated there: the
@@ -911,6 +936,7 @@ struct FastWalker {
 
         RowRegs rr;
         [[maybe_unused]] uint32_t touched[NT] = {};
+        [[maybe_unused]] uint32_t touched_x = 0;
         PT_WAIT_VM();
         PT_MARK(7); // layer setup: tables, entry point distance
         for (;;) {
@@ -944,7 +970,11 @@ struct FastWalker {
                 uint32_t fill = readlane32(nb, 0);
                 asm("" : "+v"(fill));
                 fill = fill != ID_EMPTY ? fill : xid;
-                issue_rows(nb != ID_EMPTY ? nb : fill, rr);
+                const uint8_t* tails = nullptr;
+                if constexpr (XT) { // (a pair past the row's end: slot 0's tail, the lines pair 0 reads anyway)
+                    if (adjx) tails = adjx + (size_t)xid * Ly.adjx_stride + 128u + (nb != ID_EMPTY ? R : 0u) * XTAILB;
+                }
+                issue_rows(nb != ID_EMPTY ? nb : fill, rr, tails);
             }
             if (half == 0u) {
                 // fetch ahead the row of the node that is first in line now; always one load: static wait counts
@@ -974,13 +1004,19 @@ struct FastWalker {
             if constexpr (TOUCH) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(touched[j])); // (arrived before the rows did)
+                if constexpr (XT) asm volatile("" ::"v"(touched_x));
                 // y's adjacency row came in right behind the rows; a pair past its end touches y's own row
                 const uint32_t tid = next_nb != ID_EMPTY ? next_nb : yid;
-                const uint8_t* tb = p.elements + (size_t)tid * ROWB;
+                const uint8_t* tb = p.elements + (size_t)tid * RSTRIDE;
+                // what an expansion of y reads of a neighbor's row: all of it, or (XT with the tails in y's record) its chunks
+                const uint32_t lim = (XT && adjx) ? (uint32_t)NB * 128u : ROWB;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const uint32_t off = h * 128u + (uint32_t)j * 256u;
-                    touched[j] = *reinterpret_cast<const uint32_t*>(tb + (off < ROWB ? off : ROWB - 4u));
+                    touched[j] = *reinterpret_cast<const uint32_t*>(tb + (off < lim ? off : lim - 4u));
+                }
+                if constexpr (XT) { // ... and the lines of y's record that hold its neighbors' tails (eight pairs share one)
+                    if (adjx) touched_x = *(gptr_u32)(adjx + (size_t)yid * Ly.adjx_stride + 128u + R * XTAILB);
                 }
                 asm volatile("" ::: "memory");
             }

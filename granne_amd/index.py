@@ -139,6 +139,15 @@ class Granne:
         """py/src/lib.rs:318-330."""
         check(lib().granne_hip_index_save(self._h, os.fsencode(path), None))
 
+    def index_bytes(self):
+        """Index::write_index into a buffer (src/index/mod.rs:67-70): the bytes of the index file."""
+        out, n = C.c_void_p(), C.c_uint64(0)
+        check(lib().granne_hip_index_encode(self._h, C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out, n.value)
+        finally:
+            lib().granne_hip_bytes_free(out)
+
     def save_elements(self, path):
         """py/src/lib.rs:332-343."""
         check(lib().granne_hip_index_save(self._h, None, os.fsencode(path)))

@@ -263,6 +263,11 @@ int granne_hip_write_elements_file(const char* path, const void* elements, uint6
 /* save_index / save_elements of a device-resident index (py/src/lib.rs:318-343); either path may
  * be NULL. */
 int granne_hip_index_save(const granne_hip_index* index, const char* index_path, const char* elements_path);
+/* Index::write_index<B: Write + Seek> (src/index/mod.rs:67-70, src/index/io.rs:11-70) for a device-resident index: the
+ * bytes of the index file in a buffer of the library's (released with granne_hip_bytes_free); a Rust host hands them to
+ * its writer. */
+int granne_hip_index_encode(const granne_hip_index* index, void** out_bytes, uint64_t* out_len);
+void granne_hip_bytes_free(void* bytes);
 /* Host-only inspection of an index file (no device involved): layer count, nodes and ids per
  * layer (arrays of `cap` entries), and the decoded CSR form of one layer
  * (out_offsets[layer_len + 1], out_ids[ids of that layer], ascending within a node). */
@@ -488,8 +493,17 @@ enum {
                                          is left.) Lists beyond 1024 keys and 64-id layers always walk without a set */
     GRANNE_HIP_OPT_VISITED16_LG = 7,  /* retired with the bucket tables it sized: accepted (0..12), ignored */
     GRANNE_HIP_OPT_LAST_WALKER = 8,   /* read-only (get_option): which kernel the index's last search launch took */
-    GRANNE_HIP_OPT_SEARCH_DEPTH = 9   /* batches that granne_hip_search_begin_device may have in flight: 1..GRANNE_HIP_SEARCH_DEPTH_MAX
+    GRANNE_HIP_OPT_SEARCH_DEPTH = 9,  /* batches that granne_hip_search_begin_device may have in flight: 1..GRANNE_HIP_SEARCH_DEPTH_MAX
                                          [GRANNE_HIP_SEARCH_DEPTH]; cannot change while one is */
+    GRANNE_HIP_OPT_INLINE_TAILS = 10  /* f32 indexes of 100 or 200 dimensions whose layers are 32 ids wide keep, for the
+                                         register walker, a second copy of every layer in which a node's 32 neighbor ids are
+                                         followed by the TAILS of those neighbors' rows (the dim % 32 last components, which
+                                         src/math.rs:32-39 adds after the ordered sum): an expansion then reads whole 128-byte
+                                         lines only -- three per 100-d neighbor instead of four. Costs 128 + 32 x tail bytes
+                                         per node and layer (6.9 GB at 10M x 100-d) of HBM; results are the same bits.
+                                         1 = keep it [default], 0 = drop it (the tails are read from the rows). Setting it
+                                         (re)makes or frees the copy: not while a search of the index is running.
+                                         get_option returns 1 only when the index actually holds the copy */
 };
 enum {
     GRANNE_HIP_WALKER_NONE = 0,          /* no search yet */

@@ -37,14 +37,42 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(raw, name), name
 
 
-def test_rust_binding_in_integration_md_declares_the_whole_header():
-    """INTEGRATION.md's src/gpu.rs: every entry point of include/granne_hip.h is declared, with exactly the
+RUST_GPU_RS = os.path.join(ROOT, "rust", "granne-hip", "src", "gpu.rs")
+
+
+def test_rust_crate_is_on_disk_and_integration_md_points_at_it():
+    """The Rust side is a crate a maintainer (or a box with cargo) can `cargo check`: Cargo.toml, build.rs (the link
+    line, like the reference's build.rs:1-6), src/lib.rs, src/gpu.rs -- INTEGRATION.md refers to the file instead of
+    embedding a second copy."""
+    crate = os.path.join(ROOT, "rust", "granne-hip")
+    for f in ("Cargo.toml", "build.rs", os.path.join("src", "lib.rs"), os.path.join("src", "gpu.rs")):
+        assert os.path.getsize(os.path.join(crate, f)) > 0, f
+    assert "cargo:rustc-link-lib=dylib=granne_hip" in open(os.path.join(crate, "build.rs")).read()
+    assert re.search(r'granne\s*=\s*\{[^}]*path', open(os.path.join(crate, "Cargo.toml")).read())
+    lib_rs = open(os.path.join(crate, "src", "lib.rs")).read()
+    assert "pub mod gpu;" in lib_rs
+    gpu = open(RUST_GPU_RS).read()
+    for name in re.findall(r"use crate::\{([^}]*)\}", gpu)[0].split(","):
+        assert re.search(r"pub use granne::\{[^}]*\b%s\b" % name.strip(), lib_rs), name  # what gpu.rs reaches through crate::
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "rust/granne-hip/src/gpu.rs" in doc
+    assert 'extern "C" {' not in doc  # no second copy of the binding to drift
+    # the reference's Index trait (src/index/mod.rs:54-71) on the GPU type, method for method
+    i = gpu.index("impl<E: GpuElements> Index for GpuGranne<E> {")
+    body = gpu[i:gpu.index("\n}\n", i)]
+    for m in ("fn len(", "fn num_layers(", "fn layer_len(", "fn get_neighbors(", "fn write_index<B: std::io::Write + std::io::Seek>("):
+        assert m in body, m
+    assert "granne_hip_index_encode(" in body and "granne_hip_bytes_free(" in body
+
+
+def test_rust_binding_declares_the_whole_header():
+    """rust/granne-hip/src/gpu.rs: every entry point of include/granne_hip.h is declared, with exactly the
     types the header has (tools/gen_rust_sys.py derives the Rust declaration from the C prototype)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gen_rust_sys", os.path.join(ROOT, "tools", "gen_rust_sys.py"))
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
-    doc = re.sub(r"\s+", "", open(os.path.join(ROOT, "INTEGRATION.md")).read())
+    doc = re.sub(r"\s+", "", open(RUST_GPU_RS).read())
     names = []
     for name, ret, params in g.protos():
         names.append(name)
@@ -119,7 +147,7 @@ def test_argument_validation_needs_no_device(lib):
 
 
 def test_rust_wrappers_call_the_entry_points_they_claim():
-    """INTEGRATION.md's src/gpu.rs: the safe wrappers of the device-resident entries (round 5) call exactly the prototype
+    """rust/granne-hip/src/gpu.rs: the safe wrappers of the device-resident entries (round 5) call exactly the prototype
     each one names, with the argument count the header declares -- a Rust host reaches search_batches_device / begin / end
     (and the partitioned equivalents) without writing `unsafe` itself."""
     import importlib.util
@@ -127,7 +155,7 @@ def test_rust_wrappers_call_the_entry_points_they_claim():
     g = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(g)
     arity = {name: len(params) for name, _ret, params in g.protos()}
-    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    doc = open(RUST_GPU_RS).read()
 
     def body_of(owner, fn):
         i = doc.index("impl<E: GpuElements> %s<E> {" % owner) if owner else 0
@@ -162,6 +190,7 @@ def test_rust_wrappers_call_the_entry_points_they_claim():
               ("GpuGranne", "search_batches_device", "granne_hip_search_batches_device"),
               ("GpuGranne", "begin<'a>", "granne_hip_search_begin_device"),
               ("GpuGranne", "set_search_depth", "granne_hip_index_set_option"),
+              ("GpuGranne", "set_inline_tails", "granne_hip_index_set_option"),
               ("GpuShardedGranne", "search_batch_device", "granne_hip_sharded_search_batch_device"),
               ("GpuShardedGranne", "begin<'a>", "granne_hip_sharded_begin_device")]
     for owner, fn, entry in claims:
