@@ -55,7 +55,7 @@ def test_traffic_in_profiles_is_stamped_with_the_current_kernel_sources():
     if stale:  # not an error of the product: the bench line then carries traffic = null and says why
         import pytest
         pytest.skip("profiles/pmc_traffic.json was measured on other kernel sources (%s != %s): retake the PMC passes "
-                    "(tools/r3_prof.sh + tools/prof_to_traffic.py)" % (stamped[stale[0]], sha))
+                    "(tools/r6_prof.sh + tools/r6_traffic.py)" % (stamped[stale[0]], sha))
 
 
 def test_ground_truth_rows_merge_by_distance_then_id():
