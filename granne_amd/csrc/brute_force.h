@@ -179,7 +179,10 @@ struct BfShare {
     __device__ __forceinline__ float edge(int j) const { return step * (float)(64 + j); }
     // an element with score sc (> base) has just been inserted
     __device__ __forceinline__ void count(const BruteParams& P, uint32_t q, float sc) {
-        int j = (int)(sc * __builtin_amdgcn_rcpf(step)) - 64;
+        // (clamped as a float first: sc may be many orders above a base of 1e-30, and a float beyond int's range converts
+        //  to nothing C++ defines)
+        const float jf = __builtin_fminf(sc * __builtin_amdgcn_rcpf(step), 64.0f + (float)BF_SHARE_BUCKETS);
+        int j = (int)jf - 64;
         j = j < 0 ? 0 : (j > BF_SHARE_BUCKETS - 1 ? BF_SHARE_BUCKETS - 1 : j);
         while (j > 0 && sc < edge(j)) --j; // the count of bucket j vouches for sc >= edge(j): never round up into one
         __hip_atomic_fetch_add(P.share_hist + (size_t)q * BF_SHARE_BUCKETS + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -103,14 +104,20 @@ struct ScratchCache {
         size_t cap;
         uint64_t last_use;   // `uses` at the block's last launch
         uint32_t small_runs; // consecutive launches that needed less than a quarter of an oversized block
+        std::chrono::steady_clock::time_point last_time; // wall clock of the block's last launch
     };
     std::mutex mu;
     std::vector<Block> blocks;
     uint64_t uses = 0;
+    // blocks of streams that gave their place up: freed by search_launch AFTER it has released `mu` (hipFree waits for
+    // the device; every concurrent searcher of the index would wait with it under the lock)
+    std::vector<uint8_t*> graveyard;
     void free_all() {
         for (auto& b : blocks)
             if (b.p) (void)hipFree(b.p);
         blocks.clear();
+        for (auto* p : graveyard) (void)hipFree(p);
+        graveyard.clear();
     }
 };
 
@@ -313,11 +320,33 @@ static int make_inline_tails(granne_hip_index* ix, hipStream_t s) {
     return GRANNE_HIP_OK;
 }
 
+// The exact scan of int8 rows (brute_force.h) reads 1 / |x| per row and the largest of them per half block of 32: made
+// here, when the index is made (and again after reorder), on the creating stream -- a scan never allocates, never
+// synchronises its caller's stream and can be captured (round 5 made them lazily inside the first scan, under norm_mu).
+static int make_scan_norms(granne_hip_index* ix, hipStream_t s) {
+    if (ix->dtype != GRANNE_HIP_I8 || ix->row_bytes > 128 || ix->n_elements == 0) return GRANNE_HIP_OK;
+    std::lock_guard<std::mutex> lk(ix->norm_mu);
+    if (ix->d_inv_norm) return GRANNE_HIP_OK;
+    const uint64_t n = ix->n_elements, n_pad = (n + 31u) & ~31ull;
+    float* dn = nullptr;
+    HIP_TRY(hipMalloc((void**)&dn, (size_t)inv_norm_bytes(n)));
+    hipLaunchKernelGGL(inv_norm_rows_kernel, dim3(grid_for(n * 8, 256)), dim3(256), 0, s, ix->d_elements, n, ix->row_stride, dn);
+    hipLaunchKernelGGL(inv_gmax_kernel, dim3(grid_for(n_pad / 16 + 1, 256)), dim3(256), 0, s, (const float*)dn, n, dn + n_pad);
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipFree(dn);
+        return fail(GRANNE_HIP_ERR_HIP, "inv_norm_rows_kernel failed");
+    }
+    ix->d_inv_norm = dn; // (finish_layers synchronises s before the index is handed out)
+    ix->hbm_bytes += inv_norm_bytes(n);
+    return GRANNE_HIP_OK;
+}
+
 static int finish_layers(granne_hip_index* ix, hipStream_t s) {
     std::vector<LayerDev> h(ix->layers.size());
     ix->max_dev_width = 32;
     {
         int r = make_inline_tails(ix, s);
+        if (r == 0) r = make_scan_norms(ix, s);
         if (r) return r;
     }
     // rows that name a neighbor twice (LAYER_TWIN_ROWS, walk_fast.h): looked for once, here, on the device rows
@@ -902,6 +931,7 @@ constexpr size_t SCRATCH_STATE_OFF = CTL_WORDS * 4;                   // region 
 constexpr size_t SCRATCH_FIXED = SCRATCH_STATE_OFF + (size_t)SCRATCH_MAX_REGIONS * 4; // zero between launches
 
 constexpr size_t SCRATCH_CACHE_STREAMS = 64;      // streams that keep a block for the life of the index
+constexpr int SCRATCH_IDLE_SECONDS = 10;          // a cached stream idle this long gives its place to a newcomer when the cache is full
 constexpr size_t SCRATCH_SHRINK_ABOVE = 256u << 20; // a cached block this large is let go when a launch needs < 1/4 of it
 
 // `*transient` is set when the block was taken from the stream-ordered allocator for this launch alone (the cache is
@@ -921,9 +951,12 @@ static int scratch_for(ScratchCache* cache, hipStream_t s, size_t total, uint8_t
             ScratchCache::Block* lru = &cache->blocks[0];
             for (auto& x : cache->blocks)
                 if (x.last_use < lru->last_use) lru = &x;
-            if (cache->uses - lru->last_use > 4 * SCRATCH_CACHE_STREAMS) {
-                if (lru->p) (void)hipFree(lru->p); // (waits for the device: whatever still used the block is over)
-                *lru = {s, nullptr, 0, cache->uses, 0};
+            // idle for SCRATCH_IDLE_SECONDS of wall clock (not "for so many launches": a live stream that pauses while others
+            // search keeps its block)
+            const auto idle = std::chrono::steady_clock::now() - lru->last_time;
+            if (idle > std::chrono::seconds(SCRATCH_IDLE_SECONDS)) {
+                if (lru->p) cache->graveyard.push_back(lru->p); // freed once the lock is released (search_launch)
+                *lru = {s, nullptr, 0, cache->uses, 0, std::chrono::steady_clock::now()};
                 b = lru;
             } else {
                 HIP_TRY(hipMallocAsync((void**)out, total, s));
@@ -932,11 +965,12 @@ static int scratch_for(ScratchCache* cache, hipStream_t s, size_t total, uint8_t
                 return GRANNE_HIP_OK;
             }
         } else {
-            cache->blocks.push_back({s, nullptr, 0, cache->uses, 0});
+            cache->blocks.push_back({s, nullptr, 0, cache->uses, 0, std::chrono::steady_clock::now()});
             b = &cache->blocks.back();
         }
     }
     b->last_use = cache->uses;
+    b->last_time = std::chrono::steady_clock::now();
     // a block left oversized by one exact-walker batch is let go once eight launches in a row needed less than a quarter
     // of it (not at the first: a stream that alternates the two kinds of batches keeps its block)
     if (b->cap > SCRATCH_SHRINK_ABOVE && total < b->cap / 4) b->small_runs += 1;
@@ -1047,11 +1081,18 @@ static int search_launch(const SearchTarget* ix, const void* d_queries, int64_t 
     // The cache's mutex covers finding (or growing) this stream's block and the enqueue -- host work of microseconds.
     // Whatever waits for the GPU (the synchronisation behind h_slow_count) happens after it is released: host threads
     // searching one index on streams of their own do not queue behind each other's kernels.
+    struct Bury { // (declared before the lock: destroyed after it is released)
+        std::vector<uint8_t*> blocks;
+        ~Bury() {
+            for (auto* b : blocks) (void)hipFree(b); // waits for the device: whatever still used an evicted block is over
+        }
+    } bury;
     std::unique_lock<std::mutex> cache_lock(ix->scratch->mu);
     uint8_t* scratch = nullptr;
     bool transient = false;
     {
         int r = scratch_for(ix->scratch, s, total, &scratch, &transient);
+        bury.blocks.swap(ix->scratch->graveyard);
         if (r) return r;
     }
     struct FreeTransient { // a block of the stream-ordered allocator goes back after the launch's last use of it
@@ -1637,7 +1678,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     if (ix->dtype == GRANNE_HIP_I8) {
         granne_hip_index* mix = const_cast<granne_hip_index*>(ix);
         std::lock_guard<std::mutex> lk(mix->norm_mu);
-        if (!mix->d_inv_norm) { // (rows do not change under an index: reorder builds new arrays and drops this one)
+        if (!mix->d_inv_norm) { // (made with the index, make_scan_norms: this is the path of an index that has no layers yet)
             float* dn = nullptr;
             HIP_TRY(hipMalloc((void**)&dn, (size_t)inv_norm_bytes(n)));
             hipLaunchKernelGGL(inv_norm_rows_kernel, dim3(grid_for(n * 8, 256)), dim3(256), 0, s, ix->d_elements, n, ix->row_stride, dn);

@@ -320,8 +320,8 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// one wave per query: the k best of the shards' candidates by (dist, global id). Every shard's list is ascending, so
-// the answer is a k-way merge: lane s stands at the head of shard s's list, the wave's smallest head is the next result
+// one wave per query: the k best of the shards' candidates by (dist, global id). Every shard's list is ascending (or
+// is made so first, below), so the answer is a k-way merge: lane s stands at the head of shard s's list, the wave's smallest head is the next result
 // and that lane moves on -- k rounds of one wave-wide minimum. (Ranking all C = n_shards * k candidates against each
 // other was 1.4 ms of the 8.5 ms of a 1024-query scan whose 64 element ranges bring 16 candidates each.)
 __global__ __launch_bounds__(64) void merge_topk_kernel(const MergeParams P) {
@@ -341,6 +341,31 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const MergeParams P) {
         size_t src = (size_t)q * P.k + j;
         kd[c] = ok ? __float_as_uint(sd[src]) : 0xFFFFFFFFu;
         ki[c] = ok ? sid[src] + P.offsets[s] : ~0ull;
+    }
+    __syncthreads();
+    // The merge below needs every list ascending by (dist, id), valid entries first. The searches' lists are; a caller's
+    // own may not be (the entry points promise the k best by (dist, global id) of WHATEVER they are given: round 4 ranked
+    // all candidates against each other): lane s checks list s on its way, and a list out of order is put in order
+    // first -- an insertion sort by its own lane, in LDS, the price of k reads when nothing is to be done.
+    if (lane < P.n_shards && P.k > 1) {
+        uint32_t* d = kd + lane * P.k;
+        uint64_t* i = ki + lane * P.k;
+        bool sorted = true;
+        for (uint32_t j = 1; j < P.k; ++j) sorted = sorted && (d[j - 1] < d[j] || (d[j - 1] == d[j] && i[j - 1] <= i[j]));
+        if (!sorted) {
+            for (uint32_t j = 1; j < P.k; ++j) {
+                const uint32_t dj = d[j];
+                const uint64_t ij = i[j];
+                uint32_t t = j;
+                while (t > 0 && (d[t - 1] > dj || (d[t - 1] == dj && i[t - 1] > ij))) {
+                    d[t] = d[t - 1];
+                    i[t] = i[t - 1];
+                    --t;
+                }
+                d[t] = dj;
+                i[t] = ij;
+            }
+        }
     }
     __syncthreads();
     uint32_t pos = 0; // this lane's place in its shard's list

@@ -641,6 +641,14 @@ struct FastWalker {
         }
     }
 
+    // Where a candidate's rank (the entries above its key) is counted. One slot (max_search up to 60: the shape of one
+    // query per call and of one batch per launch, where a walker has its SIMD to itself): on the VECTOR side -- v_bcnt of
+    // the compare's mask, because a scalar instruction that reads a vector result makes a lone wave wait ~16 clocks. Longer
+    // lists run many walkers per SIMD (max_search 61 and up: 4-6 waves) and are bound by the VALU's issue slots instead
+    // (C5's shard: 70 k vector instructions per query, the vector pipe 60 % busy; per pair of candidates and four slots 16
+    // v_mov + 16 v_bcnt + 6 v_add3 of 62 vector instructions were this count): there s_bcnt1_i32_b64 counts the mask where
+    // v_cmp left it, on the scalar pipe, which the other waves' vector work hides.
+    static constexpr bool SCALAR_COUNTS = S >= 2;
     struct Ranked {
         uint32_t shift[S]; // list entries: candidates that sort before my key
         uint32_t rankv;    // candidate lanes: entries of the list below my key
@@ -671,10 +679,14 @@ struct FastWalker {
             const bool g = L.key[s] > K;
             rk.shift[s] += g ? 1u : 0u;
             const uint64_t gm = wave_ballot(g);
-            uint32_t g_lo = (uint32_t)gm, g_hi = (uint32_t)(gm >> 32);
-            asm("" : "+v"(g_lo));
-            asm("" : "+v"(g_hi)); // (in vector registers: the counts are v_bcnt's, not s_bcnt1's)
-            above += (uint32_t)__builtin_popcount(g_lo) + (uint32_t)__builtin_popcount(g_hi);
+            if constexpr (SCALAR_COUNTS) {
+                above += (uint32_t)__popcll(gm); // s_bcnt1_i32_b64
+            } else {
+                uint32_t g_lo = (uint32_t)gm, g_hi = (uint32_t)(gm >> 32);
+                asm("" : "+v"(g_lo));
+                asm("" : "+v"(g_hi)); // (in vector registers: the counts are v_bcnt's, not s_bcnt1's)
+                above += (uint32_t)__builtin_popcount(g_lo) + (uint32_t)__builtin_popcount(g_hi);
+            }
         }
         rk.rankv = __builtin_amdgcn_inverse_ballot_w64(bit) ? above : rk.rankv;
         rk.below += (ck > K) ? 1u : 0u;
@@ -697,14 +709,19 @@ struct FastWalker {
         for (int s = 0; s < S; ++s) {
             const bool ga = L.key[s] > Ka, gb = L.key[s] > Kb;
             const uint64_t gma = wave_ballot(ga), gmb = wave_ballot(gb);
-            uint32_t a0 = (uint32_t)gma, a1 = (uint32_t)(gma >> 32), b0 = (uint32_t)gmb, b1 = (uint32_t)(gmb >> 32);
-            asm("" : "+v"(a0));
-            asm("" : "+v"(b0));
-            asm("" : "+v"(a1));
-            asm("" : "+v"(b1));
             rk.shift[s] += (ga ? 1u : 0u) + (gb ? 1u : 0u);
-            above_a += (uint32_t)__builtin_popcount(a0) + (uint32_t)__builtin_popcount(a1);
-            above_b += (uint32_t)__builtin_popcount(b0) + (uint32_t)__builtin_popcount(b1);
+            if constexpr (SCALAR_COUNTS) {
+                above_a += (uint32_t)__popcll(gma);
+                above_b += (uint32_t)__popcll(gmb);
+            } else {
+                uint32_t a0 = (uint32_t)gma, a1 = (uint32_t)(gma >> 32), b0 = (uint32_t)gmb, b1 = (uint32_t)(gmb >> 32);
+                asm("" : "+v"(a0));
+                asm("" : "+v"(b0));
+                asm("" : "+v"(a1));
+                asm("" : "+v"(b1));
+                above_a += (uint32_t)__builtin_popcount(a0) + (uint32_t)__builtin_popcount(a1);
+                above_b += (uint32_t)__builtin_popcount(b0) + (uint32_t)__builtin_popcount(b1);
+            }
         }
         rk.rankv = __builtin_amdgcn_inverse_ballot_w64(bit_a) ? above_a : rk.rankv;
         rk.rankv = __builtin_amdgcn_inverse_ballot_w64(bit_b) ? above_b : rk.rankv;

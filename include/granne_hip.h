@@ -282,7 +282,10 @@ int granne_hip_index_file_decode_layer(const void* index_bytes, uint64_t index_l
  * query batch; this call merges the n_shards x k candidates of each query into the k best by
  * (dist, global id). d_ids/d_dists: [n_shards][nq][k] (the layout an all-gather of per-rank
  * [nq][k] results produces), d_counts: [n_shards][nq]; shard_offsets (HOST array, n_shards
- * entries) are added to the local ids. n_shards <= 64, n_shards * k <= 4096.               */
+ * entries) are added to the local ids. n_shards <= 64, n_shards * k <= 4096.
+ * A shard's list is normally what a search returned: ascending by (dist, id), its count[q] valid entries first. Lists in
+ * any other order are accepted and give the same answer (the kernel checks each list and sorts one that is out of
+ * order before its k-way merge) -- sorted lists are just the fast case.                                            */
 int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, const uint32_t* d_counts,
                                  const uint64_t* shard_offsets, uint32_t n_shards, uint32_t nq, uint32_t k,
                                  uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,

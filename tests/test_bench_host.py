@@ -143,3 +143,77 @@ def test_gpus_n_without_a_launcher_never_measures_one_gpu_silently():
     a = seen["argv"]
     assert a[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and a[a.index("--nproc-per-node") + 1] == "8"
     assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+
+
+def test_the_line_of_an_n_gpu_run_carries_roofline_and_cpu_baseline():
+    """N > 1 (the driver's SCALE runs): rank 0 still takes recall and the CPU baseline after the timed region (the other
+    ranks wait on the rendezvous store meanwhile), so the N-GPU line has `roofline` AND `cpu_baseline` like the one-GPU
+    line; the sweep, the latency probe and the sub-records stay with N = 1. Assembled here with a stand-in for the GPU."""
+    import json
+    import numpy as np
+    import torch
+    saved = sys.argv
+    sys.argv = ["bench.py", "--gpus", "2"]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = saved
+    plan = bench.rank0_plan(2, args)
+    assert plan["recall"] and plan["cpu_baseline"] and not plan["ef_sweep"] and not plan["extras"] and not plan["cpu_thread_sweep"]
+    one = bench.rank0_plan(1, args)
+    assert one["recall"] and one["cpu_baseline"] and one["ef_sweep"] and one["extras"] and one["cpu_thread_sweep"]
+
+    nq, k, dim, nb = args.batch, args.k, args.dim, args.warmup + args.steps
+    calls = []
+
+    class FakeBench:
+        world, rank = 2, 0
+
+        def __init__(self):
+            self.torch = torch
+
+        def ground_truth(self, index, q0, k, dtype, timing=None, n=None):
+            calls.append("ground_truth")
+            timing.update({"ms": 17.0, "value": 60000.0, "frac": 0.76, "bound": "mfma", "peak": 157.3, "unit": "TFLOP/s"})
+            return np.zeros((q0.shape[0], k), np.int64)
+
+        @staticmethod
+        def recall(gt, got, k):
+            return 0.02
+
+        def host_index(self, elements, builder, order=None):
+            calls.append("host_index")
+            return object()
+
+        def cpu_baseline(self, oix, h_q, ef, k, g_ids, g_d, single_thread_queries=256, sweep=True):
+            calls.append(("cpu_baseline", sweep, h_q.shape[0]))
+            return {"value": 45000.0, "unit": "queries/s", "cores": 16, "kind": "port", "sample": "stand-in",
+                    "gpu_matches_oracle": {"ids_bit_exact": True, "dists_bit_exact": True, "queries_checked": int(h_q.shape[0])}}
+
+        def check_scan(self, *a, **kw):
+            calls.append("check_scan")
+
+    m = {"ids": torch.zeros((nb, nq, k), dtype=torch.int64), "dists": torch.zeros((nb, nq, k), dtype=torch.float32)}
+    queries = torch.zeros((nb * nq, dim), dtype=torch.float32)
+    value = 2 * 7.6e6
+    out = {"metric": "queries/sec (recall@10 alongside), 10M x 100-d angular, batch=1024", "value": value, "unit": "queries/s",
+           "n_gpus": 2, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.134, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": bench.workload_label(args.n, dim, "f32", "uniform", nq, args.ef, k)},
+           "roofline": {"bound": "hbm", "achieved": 6200.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.775, "traffic": None}}
+    bench.rank0_after_the_timed_region(FakeBench(), args, out, None, None, None, queries, m, None, value, 20)
+    assert "ground_truth" in calls and "host_index" in calls and ("cpu_baseline", False, min(args.cpu_batches, args.steps) * nq) in calls
+    assert out["cpu_baseline"]["value"] == 45000.0 and out["recall_at_10"] == 0.02 and out["speedup_vs_cpu"] == round(value / 45000.0, 2)
+    for absent in ("ef_sweep", "latency_nq1", "int8", "secondary", "c4_shard", "c5_shard", "recall_target"):
+        assert absent not in out, absent
+    line = json.loads(bench.compact_line(out, None))
+    assert line["n_gpus"] == 2
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"], key
+
+
+def test_the_secondary_generators_are_named_in_their_labels():
+    mix = bench.workload_label(10_000_000, 100, "f32", "mixture", 1024, 100, 10)
+    assert "mixture of %d Gaussians" % bench.MIX_CENTERS in mix and not mix.startswith("C2")

@@ -248,3 +248,94 @@ def test_c1_glove_example_shape(oracle):
     oi, od, oc, _ = oix.search_batch(q, 200, 10)
     assert (ids == oi).all() and ds.tobytes() == od.tobytes() and (cnt == oc).all()
     assert (ids[:, 0] == mem).mean() > 0.5
+
+
+def test_c5_shard_shape_int8_max_search_200_batch_4096(oracle):
+    """BASELINE.json configs[4] as one shard holds it: 100-d int8 rows, max_search 200 (four list slots of the register
+    walker), batches of 4096, seven layers -- at 25M points (a shard of the real job has 125M and the same seven layers:
+    bench.py's c5_shard sub-record measures that one; its host copy alone is 30 GB). 4,096 queries against the CPU oracle
+    on the same index: ids, distance bits, counters. Set GRANNE_FULLSIZE_N_C5 for another size."""
+    import torch
+    import granne_amd
+    from granne_amd import _lib
+    from concurrent.futures import ThreadPoolExecutor
+    lib = _lib.lib()
+    n, dim, nq, ef, k = int(os.environ.get("GRANNE_FULLSIZE_N_C5", "25000000")), 100, 4096, 200, 10
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    el = torch.empty((n, dim), dtype=torch.int8, device="cuda")
+    step = 12_500_000
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        raw = torch.empty((r1 - r0, dim), dtype=torch.float32, device="cuda")
+        _lib.check(lib.granne_hip_synth_rows_device(C.c_void_p(raw.data_ptr()), SEED, r0, r1 - r0, dim, 0, sp))
+        _lib.check(lib.granne_hip_quantize_f32_device(C.c_void_p(raw.data_ptr()), C.c_void_p(el[r0:r1].data_ptr()), r1 - r0, dim, 0, sp))
+        torch.cuda.synchronize()
+        del raw
+    rawq = torch.empty((nq, dim), dtype=torch.float32, device="cuda")
+    _lib.check(lib.granne_hip_synth_rows_device(C.c_void_p(rawq.data_ptr()), SEED + 1, 0, nq, dim, 0, sp))
+    q = torch.empty((nq, dim), dtype=torch.int8, device="cuda")
+    _lib.check(lib.granne_hip_quantize_f32_device(C.c_void_p(rawq.data_ptr()), C.c_void_p(q.data_ptr()), nq, dim, 0, sp))
+    torch.cuda.synchronize()
+    b = granne_amd.GranneBuilder.from_device("angular_int", el.data_ptr(), n, dim, num_neighbors=30, max_search=200,
+                                             reinsert_elements=True)
+    b.build()
+    sizes = [b.layer_len(l) for l in range(b.num_layers())]
+    assert sizes == [oracle.num_elements_in_layer(n, 15.0, l) for l in range(len(sizes))]
+    if n == 25_000_000:
+        assert len(sizes) == 7  # like the 125M shard (src/index/mod.rs:634-643)
+    ix = b.get_index()
+    layers = b.layers()
+    b.close()
+    h_el = np.empty((n, dim), np.int8)
+    parts = 16
+    bounds = [n * i // parts for i in range(parts + 1)]
+
+    def cp(i):
+        h_el[bounds[i]:bounds[i + 1]] = el[bounds[i]:bounds[i + 1]].cpu().numpy()
+    with ThreadPoolExecutor(8) as ex:
+        list(ex.map(cp, range(parts)))
+    oix = oracle.Index(h_el, layers)
+    h_q = q.cpu().numpy()
+    ids, ds, cnt, st = ix.search_batch(h_q, ef, k, stats=True)
+    assert ix.get_option(_lib.OPT_LAST_WALKER) == 1  # the register walker
+    oi, od, oc, octr = oix.search_batch(h_q, ef, k, n_threads=0)
+    assert (cnt == oc).all() and (ids == oi).all(), int((ids != oi).any(axis=1).sum())
+    assert ds.tobytes() == od.tobytes()
+    assert_counters(st, octr, exact=False)
+    assert ix.last_slow_count() == 0
+    # the same batch as part of a launch of several (how bench.py hands batches over) and with the exact visited set
+    ix.set_option(_lib.OPT_VISITED16, 3)
+    ids3, ds3, cnt3, st3 = ix.search_batch(h_q[:1024], ef, k, stats=True)
+    ix.set_option(_lib.OPT_VISITED16, 0)
+    assert (ids3 == oi[:1024]).all() and ds3.tobytes() == od[:1024].tobytes()
+    assert_counters(st3, octr[:1024], exact=True)
+
+
+@pytest.mark.parametrize("data", ["latent", "mixture"])
+def test_graph_quality_on_data_with_structure(data):
+    """The reference's own quality bar (verify_search, src/index/tests.rs:50-62: members of the set, searched at
+    (max_search, 1), find themselves more than 95 % of the time) holds on 10M-point graphs the GPU builder makes -- on data
+    with structure (bench.py's two secondary generators at 1M points). On BASELINE's i.i.d.-uniform 100-d points no graph
+    of this family reaches it (test_members_find_themselves states what it does reach), which is why a build gone wrong
+    would not show there and must show here."""
+    import types
+    import torch
+    import bench
+    import granne_amd
+    n, dim = 1_000_000, 100
+    args = types.SimpleNamespace(gpus=1)
+    os.environ.pop("WORLD_SIZE", None)
+    B = bench.Bench(args)
+    el = B.rows(data, SEED, 0, n, dim, "f32")
+    torch.cuda.synchronize()
+    b = granne_amd.GranneBuilder.from_device("angular", el.data_ptr(), n, dim, num_neighbors=30, max_search=200,
+                                             reinsert_elements=True)
+    b.build()
+    ix = b.get_index()
+    b.close()
+    mem = torch.arange(0, n, n // 4096, device="cuda")[:4096]
+    rows = el[mem].cpu().numpy()
+    ids, ds, cnt = ix.search_batch(rows, 50, 1)
+    hit = (ids[:, 0] == mem.cpu().numpy().astype(np.uint64)) | (ds[:, 0] <= 1e-6)
+    print("self-query hit rate, %s, n=%d: %.4f" % (data, n, hit.mean()))
+    assert hit.mean() > 0.95, hit.mean()

@@ -885,3 +885,110 @@ def test_neighbor_ids_outside_their_layer_are_rejected(ga, oracle):
     with pytest.raises(_lib.GranneHipError) as e:
         ga.Granne("angular", el, layers)
     assert e.value.code == _lib.ERR_INVALID
+
+
+# ---- round 6: rows on lines, the neighbors' tails next to the ids (LayerDev::adjx) --------------------------------------
+@pytest.mark.parametrize("dim", [100, 200])
+@pytest.mark.parametrize("max_search", [1, 50, 200, 600, 1500, 3000])
+def test_inline_tails_on_and_off_are_the_same_walk(ga, oracle, dim, max_search):
+    """GRANNE_HIP_OPT_INLINE_TAILS: 100-d / 200-d f32 indexes keep a copy of every layer in which a node's ids are followed
+    by the tails (the dim % 32 last floats, added after the ordered sum: src/math.rs:32-39) of its neighbors' rows. On (the
+    default) or off, every list length of the register walker returns the oracle's ids, distance bits and counters; rows
+    shorter than 32 ids (and empty ones) read no tail of their own; the option can be flipped on a live index."""
+    from granne_amd import _lib
+    rng = np.random.default_rng(dim * 7 + max_search)
+    n, nq = 6000, 96
+    el = prep(oracle, random_floats(rng, n, dim), False)
+    el[17] = el[4000]  # exact distance ties
+    el[18] = 0         # a zero vector: never indexed, its row stays empty (src/index/mod.rs:813-815)
+    q = prep(oracle, random_floats(rng, nq, dim), False)
+    oix = oracle.build_index(el, num_neighbors=30, max_search=40, reinsert_elements=True, n_threads=0)
+    gix = ga.Granne("angular", el, oix.layers)
+    assert gix.get_option(_lib.OPT_INLINE_TAILS) == 1
+    with_tails = gix.hbm_bytes()
+    a = assert_same(oix, gix, q, max_search, 10)
+    gix.set_option(_lib.OPT_INLINE_TAILS, 0)
+    assert gix.get_option(_lib.OPT_INLINE_TAILS) == 0
+    per_node = 128 + 32 * 4 * (dim % 32)
+    assert with_tails - gix.hbm_bytes() == per_node * sum(len(l) for l in oix.layers)
+    b = assert_same(oix, gix, q, max_search, 10)
+    gix.set_option(_lib.OPT_INLINE_TAILS, 1)
+    c = assert_same(oix, gix, q, max_search, 10)
+    for x, y in ((a, b), (a, c)):
+        assert (x[0] == y[0]).all() and x[1].tobytes() == y[1].tobytes()
+    assert gix.hbm_bytes() == with_tails
+    # one query per call (the rows-touched-ahead form of the walker touches the record's tail lines too)
+    for i in range(4):
+        res = gix.search(q[i], max_search, 10)
+        oi, od, oc, _ = oix.search_batch(q[i:i + 1], max_search, 10)
+        assert [r[0] for r in res] == oi[0, :int(oc[0])].tolist()
+
+
+def test_inline_tails_follow_reorder_and_builder_output(ga, oracle):
+    """The copy is made whenever an index's layers are final: from host layers, from a GPU builder's get_index, after
+    Granne::reorder (ids and elements have moved: the tails must be the NEW neighbors')."""
+    from granne_amd import _lib
+    rng = np.random.default_rng(99)
+    n, dim, nq = 5000, 100, 64
+    el = prep(oracle, random_floats(rng, n, dim), False)
+    q = prep(oracle, random_floats(rng, nq, dim), False)
+    b = ga.GranneBuilder("angular", el, num_neighbors=30, max_search=40, reinsert_elements=True, batch_max=256, batch_div=8)
+    b.build()
+    gix = b.get_index()
+    assert gix.get_option(_lib.OPT_INLINE_TAILS) == 1
+    oix = oracle.Index(el, b.layers())
+    before = assert_same(oix, gix, q, 50, 10)
+    order = gix.reorder()
+    assert gix.get_option(_lib.OPT_INLINE_TAILS) == 1
+    after = gix.search_batch(q, 50, 10)
+    assert after[1].tobytes() == before[1].tobytes()
+    distinct = (np.diff(before[1], axis=1) > 0).all(axis=1)
+    assert np.array_equal(order[after[0][distinct].astype(np.int64)], before[0][distinct])
+    # other shapes have no such copy: int8 rows are one line already, streamed dims read their tails from the rows
+    for et, d in (("angular_int", 100), ("angular", 96), ("angular", 300)):
+        e2 = prep(oracle, random_floats(rng, 500, d), et == "angular_int")
+        o2 = oracle.build_index(e2, num_neighbors=10, max_search=20, n_threads=0)
+        g2 = ga.Granne(et, e2, o2.layers)
+        assert g2.get_option(_lib.OPT_INLINE_TAILS) == 0
+        assert_same(o2, g2, prep(oracle, random_floats(rng, 16, d), et == "angular_int"), 30, 5)
+
+
+@pytest.mark.parametrize("dim", [64, 65, 100, 127, 160, 200, 300])
+def test_f32_rows_start_on_lines_and_every_operator_reads_them(ga, oracle, dim):
+    """f32 rows of 256 bytes and more start on a 128-byte line on the device (row stride != row bytes for most dims): search,
+    dists, get_element, the exact scan and the GPU builder all read the same rows."""
+    rng = np.random.default_rng(dim)
+    n = 3000
+    el = prep(oracle, random_floats(rng, n, dim), False)
+    q = prep(oracle, random_floats(rng, 32, dim), False)
+    b = ga.GranneBuilder("angular", el, num_neighbors=20, max_search=30, reinsert_elements=False, batch_max=256, batch_div=8)
+    b.build()
+    gix = b.get_index()
+    oix = oracle.Index(el, b.layers())
+    ob = oracle.build_index(el, num_neighbors=20, max_search=30, reinsert_elements=False, batch_max=256, batch_div=8, n_threads=0)
+    for lg, lo in zip(b.layers(), ob.layers):
+        assert np.array_equal(lg, lo)  # the GPU build is the oracle's batched build
+    assert_same(oix, gix, q, 40, 10)
+    for i in (0, 1, n - 1):
+        assert gix.get_element(i).tobytes() == el[i].tobytes()
+    ids = rng.integers(0, n, (32, 9)).astype(np.uint32)
+    want = np.array([[oracle.dist(el[e], q[a]) for e in ids[a]] for a in range(32)], np.float32)
+    assert gix.dists_many(q, ids).tobytes() == want.tobytes()
+    if dim <= 256:
+        bi, bd, bc = gix.brute_force(q, 10)
+        d_all = np.array([[oracle.dist(el[e], q[a]) for e in range(n)] for a in range(4)], np.float32)
+        for a in range(4):
+            order = np.lexsort((np.arange(n), d_all[a]))[:10]
+            assert bd[a].tobytes() == d_all[a][order].tobytes()
+
+
+def test_index_bytes_are_the_index_file(ga, oracle, tmp_path):
+    """granne_hip_index_encode (Index::write_index into a writer, src/index/mod.rs:67-70) = the bytes save_index writes."""
+    rng = np.random.default_rng(5)
+    el = prep(oracle, random_floats(rng, 2000, 40), False)
+    oix = oracle.build_index(el, num_neighbors=12, max_search=20, n_threads=0)
+    gix = ga.Granne("angular", el, oix.layers)
+    p = tmp_path / "ix.granne"
+    gix.save_index(str(p))
+    blob = gix.index_bytes()
+    assert blob == p.read_bytes() and blob[:6] == b"granne" and len(blob) > 1024

@@ -321,3 +321,35 @@ def test_sharded_build_builds_the_groups_at_the_same_time(oracle):
     w = _want(oixs, q, ef, k, [b[0] for b in bounds])
     assert (cnt == w[2]).all() and (ids == w[0]).all() and ds.tobytes() == w[1].tobytes()
     sh.close()
+
+
+@pytest.mark.parametrize("shards,k", [(4, 10), (64, 16), (7, 1), (3, 33)])
+def test_merge_topk_accepts_lists_in_any_order(shards, k):
+    """ADVICE r5 (medium), util_kernels.h merge_topk_kernel: the k-way merge is only right for lists ascending by (dist, id);
+    the public entry promises the k best by (dist, global id) of whatever it is given (include/granne_hip.h). Lists out of
+    order -- shuffled, ties on distance, ragged counts -- must merge like the numpy reference; sorted ones stay the fast case."""
+    import torch
+    from granne_amd import _lib
+    rng = np.random.default_rng(shards * 1000 + k)
+    nq = 37
+    ids = rng.integers(0, 5000, (shards, nq, k)).astype(np.uint64)
+    ds = (rng.integers(0, 12, (shards, nq, k)) / 16.0).astype(np.float32)  # many ties on distance
+    cnt = rng.integers(0, k + 1, (shards, nq)).astype(np.uint32)
+    cnt[0, :] = k
+    offsets = (np.arange(shards, dtype=np.uint64) * 5000)
+    want = merge_topk_numpy(ids, ds, cnt, offsets, k)
+    d_ids, d_ds, d_cnt = (torch.from_numpy(ids.view(np.int64)).cuda(), torch.from_numpy(ds).cuda(), torch.from_numpy(cnt.view(np.int32)).cuda())
+    o_ids = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    o_ds = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    o_cnt = torch.empty(nq, dtype=torch.int32, device="cuda")
+    off = (C.c_uint64 * shards)(*[int(x) for x in offsets])
+    _lib.check(_lib.lib().granne_hip_merge_topk_device(
+        C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_ds.data_ptr()), C.c_void_p(d_cnt.data_ptr()), off, shards, nq, k,
+        C.c_void_p(o_ids.data_ptr()), C.c_void_p(o_ds.data_ptr()), C.c_void_p(o_cnt.data_ptr()), 0,
+        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert (o_cnt.cpu().numpy().astype(np.uint32) == want[2]).all()
+    got_ids, got_d = o_ids.cpu().numpy().view(np.uint64), o_ds.cpu().numpy()
+    for q in range(nq):
+        c = int(want[2][q])
+        assert got_d[q, :c].tobytes() == want[1][q, :c].tobytes() and (got_ids[q, :c] == want[0][q, :c]).all(), q
