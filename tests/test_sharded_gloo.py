@@ -173,3 +173,32 @@ def test_shard_bounds():
     assert sharded.shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert sharded.shard_bounds(100_000_000, 8)[7] == (87_500_000, 100_000_000)
     assert sharded.shard_bounds(3, 8)[5] == (3, 3)
+
+
+def _wait_worker(rank, world, port, out_dir):
+    """bench.py's N > 1 tail: rank 0 works (recall, the CPU baseline) while the others block on the rendezvous store --
+    not inside a collective, which would spin on the host cores the baseline is timed on."""
+    import time
+    import types
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    B = types.SimpleNamespace(rank=rank, world=world)
+    t0 = time.time()
+    if rank == 0:
+        time.sleep(1.5)  # "measuring"
+    bench.wait_for_rank0(B, "granne_bench_line_out", timeout_s=60)
+    waited = time.time() - t0
+    with open(os.path.join(out_dir, "wait%d.txt" % rank), "w") as f:
+        f.write("%.3f" % waited)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_wait_for_rank0_on_the_store(tmp_path):
+    world = 2
+    mp.start_processes(_wait_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    w = [float(open(os.path.join(tmp_path, "wait%d.txt" % i)).read()) for i in range(world)]
+    assert w[0] >= 1.4 and w[1] >= 1.0  # rank 1 left only after rank 0 posted the key

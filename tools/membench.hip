@@ -93,6 +93,63 @@ __global__ void touch_kernel(const uint8_t* base, uint64_t bytes, uint32_t* out)
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// round 6: a wavefront reads ONE contiguous record of `lines` 128-byte lines at a random place (what an expansion would
+// read if a node's record held its neighbors' rows themselves: 25 lines for 30 int8 rows of 100 bytes + the ids, 95 for
+// 30 f32 rows of 400 bytes + the ids), 16 bytes per lane and load, all loads in flight, waits, repeats.
+template <int NL>
+__global__ __launch_bounds__(64) void record_kernel(const uint8_t* base, uint64_t n_records, uint32_t record_bytes, uint32_t lines,
+                                                    uint32_t iters, uint64_t* out_cycles, uint32_t* out_sink) {
+    const uint32_t lane = threadIdx.x;
+    uint64_t cycles = 0;
+    uint32_t sink = 0;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint64_t rec = mix(((uint64_t)blockIdx.x << 32) ^ ((uint64_t)it << 8) ^ sink) % n_records;
+        const uint8_t* p = base + rec * record_bytes;
+        uint4 v[NL];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            uint32_t unit = (uint32_t)k * 64u + lane;
+            unit = unit < lines * 8u ? unit : lines * 8u - 1u;
+            v[k] = *reinterpret_cast<const uint4*>(p + (size_t)unit * 16u);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cycles += __builtin_amdgcn_s_memtime() - t0;
+        sink = 0;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(v[k].z), "v"(v[k].w));
+            sink |= v[k].x - 0x01010101u;
+        }
+    }
+    if (lane == 0) {
+        out_cycles[blockIdx.x] = cycles;
+        out_sink[blockIdx.x] = sink;
+    }
+}
+
+template <int NL>
+static void run_record(const char* name, const uint8_t* d, uint64_t n_records, uint32_t record_bytes, uint32_t lines, uint64_t* d_cyc,
+                       uint32_t* d_sink) {
+    const uint32_t iters = 64;
+    const int waves[] = {1024, 3072, 8192};
+    for (int w : waves) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(record_kernel<NL>, dim3(w), dim3(64), 0, 0, d, n_records, record_bytes, lines, 4u, d_cyc, d_sink);
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(record_kernel<NL>, dim3(w), dim3(64), 0, 0, d, n_records, record_bytes, lines, iters, d_cyc, d_sink);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-34s waves %5d: kernel %8.3f ms | %7.1f GB/s of 128-byte lines\n", name, w, ms,
+               (double)lines * iters * w * 128.0 / (ms * 1e-3) / 1e9);
+    }
+}
+
 template <int NL>
 static void run_burst(const char* name, const uint8_t* d, uint64_t n_rows, uint32_t stride, uint64_t* d_cyc, uint32_t* d_sink) {
     const uint32_t iters = 64;
@@ -112,13 +169,31 @@ static void run_burst(const char* name, const uint8_t* d, uint64_t n_rows, uint3
         CK(hipMemcpy(cyc.data(), d_cyc, (size_t)w * 8, hipMemcpyDeviceToHost));
         double sum = 0;
         for (auto c : cyc) sum += (double)c;
-        const double lines = (NL == 4 ? 1.0 : 4.0) * 32.0 * iters * w; // 128-byte lines touched
+        const double lines = (NL == 4 ? 1.0 : NL == 12 ? 3.0 : 4.0) * 32.0 * iters * w; // 128-byte lines touched
         printf("%-22s waves %5d: %8.0f cycles per burst | kernel %8.3f ms | %7.1f GB/s of 128-byte lines\n", name, w,
                sum / w / iters, ms, lines * 128.0 / (ms * 1e-3) / 1e9);
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && atoi(argv[1]) == 6) { // round 6: the ceilings of the layouts (3-line rows; 16 GB footprints; whole records)
+        const uint64_t big = 125000000ull; // rows of a C5 shard: 16 GB of 128-byte rows
+        uint8_t* d = nullptr;
+        CK(hipMalloc((void**)&d, big * 128ull + 65536));
+        CK(hipMemset(d, 1, big * 128ull + 65536));
+        uint64_t* d_cyc;
+        uint32_t* d_sink;
+        CK(hipMalloc((void**)&d_cyc, 8192 * 8));
+        CK(hipMalloc((void**)&d_sink, 8192 * 4));
+        run_burst<4>("i8 rows, stride 128, 1.3 GB", d, 10000000ull, 128, d_cyc, d_sink);
+        run_burst<4>("i8 rows, stride 128, 16 GB", d, big, 128, d_cyc, d_sink);
+        run_burst<12>("f32 3 of 4 lines, stride 512, 5 GB", d, 10000000ull, 512, d_cyc, d_sink);
+        run_burst<13>("f32 rows, stride 400, 4 GB", d, 10000000ull, 400, d_cyc, d_sink);
+        run_record<4>("int8 record 3200 B (25 lines), 16 GB", d, big * 128ull / 3200ull, 3200, 25, d_cyc, d_sink);
+        run_record<12>("f32 record 12160 B (95 lines), 16 GB", d, big * 128ull / 12160ull, 12160, 95, d_cyc, d_sink);
+        run_record<5>("f32 record 5 lines (ids + tails), 6 GB", d, 10000000ull, 640, 5, d_cyc, d_sink);
+        return 0;
+    }
     const uint64_t n_rows = 10000000ull;
     const size_t bytes = n_rows * 512ull + 4096;
     uint8_t* d = nullptr;
