@@ -747,9 +747,9 @@ static search_fn pick_kernel(int dtype, uint32_t ef) {
 // hold max_search of them plus a few spare places: two distances of a walk tie surprisingly often (4000
 // candidates share 2^23 float values), and a tie between entry max_search-1 and an entry pushed off the
 // end hands the walk over -- with spare places that takes a run of ties.
-constexpr uint32_t FAST_MAX_SEARCH = 4096; // f32 rows of 100 / 200 dims and int8 rows of 128 bytes: lists of up to 65 x 64 keys
+constexpr uint32_t FAST_MAX_SEARCH = 8192; // f32 rows of 100 / 200 dims and int8 rows of 128 bytes: two-level lists of up to 129 x 64 keys
 static uint32_t fast_list_slots(uint32_t ef) {
-    return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : ef <= 1024 ? 17u : ef <= 2048 ? 33u : 65u;
+    return ef <= 60 ? 1u : ef <= 124 ? 2u : ef <= 252 ? 4u : ef <= 508 ? 8u : ef <= 1024 ? 17u : ef <= 2048 ? 33u : ef <= 4096 ? 65u : 129u;
 }
 // v16: the form of the visited set (FastWalker's V16): 0 = the exact 32-bit table, 3 = none, 4 = none + rows touched ahead
 template <int DT, int DIM, int S>
@@ -777,6 +777,7 @@ static search_fn pick_fast_s(uint32_t S, bool trail, int v16) {
             // such a search there whatever the option says (an exact set of ~40 x max_search ids fits no LDS)
             if (S == 33) return fast_kernel<DT, DIM, 33, false, 3>;
             if (S == 65) return fast_kernel<DT, DIM, 65, false, 3>;
+            if (S == 129) return fast_kernel<DT, DIM, 129, false, 3>;
             return v16 >= 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
         }
     }

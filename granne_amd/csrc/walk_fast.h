@@ -113,28 +113,9 @@ struct WalkList : SortedList<S> {
     using SortedList<S>::key;
     static constexpr uint32_t CAP = 64u * S;
 
-    // Lists of 33 / 65 slots (LONG): everything before `fu_lb` is expanded -- a lower bound of the first unexpanded entry's
-    // position, kept across expansions (mark_expanded never breaks it; a merge lowers it to the smallest place a
-    // candidate took) -- so the search reads the mirror from there, 64 keys at a time, instead of asking every slot.
-    static constexpr bool LONG = S >= 33;
-    mutable uint32_t fu_lb;
+    static constexpr bool LONG = S >= 33; // lists beyond 1024 keys live in LDS only (FastWalker::search_layer_long): `key` stays unused
     // position of the first entry whose expanded flag is clear (KEY_INF has it set)
     __device__ __forceinline__ bool first_unexpanded(uint32_t& pos) const {
-        if constexpr (LONG) {
-            const uint32_t lane = threadIdx.x;
-            for (;;) {
-                if (fu_lb >= CAP) return false;
-                const uint32_t e = fu_lb + lane;
-                const uint64_t v = mir[e < CAP ? e : CAP - 1u];
-                const uint64_t um = wave_ballot(e < CAP && (((uint32_t)v) & 1u) == 0u);
-                if (um) {
-                    fu_lb += (uint32_t)__builtin_ctzll(um);
-                    pos = fu_lb;
-                    return true;
-                }
-                fu_lb += 64u;
-            }
-        }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint64_t um = wave_ballot((((uint32_t)key[s]) & 1u) == 0u);
@@ -189,17 +170,21 @@ struct WalkList : SortedList<S> {
     }
     __device__ __forceinline__ void init_list(uint64_t* mirror, uint32_t lane) {
         mir = mirror;
-        fu_lb = 0;
+        if constexpr (LONG) {
+#pragma unroll 1
+            for (uint32_t s = 0; s < (uint32_t)S; ++s) mir[s * 64u + lane] = KEY_INF;
+        } else {
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            key[s] = KEY_INF;
-            mir[(uint32_t)s * 64u + lane] = KEY_INF; // the image holds the list from the start
+            for (int s = 0; s < S; ++s) {
+                key[s] = KEY_INF;
+                mir[(uint32_t)s * 64u + lane] = KEY_INF; // the image holds the list from the start
+            }
         }
     }
     // the first entry of an empty list
     __device__ __forceinline__ void set_first(uint64_t k0, uint32_t lane) {
         if (lane == 0) {
-            key[0] = k0;
+            if constexpr (!LONG) key[0] = k0;
             mir[0] = k0;
         }
     }
@@ -318,6 +303,12 @@ struct FastWalker {
         lds_q = smem;
         mslot = reinterpret_cast<uint64_t*>(smem + qb);
         vcache = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u);
+        fimg = reinterpret_cast<uint64_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u); // (lists beyond 1024 keys have F's image where the shorter ones have their cache of entered ids)
+        fkey = KEY_INF;
+        nF = nM = 0;
+        m_un = 0;
+        m_un_key = KEY_INF;
+        lost_bits = 0xFFFFFFFFu;
         vis_tab = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u + (LONG_LIST ? 0u : VCACHE_SLOTS * 4u));
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
@@ -532,84 +523,225 @@ struct FastWalker {
         return d;
     }
 
-    // ---- lists of 33 / 65 slots (max_search 1025..4096) -----------------------------------------------------------------
-    // The bulk merge above costs (slots x candidates): every entry is compared with every candidate, every candidate is
-    // looked up in every slot. Long lists rank a candidate by a binary search in the list's LDS mirror instead (which holds
-    // the list exactly): the number of entries below its key -- and the entry it stops at is the candidate's own node
-    // when the list holds it already (same distance, same id: the same key up to the expanded flag), so the look-up of
-    // drop_known falls out of the same search. Entries then move up by the number of candidates whose rank is at most their
-    // position: uniform per slot (a running count) except in the few slots a candidate's rank falls into.
+    // ---- lists of 33 / 65 / 129 slots (max_search 1025 .. 8192): the TWO-LEVEL list ---------------------------------------
+    // Round 4 kept one sorted array of 64 S keys (registers + an LDS image) and merged every expansion's candidates into
+    // it: O(S) per expansion with a large constant (13.7 k of 25.4 k clocks per expansion at max_search 4096,
+    // profiles/r6_phase_f32_ef4096_before.txt). Now (tools/model_twolevel.py replays this against the reference's two heaps):
+    //   M  the main sorted array, CAP keys, in LDS ONLY (no register copy: 2 S registers free);
+    //   F  the "fresh" list: up to 63 keys, sorted, ONE register pair per lane (+ a 96-key image in LDS for its scatter) --
+    //      an expansion's candidates enter here, by the one-slot ranked merge of the short lists;
+    //   the logical list is M u F: keys are unique across both (a candidate is looked up in both before it enters).
+    //   theta = distance of the union's entry max_search-1: one merge-path split of the two sorted arrays, the 64 lanes
+    //           trying the 64 possible splits at once (update_theta);
+    //   next  = the smaller of the two first unexpanded entries, flagged where it stands;
+    //   break <=> theta < d_next  (#{entries with dist < d_x} >= max_search  <=>  entry max_search-1 is strictly closer);
+    //   flush : when F cannot take an expansion's candidates it is merged into M -- the O(S) step, now once per several
+    //           expansions: every F entry's rank in M by binary search (all lanes at once), M's windows of 64 moved up IN
+    //           PLACE from the top down (a window's shift is uniform except where an F entry's rank falls into it), F's
+    //           entries written last. What falls off M's end is dead unless the closest of it ties with theta after the
+    //           expansion's inserts: then the walk is handed to the exact walker, as with the short lists.
     static constexpr bool LONG = WalkList<S>::LONG;
-    static constexpr int LONG_STEPS = CAP >= 4096u ? 13 : 12; // lower_bound over CAP + 1 outcomes: 2112 -> 12, 4160 -> 13
+    static constexpr int LONG_STEPS = CAP >= 8192u ? 14 : CAP >= 4096u ? 13 : 12; // lower_bound over CAP + 1 outcomes: 2112 -> 12, 4160 -> 13, 8256 -> 14
+    static constexpr uint32_t FCAP = 63u;       // keys F may hold (a split of the union takes 0..63 of them: one per lane)
+    static constexpr uint32_t FIMG_KEYS = 128u; // F's image: 64 entries + up to 32 candidates, padded
+    uint64_t* fimg;     // LONG: F's image (behind M's)
+    uint64_t fkey;      // LONG: lane j holds F[j] (KEY_INF beyond nF)
+    uint32_t nF, nM;    // LONG: real entries of F and of M
+    uint32_t m_un;      // LONG: position of M's first unexpanded entry (CAP: none)
+    uint64_t m_un_key;  // LONG: its key (KEY_INF: none)
+    uint32_t lost_bits; // LONG: smallest distance bits among what flushes pushed off M's end since the last tie test
 
-    // Which candidates remain (the list holds some already; a row may name a node twice), and each one's rank in the list.
-    __device__ __forceinline__ uint64_t rank_long(bool& pass, uint64_t ck, uint32_t& rank) const {
+    // number of M's entries below k (k differs per lane; every lane runs the same steps)
+    __device__ __forceinline__ uint32_t m_lower_bound(uint64_t k) const {
         uint32_t lo = 0, hi = CAP;
 #pragma unroll 1
         for (int t = 0; t < LONG_STEPS; ++t) {
             const uint32_t mid = (lo + hi) >> 1;
             const uint64_t v = mslot[mid < CAP ? mid : CAP - 1u];
-            const bool go = lo < hi, less = v < ck;
+            const bool go = lo < hi, less = v < k;
             lo = (go && less) ? mid + 1u : lo;
             hi = (go && !less) ? mid : hi;
         }
-        rank = lo;
-        const uint64_t at = mslot[lo < CAP ? lo : CAP - 1u];
-        pass = pass && !(lo < CAP && (at | 1ull) == (ck | 1ull)); // in the list already, expanded or not
-        uint64_t pm = wave_ballot(pass);
-        for (uint64_t it = pm; it; it &= it - 1) { // the second of two lanes with one key leaves
-            const uint32_t j = (uint32_t)__builtin_ctzll(it);
-            const uint64_t K = readlane64(ck, j);
-            const uint64_t twin = wave_ballot(pass && ck == K && lane > j);
-            if (twin) {
-                pass = pass && !((twin >> lane) & 1ull);
-                pm &= ~twin;
+        return lo;
+    }
+    // M's first unexpanded entry at or after `from`
+    __device__ __forceinline__ void m_scan_unexpanded(uint32_t from) {
+        for (;;) {
+            if (from >= nM) {
+                m_un = CAP;
+                m_un_key = KEY_INF;
+                return;
+            }
+            const uint32_t e = from + lane;
+            const uint64_t v = mslot[e < CAP ? e : CAP - 1u];
+            const uint64_t um = wave_ballot(e < nM && (((uint32_t)v) & 1u) == 0u);
+            if (um) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(um);
+                m_un = from + l;
+                m_un_key = readlane64(v, l);
+                return;
+            }
+            from += 64u;
+        }
+    }
+    // position of M's n-th (n >= 1) expanded entry, WPOS_NONE when there are fewer (the tie path of the filter)
+    __device__ __forceinline__ uint32_t m_nth_expanded(uint32_t n) const {
+        uint32_t before = 0;
+        for (uint32_t w0 = 0; w0 < nM; w0 += 64u) {
+            const uint32_t e = w0 + lane;
+            const uint64_t v = mslot[e < CAP ? e : CAP - 1u];
+            const bool f = e < nM && (((uint32_t)v) & 1u) != 0u;
+            const uint64_t em = wave_ballot(f);
+            const uint32_t c = (uint32_t)__popcll(em);
+            if (before + c >= n) {
+                const uint64_t hit = wave_ballot(f && mbcnt64(em) == n - 1u - before);
+                return w0 + (uint32_t)__builtin_ctzll(hit);
+            }
+            before += c;
+        }
+        return WPOS_NONE;
+    }
+    __device__ __forceinline__ void long_init(uint32_t xkey_lo_unused) {
+        (void)xkey_lo_unused;
+        fkey = KEY_INF;
+        nF = 0;
+        lost_bits = 0xFFFFFFFFu;
+        fimg[lane] = KEY_INF;
+        fimg[64u + lane] = KEY_INF;
+    }
+    // F into M. Afterwards F is empty and the union is M.
+    __device__ __forceinline__ void flush() {
+        if (nF == 0u) return;
+        const bool live = lane < nF;
+        const uint32_t r = m_lower_bound(fkey); // F is ascending, so are the ranks; lanes beyond nF hold KEY_INF: r = nM
+        uint32_t lost = 0xFFFFFFFFu;
+        if (nM) {
+            const uint32_t w_first = readlane32(r, 0) >> 6, w_top = (nM - 1u) >> 6;
+            uint32_t a_hi = nF; // F entries whose rank lies below the end of the window in hand (all of them, at the top)
+            for (uint32_t w = w_top + 1u; w-- > w_first;) {
+                const uint32_t a_lo = (uint32_t)__popcll(wave_ballot(live && r < w * 64u));
+                const uint32_t e = w * 64u + lane;
+                const uint64_t v = mslot[e]; // (w <= S - 1: inside the image)
+                uint32_t c = a_lo;
+                for (uint32_t j = a_lo; j < a_hi; ++j) c += (e >= readlane32(r, j)) ? 1u : 0u; // F entries ranked inside this window
+                const uint32_t dest = e + c;
+                if (e < nM) {
+                    if (dest < CAP) mslot[dest] = v;
+                    else lost = min(lost, wkey_hi(v));
+                }
+                a_hi = a_lo;
+            }
+        }
+        const uint32_t dest = r + lane; // F[j] lands behind the r_j entries of M below it and the j entries of F below it
+        if (live) {
+            if (dest < CAP) mslot[dest] = fkey;
+            else lost = min(lost, wkey_hi(fkey));
+        }
+        // M's first unexpanded entry: where it stood or later, or the first unexpanded entry that came from F
+        const uint64_t fun = wave_ballot(live && (((uint32_t)fkey) & 1u) == 0u);
+        uint32_t lb = m_un < CAP ? m_un : nM;
+        if (fun) lb = min(lb, readlane32(dest, (uint32_t)__builtin_ctzll(fun)));
+        for (int o = 32; o > 0; o >>= 1) lost = min(lost, (uint32_t)__shfl_xor((int)lost, o, 64));
+        lost_bits = min(lost_bits, lost);
+        nM = min(CAP, nM + nF);
+        nF = 0;
+        fkey = KEY_INF;
+        fimg[lane] = KEY_INF;
+        asm volatile("" ::: "memory"); // one wave: LDS executes its accesses in program order
+        m_scan_unexpanded(lb);
+    }
+    // theta = distance bits of the union's entry ef-1 (0xFFFFFFFF while the union is shorter). Lane j tries the split "j keys
+    // of F and ef - j of M are the union's first ef": right iff F[j-1] < M[ef-j] and M[ef-j-1] < F[j]; keys are unique, so
+    // exactly one lane is right, and the entry wanted is the larger of F[j-1] and M[ef-j-1].
+    __device__ __forceinline__ void update_theta(uint32_t ef) {
+        if (nM + nF < ef) {
+            theta = 0xFFFFFFFFu;
+            return;
+        }
+        const uint32_t j = lane;
+        const bool in_range = j <= nF && j <= ef && ef - j <= nM;
+        const uint32_t i = in_range ? ef - j : 0u;
+        const uint64_t Mi = mslot[i < CAP ? i : CAP - 1u]; // (i <= ef <= CAP - 64; at nM and beyond: KEY_INF)
+        const uint64_t Mi1 = mslot[i ? i - 1u : 0u];
+        const uint64_t Fj1 = shift_up1(fkey);
+        const bool ok = in_range && (j == 0u || Fj1 < Mi) && (i == 0u || Mi1 < fkey);
+        const uint64_t last = (j == 0u) ? Mi1 : (i == 0u) ? Fj1 : (Fj1 > Mi1 ? Fj1 : Mi1);
+        const uint64_t okm = wave_ballot(ok);
+        if (okm == 0) { // (cannot happen while the two arrays are sorted and their keys distinct: never walk on on a wrong theta)
+            bail = true;
+            return;
+        }
+        theta = readlane32(wkey_hi(last), (uint32_t)__builtin_ctzll(okm));
+    }
+    // mod.rs:1029 on the union: a candidate beyond theta is dead; one that ties with it needs res.peek() -- the ef-th
+    // EXPANDED entry: rare, and taken on M alone after a flush
+    __device__ __forceinline__ uint64_t filter_mask_long(const uint64_t candm, const uint32_t dbits, const uint32_t ef) {
+        uint64_t passm = candm & wave_ballot(dbits <= theta);
+        const uint64_t tiem = passm & wave_ballot(dbits == theta);
+        if (tiem) {
+            flush();
+            const uint32_t w = m_nth_expanded(ef);
+            if (w != WPOS_NONE) {
+                const uint64_t wk = mslot[w];
+                const uint32_t worst = (uint32_t)__builtin_amdgcn_readfirstlane((int)wkey_hi(wk));
+                passm &= ~(tiem & ~wave_ballot(dbits < worst));
+            }
+        }
+        return passm;
+    }
+    // The candidates of passm (odd lanes; ck = their keys) enter F. Before: the ones M or F holds already leave, and so does
+    // the second lane of a row that names a node twice. Returns the lanes that entered; `cmin` = the smallest entered key.
+    __device__ __forceinline__ uint64_t insert_fresh(uint64_t passm, const uint64_t ck, const bool twin_rows, uint64_t& cmin) {
+        cmin = KEY_INF;
+        if (passm == 0) return 0;
+        {   // in M already? the lower bound stops at the candidate's own node (same key up to the flag)
+            const uint32_t rm = m_lower_bound(ck);
+            const uint64_t at = mslot[rm < CAP ? rm : CAP - 1u];
+            passm &= ~wave_ballot(rm < CAP && (at | 1ull) == (ck | 1ull));
+        }
+        if (twin_rows) {
+            for (uint64_t it = passm; it; it &= it - 1) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(it);
+                const uint64_t K = readlane64(ck, j);
+                const uint64_t twin = wave_ballot(ck == K && lane > j) & it;
+                passm &= ~twin;
                 it &= ~twin;
             }
         }
-        return pm;
-    }
-
-    // pq.push of the candidates in pm (pass: this lane is one of them), ranks from rank_long.
-    __device__ __forceinline__ void place_long(uint64_t pm, bool pass, uint64_t ck, uint32_t rank, uint32_t ef) {
-        const uint32_t m = (uint32_t)__popcll(pm);
-        if (m == 0) return;
-        uint32_t mypos = rank; // + the candidates below mine
-        for (uint64_t it = pm; it; it &= it - 1) {
-            const uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(it));
-            mypos += (pass && K < ck) ? 1u : 0u;
+        const uint32_t* fimg_lo = reinterpret_cast<const uint32_t*>(fimg);
+        const uint32_t me = (uint32_t)ck | 1u;
+        uint32_t shift, rankv, below;
+        for (;;) {
+            if (passm == 0) return 0;
+            shift = 0;
+            rankv = 0;
+            below = 0;
+            for (uint64_t it = passm; it; it &= it - 1) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(it);
+                const uint64_t K = readlane64(ck, j);
+                const bool g = fkey > K;
+                shift += g ? 1u : 0u;
+                const uint32_t above = (uint32_t)__popcll(wave_ballot(g));
+                rankv = (lane == j) ? 64u - above : rankv; // F's entries below K
+                below += (ck > K) ? 1u : 0u;
+            }
+            // in F already? it stands at `rank` when expanded (K|1 is the smallest key above K), at rank - 1 when not
+            const uint32_t r0 = rankv < 64u ? rankv : 63u, r1 = rankv ? rankv - 1u : 0u;
+            const uint32_t e0 = fimg_lo[2u * r0], e1 = fimg_lo[2u * r1];
+            const uint64_t known = passm & ((wave_ballot((e0 | 1u) == me) & wave_ballot(rankv < 64u)) | wave_ballot((e1 | 1u) == me));
+            if (known == 0) break;
+            passm &= ~known;
         }
-        const uint32_t rslot = pass ? (rank >> 6) : 0xFFFFFFFFu, rlane = rank & 63u;
-        uint32_t base = 0;               // candidates whose rank lies in an earlier slot
-        uint32_t lost = 0xFFFFFFFFu;     // smallest distance bits among what falls off the end
-        uint32_t first_moved = S;        // slots before it keep their keys (no candidate below any of their entries)
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const uint64_t in = wave_ballot(rslot == (uint32_t)s);
-            if (base == 0u && in == 0ull) continue; // nothing has been inserted below this slot's entries
-            if (first_moved == (uint32_t)S) first_moved = (uint32_t)s;
-            uint32_t shift = base;
-            for (uint64_t it = in; it; it &= it - 1) shift += (lane >= readlane32(rlane, (uint32_t)__builtin_ctzll(it))) ? 1u : 0u;
-            base += (uint32_t)__popcll(in);
-            const uint32_t newpos = (uint32_t)s * 64u + lane + shift;
-            const uint64_t mine = L.key[s];
-            if (newpos < CAP) mslot[newpos] = mine;
-            else lost = min(lost, wkey_hi(mine));
-        }
-        if (pass && mypos < CAP) mslot[mypos] = ck;
-        if (pass && mypos >= CAP) lost = min(lost, wkey_hi(ck));
-        asm volatile("" ::: "memory"); // one wave: LDS executes its accesses in program order
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-            if ((uint32_t)s >= first_moved) L.key[s] = mslot[(uint32_t)s * 64u + lane];
+        const bool mine = __builtin_amdgcn_inverse_ballot_w64(passm);
+        fimg[lane + shift] = fkey;
+        if (mine) fimg[rankv + below] = ck;
         asm volatile("" ::: "memory");
-        // the first unexpanded entry may now be one of the candidates
-        const uint32_t myp = pass ? mypos : 0xFFFFFFFFu;
-        uint32_t minpos = myp;
-        for (int o = 32; o > 0; o >>= 1) minpos = min(minpos, (uint32_t)__shfl_xor((int)minpos, o, 64));
-        L.fu_lb = min(L.fu_lb, minpos);
-        theta = wkey_hi(L.at(ef - 1));
-        if (wave_ballot(lost != 0xFFFFFFFFu && lost == theta && theta != 0xFFFFFFFFu)) bail = true;
+        fkey = fimg[lane];
+        asm volatile("" ::: "memory");
+        nF += (uint32_t)__popcll(passm);
+        const uint64_t firstm = passm & wave_ballot(below == 0u);
+        cmin = readlane64(ck, (uint32_t)__builtin_ctzll(firstm));
+        return passm;
     }
 
     // ---- lists of up to 17 slots: every candidate of an expansion ranked at once, ONE pass through the LDS image -----------
@@ -801,107 +933,131 @@ struct FastWalker {
         return __builtin_amdgcn_inverse_ballot_w64(filter_mask(wave_ballot(cand), __float_as_uint(d), ef));
     }
 
-    // The same walk for the lists of 33 / 65 slots (max_search 1025..4096): the pop searches the image from a cached lower
-    // bound, the candidates are ranked by binary search (rank_long) and placed by place_long. One iteration = one
-    // expansion: pop, adjacency row, row loads, distances, filter, merge; the adjacency row of the list's first unexpanded
-    // entry y is fetched during the expansion before it, and a candidate that sorts before y (then it is expanded next) has
-    // its row requested before the merge.
+    // The walk on the two-level list. One iteration = one expansion of x (flagged when it was chosen): adjacency row, row
+    // loads, the fetch-ahead of the adjacency row of the entry that is first in line now, distances, filter, room in F (or
+    // a flush), the candidates into F, theta, who is next (a candidate that sorts before everything unexpanded has its
+    // adjacency row requested at once), break test, flag.
     __device__ __forceinline__ void search_layer_long(const LayerDev& Ly, uint32_t entrypoint, uint32_t ef, uint32_t slots,
                                                       bool d0_known, float d0_value) {
-        static_assert(!LONG || (NOVIS && !WIDE && !TOUCH), "lists of 33 / 65 slots: no visited set, 32-id layers");
+        static_assert(!LONG || (NOVIS && !WIDE && !TOUCH), "lists beyond 1024 keys: no visited set, 32-id layers");
         PT_RESET();
         L.init_list(mslot, lane);
+        long_init(0u);
         __syncthreads();
         [[maybe_unused]] const uint8_t* const adjx = XT ? Ly.adjx : nullptr; // ids + the neighbors' tails (LayerDev::adjx), or null
         const gptr_u32 adjg = (XT && adjx) ? (gptr_u32)adjx : (gptr_u32)Ly.adj;
         const uint32_t W = (XT && adjx) ? Ly.adjx_stride / 4u : 32u; // u32 from one node's ids to the next's
+        const bool twin_rows = (Ly.flags & LAYER_TWIN_ROWS) != 0u;
         uint32_t pre_id = entrypoint, pre_nb; // adjacency row fetched ahead (one id per pair) and whose it is
         pre_nb = adjg[(size_t)entrypoint * W + R]; // get_neighbors(entrypoint): needed right after
         vis.count = 1;
         st.n_dist += 1;
+        uint64_t xkey;
         if (d0_known) {
-            L.set_first(wkey(d0_value, entrypoint), lane);
+            xkey = wkey(d0_value, entrypoint) | 1ull;
         } else {
             RowRegs r0;
             issue_rows(entrypoint, r0);
             const float d0 = finish_rows(r0);
-            L.set_first(readlane64(wkey(d0, entrypoint), 1), lane);
+            xkey = readlane64(wkey(d0, entrypoint), 1) | 1ull;
         }
-        theta = wkey_hi(L.at(ef - 1));
+        L.set_first(xkey, lane); // M[0]: popped at once, flagged
+        nM = 1;
+        m_un = CAP;
+        m_un_key = KEY_INF;
+        theta = ef == 1u ? wkey_hi(xkey) : 0xFFFFFFFFu;
+        uint32_t xid = entrypoint;
 
         RowRegs rr;
         PT_WAIT_VM();
         PT_MARK(7); // layer setup: entry point distance
         for (;;) {
-            uint32_t pos;
-            if (!L.first_unexpanded(pos)) break;          // pq.pop() on an empty queue, mod.rs:1018
-            const uint64_t x = L.at(pos);
-            // mod.rs:1019-1021. Every entry before x is expanded and at most as far; #{closer} = pos - #{ties
-            // before x}, so the count is only taken when pos alone does not already decide
-            if (pos >= ef && L.count_closer(wkey_hi(x)) >= ef) break;
-            L.mark_expanded(pos, x, lane);                 // res.push((d, idx)), mod.rs:1023
             st.n_expand += 1;
-
-            // layer.get_neighbors(idx), mod.rs:1025 / 540-552: row prefix until UNUSED, one id per pair
-            const uint32_t xid = wkey_id(x);
+            // layer.get_neighbors(x), mod.rs:1025 / 540-552: row prefix until UNUSED, one id per pair
             uint32_t nb;
             if (pre_id == xid) nb = pre_nb;
             else nb = adjg[(size_t)xid * W + R];
-            PT_MARK(0); // pop, break test, mark
+            PT_MARK(0);
             PT_WAIT_VM();
             PT_MARK(8); // wait for the adjacency row
             PT_COUNT();
             const uint64_t unused = wave_ballot(nb == ID_EMPTY);
             const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
             st.n_adj += nvalid;
-            {   // lanes beyond the row re-read its last neighbor (an empty row: the node itself)
-                const uint32_t last_id = nvalid ? readlane32(nb, 2u * (nvalid - 1u)) : xid;
+            {   // pairs beyond the row re-read its first neighbor (an empty row: the node itself)
+                uint32_t fill = readlane32(nb, 0);
+                fill = fill != ID_EMPTY ? fill : xid;
                 const uint8_t* tails = nullptr;
                 if constexpr (XT) {
-                    if (adjx) tails = adjx + (size_t)xid * Ly.adjx_stride + 128u + ((R < nvalid) ? R : 0u) * XTAILB;
+                    if (adjx) tails = adjx + (size_t)xid * Ly.adjx_stride + 128u + (nb != ID_EMPTY ? R : 0u) * XTAILB;
                 }
-                issue_rows((R < nvalid) ? nb : last_id, rr, tails);
+                issue_rows(nb != ID_EMPTY ? nb : fill, rr, tails);
             }
-            // fetch ahead the row of the node that is first in line now; always one load: static wait counts
-            uint32_t ypos = 0;
-            const bool has_y = L.first_unexpanded(ypos);
-            const uint64_t ykey = has_y ? L.at(ypos) : KEY_INF;
-            pre_id = has_y ? wkey_id(ykey) : xid;
+            // fetch ahead the adjacency row of the entry that is first in line now; always one load: static wait counts
+            uint64_t ypre;
+            {
+                const uint64_t fun = wave_ballot((((uint32_t)fkey) & 1u) == 0u); // (KEY_INF carries the flag)
+                const uint64_t yF = fun ? readlane64(fkey, (uint32_t)__builtin_ctzll(fun)) : KEY_INF;
+                ypre = yF < m_un_key ? yF : m_un_key;
+            }
+            pre_id = ypre != KEY_INF ? wkey_id(ypre) : xid;
             pre_nb = adjg[(size_t)pre_id * W + R];
+            asm volatile("" ::: "memory");
             PT_MARK(1); // row loads and the fetch-ahead issued
-            const bool fresh = h == 0u && R < nvalid; // every neighbor is evaluated
+            const uint64_t fm = 0x5555555555555555ull & ~unused; // every neighbor is evaluated (valid ids come first)
             PT_MARK(2);
             PT_WAIT_VM();
             PT_MARK(3); // what is left of the wait for the rows
             const float d = finish_rows(rr);
-            const uint64_t fm = wave_ballot(fresh);
             st.n_dist += (uint32_t)__popcll(fm);
             PT_PIN(d);
             PT_MARK(4); // distances
-            const bool cand = ((fm << 1) >> lane) & 1ull; // odd lanes whose even partner holds an id
-            bool pass = filter(cand, d, ef);
-            const uint64_t ck = wkey(d, nb);
-            uint32_t lrank = 0;
-            const uint64_t pm = rank_long(pass, ck, lrank); // rank by binary search; known candidates leave in the same search
-            // a candidate that sorts before y is expanded next (the smallest such): request its adjacency row now
-            // (not with 800-byte rows: the walk is bandwidth-bound there and the kernel sits at its register limit)
-            uint64_t beat = (F32 && DIM > 128) ? 0ull : wave_ballot(pass && ck < ykey); // ykey = KEY_INF without y: every passing candidate
-            if (beat) {
-                uint64_t K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
-                for (;;) { // usually one or two rounds
-                    beat = wave_ballot(pass && ck < K);
-                    if (!beat) break;
-                    K = readlane64(ck, (uint32_t)__builtin_ctzll(beat));
+            const uint32_t dbits = __float_as_uint(d);
+            uint64_t passm = filter_mask_long(fm << 1, dbits, ef); // odd lanes whose even partner holds an id
+            if (nF + (uint32_t)__popcll(passm) > FCAP) flush(); // F must take them all: BEFORE they are ranked against M
+            PT_MARK(10); // filter (and a flush)
+            const uint64_t ck = ((uint64_t)dbits << 32) | (nb << 1);
+            uint64_t cmin;
+            passm = insert_fresh(passm, ck, twin_rows, cmin);           // pq.push, mod.rs:1029-1031
+            PT_MARK(11); // look-ups, ranks, the candidates into F
+            if (passm) {
+                if (cmin < ypre) { // it is expanded next: its adjacency row is wanted
+                    pre_id = wkey_id(cmin);
+                    uint32_t pv = pre_id;
+                    asm("" : "+v"(pv));
+                    pre_nb = adjg[(size_t)pv * W + R];
                 }
-                pre_id = wkey_id(K);
-                pre_nb = adjg[(size_t)pre_id * W + R];
+                update_theta(ef);
             }
-            PT_MARK(5); // filter, next-node decision, its adjacency request
-            place_long(pm, pass, ck, lrank, ef);           // pq.push, mod.rs:1029-1031
-            PT_MARK(6); // merge
-            PT_MARK(9);
+            if (lost_bits != 0xFFFFFFFFu) { // what a flush pushed off M's end: dead unless the closest of it ties with theta
+                if (lost_bits == theta) bail = true;
+                lost_bits = 0xFFFFFFFFu;
+            }
+            PT_MARK(5); // theta, the next node's adjacency request
             if (bail) return;
+            // who is next: the smaller of the two first unexpanded entries (pq.pop(), mod.rs:1018)
+            const uint64_t fun = wave_ballot((((uint32_t)fkey) & 1u) == 0u);
+            const uint32_t pF = fun ? (uint32_t)__builtin_ctzll(fun) : 0u;
+            const uint64_t yF = fun ? readlane64(fkey, pF) : KEY_INF;
+            const bool fromF = yF < m_un_key;
+            const uint64_t y = fromF ? yF : m_un_key;
+            if (y == KEY_INF) break;                 // the queue is empty
+            if (theta < wkey_hi(y)) break;           // mod.rs:1019-1021: max_search entries are strictly closer
+            if (fromF) {                             // res.push((d, idx)), mod.rs:1023
+                if (lane == pF) {
+                    fkey |= 1ull;
+                    fimg[pF] = fkey;
+                }
+            } else {
+                if (lane == 0) mslot[m_un] = y | 1ull;
+                asm volatile("" ::: "memory");
+                m_scan_unexpanded(m_un + 1u);
+            }
+            xid = wkey_id(y);
+            PT_MARK(6); // pop, break test, flag
+            PT_MARK(9);
         }
+        flush(); // the layer's result is read from M
     }
 
     // search_for_neighbors (mod.rs:999-1037) on one layer; the result is the list's expanded entries.
@@ -1167,6 +1323,26 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
             return;
         }
         // res = the first max_search expanded entries; .take(num_neighbors), mod.rs:974-977
+        uint32_t count;
+        const QueryIO io = query_io(p, qi);
+        if constexpr (FastWalker<DT, DIM, S, V16, WIDE>::LONG) { // the list is M (flushed at the layer's end), in LDS
+            const uint32_t want = min(p.ef, p.k);
+            uint32_t total = 0;
+            const uint32_t nm = p.n_layers > 0 ? w.nM : 0u;
+            for (uint32_t w0 = 0; w0 < nm && total < want; w0 += 64u) {
+                const uint32_t e = w0 + lane;
+                const uint64_t v = w.mslot[e < w.CAP ? e : w.CAP - 1u];
+                const bool f = e < nm && (((uint32_t)v) & 1u) != 0u;
+                const uint64_t em = wave_ballot(f);
+                const uint32_t r = total + mbcnt64(em);
+                if (f && r < want) {
+                    io.ids[r] = (uint64_t)wkey_id(v);
+                    io.dists[r] = wkey_dist(v);
+                }
+                total += (uint32_t)__popcll(em);
+            }
+            count = min(total, want);
+        } else {
         uint32_t total = 0;
         uint32_t rank[S];
         bool flag[S];
@@ -1182,14 +1358,14 @@ __device__ __forceinline__ void fast_walk_one(const SearchParams& p, const uint3
 #pragma unroll
             for (int s = 0; s < S; ++s) { flag[s] = false; rank[s] = 0; }
         }
-        const uint32_t count = min(min(total, p.ef), p.k);
-        const QueryIO io = query_io(p, qi);
+        count = min(min(total, p.ef), p.k);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             if (flag[s] && rank[s] < count) {
                 io.ids[rank[s]] = (uint64_t)wkey_id(w.L.key[s]);
                 io.dists[rank[s]] = wkey_dist(w.L.key[s]);
             }
+        }
         }
         for (uint32_t e = count + lane; e < p.k; e += 64) {
             io.ids[e] = ~0ull;
@@ -1227,8 +1403,7 @@ constexpr int fast_waves_per_simd(int DT, int DIM, int S, bool WIDE = false) {
     // lists of 2112 / 4160 keys: 2 registers per 64 keys + the merge's bookkeeping; 17 / 33 KB of LDS mirror each. Two
     // walkers per SIMD for the 33-slot lists (256 registers: measured 137 k against 97 k queries/s at max_search 1600 when the
     // allocation crept to 259), one for the 65-slot ones
-    if (S >= 65) return 1;
-    if (S >= 33) return 2;
+    if (S >= 33) return 2; // the two-level lists (M in LDS only): 17 / 33 / 66 KB of LDS each bound the walkers per CU before the registers do
     if (DT == DT_I8 && DIM >= 256) return DIM == 256 ? 3 : 2; // 2 / 4 blocks of row data and of query per lane
     if (DT == DT_I8) return S == 1 ? 5 : S <= 4 ? 4 : S == 8 ? 3 : 2;
     if (DIM == 0) return 2; // the streamed walker keeps a group of chunks, the tail and the accumulators: ~210 VGPRs
@@ -1251,7 +1426,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S, WIDE)) void fas
 
 __host__ __device__ inline uint32_t fast_lds_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {
     // [query][the list's image][lists of up to 17 slots: the cache of entered ids][visited]
-    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (64u * S + (S >= 33u ? 0u : 32u)) * 8u + (S >= 33u ? 0u : VCACHE_SLOTS * 4u) + visited_slots * 4u;
+    // (lists beyond 1024 keys: M's image, then F's of 128 keys)
+    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (64u * S + (S >= 33u ? 0u : 32u)) * 8u + (S >= 33u ? 128u * 8u : VCACHE_SLOTS * 4u) + visited_slots * 4u;
 }
 
 } // namespace granne_hip

@@ -51,9 +51,9 @@ def assert_same(oracle_index, gpu_index, queries, max_search, k, check_stats=Tru
             assert ds[i, :c].tobytes() == od[i, :c].tobytes(), (m, i, ds[i, :c], od[i, :c])
             assert (ids[i, c:] == np.iinfo(np.uint64).max).all() and np.isinf(ds[i, c:]).all()
         if check_stats:
-            # (lists of 33 / 65 slots -- max_search 1025..4096 -- keep no visited set whatever the option asks for)
+            # (the two-level lists -- max_search 1025..8192 -- keep no visited set whatever the option asks for)
             # (and has_exact_set=False: graphs of 64-id layers, walked without a set whatever the option asks for)
-            assert_counters(st, octr, exact=(m in (1, 2, 3) and not 1024 < max_search <= 4096 and has_exact_set))
+            assert_counters(st, octr, exact=(m in (1, 2, 3) and not 1024 < max_search <= 8192 and has_exact_set))
     return ids, ds, cnt
 
 
@@ -392,13 +392,13 @@ def test_slow_path_equals_fast_path(ga, oracle):
 
 
 @pytest.mark.parametrize("int8", [False, True])
-@pytest.mark.parametrize("ms", [61, 64, 125, 128, 253, 300, 512, 1000, 1024, 1025, 1500, 2048, 2049, 3000, 4096])
+@pytest.mark.parametrize("ms", [61, 64, 125, 128, 253, 300, 512, 1000, 1024, 1025, 1500, 2048, 2049, 3000, 4096, 4097, 6000, 8192])
 def test_large_max_search_stays_on_the_register_walker(ga, oracle, int8, ms):
-    """The reference takes any max_search (src/index/mod.rs:1006-1010). Up to 4096 the walk stays in
-    registers/LDS (lists of 64..4160 keys); only distance ties at the list's end may hand a walk over.
-    The long lists (33 / 65 slots: max_search beyond 1024) are walked on 9000 points, more than their lists hold."""
+    """The reference takes any max_search (src/index/mod.rs:1006-1010). Up to 8192 the walk stays in
+    registers/LDS (lists of 64..8256 keys); only distance ties at the list's end may hand a walk over.
+    The two-level lists (max_search beyond 1024: M in LDS, F in registers) are walked on more points than their lists hold."""
     rng = np.random.default_rng(1000 + ms)
-    el = prep(oracle, random_floats(rng, 4000 if ms <= 1024 else 9000, 100), int8)
+    el = prep(oracle, random_floats(rng, 4000 if ms <= 1024 else 9000 if ms <= 4096 else 14000, 100), int8)
     oix = oracle.build_index(el, num_neighbors=30, max_search=40, n_threads=4)
     gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
     q = prep(oracle, random_floats(rng, 48 if ms <= 1024 else 24, 100), int8)
@@ -447,10 +447,10 @@ def test_long_lists_on_200d_rows_and_with_an_exact_set_requested(ga, oracle):
 
 
 def test_max_search_beyond_the_register_lists(ga, oracle):
-    """max_search above 4096 (above 1024 for wide int8 rows and streamed f32 dims) is the exact global-memory
+    """max_search above 8192 (above 1024 for wide int8 rows and streamed f32 dims) is the exact global-memory
     walker's as a whole batch -- its own launch, one block per query up to 32 x OPT_SLOW_BLOCKS. Same results."""
     rng = np.random.default_rng(41)
-    for int8, dim, ms in [(False, 100, 4500), (True, 100, 4097), (True, 200, 1100), (False, 50, 1025)]:
+    for int8, dim, ms in [(False, 100, 8500), (True, 100, 8193), (True, 200, 1100), (False, 50, 1025)]:
         el = prep(oracle, random_floats(rng, 5000, dim), int8)
         oix = oracle.build_index(el, num_neighbors=20, max_search=20, n_threads=4)
         gix = ga.Granne("angular_int" if int8 else "angular", el, oix.layers)
@@ -992,3 +992,34 @@ def test_index_bytes_are_the_index_file(ga, oracle, tmp_path):
     gix.save_index(str(p))
     blob = gix.index_bytes()
     assert blob == p.read_bytes() and blob[:6] == b"granne" and len(blob) > 1024
+
+
+@pytest.mark.parametrize("int8", [False, True])
+def test_two_level_lists_on_ties_twins_and_short_graphs(ga, oracle, int8):
+    """The two-level list of max_search beyond 1024 (walk_fast.h, search_layer_long; tools/model_twolevel.py): its flush,
+    its theta by a split of two sorted arrays, its tie path -- on data made of ties (every vector five times: distances
+    repeat, ids decide), on rows that name a neighbor twice, on a graph shorter than the list (everything is expanded, the
+    queue runs empty), with every max_search class (33 / 65 / 129 windows) and k up to max_search."""
+    rng = np.random.default_rng(4242 + int8)
+    base = prep(oracle, random_floats(rng, 1800, 100), int8)
+    el = np.concatenate([base] * 5)[rng.permutation(9000)]
+    oix = oracle.build_index(el, num_neighbors=30, max_search=40, n_threads=4)
+    layers = [l.copy() for l in oix.layers]
+    bottom = layers[-1]
+    for i in range(0, len(bottom), 7):  # rows that name their first neighbor twice
+        row = bottom[i]
+        nv = int((row != 0xFFFFFFFF).sum())
+        if nv >= 3:
+            row[nv - 1] = row[0]
+    oix2 = oracle.Index(el, layers)
+    gix = ga.Granne("angular_int" if int8 else "angular", el, layers)
+    q = np.concatenate([prep(oracle, random_floats(rng, 12, 100), int8), el[:4]])
+    for ms in (1100, 2048, 2500, 4096, 5000):
+        assert_same(oix2, gix, q, ms, 10, check_stats=True)
+    assert_same(oix2, gix, q[:6], 3000, 3000)
+    # a graph shorter than the list: 700 points, max_search 1500
+    small = prep(oracle, random_floats(rng, 700, 100), int8)
+    o3 = oracle.build_index(small, num_neighbors=30, max_search=40, n_threads=4)
+    g3 = ga.Granne("angular_int" if int8 else "angular", small, o3.layers)
+    assert_same(o3, g3, q[:12], 1500, 700)
+    assert_same(o3, g3, q[:12], 8000, 10)
