@@ -302,14 +302,15 @@ struct FastWalker {
         g_tu = ((p.dim & 31u) + 3u) / 4u;
         lds_q = smem;
         mslot = reinterpret_cast<uint64_t*>(smem + qb);
-        vcache = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u);
-        fimg = reinterpret_cast<uint64_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u); // (lists beyond 1024 keys have F's image where the shorter ones have their cache of entered ids)
+        // [query][the list's image (lists beyond 1024 keys: M)][those lists: F's image][the cache of entered ids][visited]
+        fimg = reinterpret_cast<uint64_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u);
+        vcache = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u + (LONG_LIST ? FIMG_KEYS * 8u : 0u));
         fkey = KEY_INF;
         nF = nM = 0;
         m_un = 0;
         m_un_key = KEY_INF;
         lost_bits = 0xFFFFFFFFu;
-        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u + (LONG_LIST ? 0u : VCACHE_SLOTS * 4u));
+        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u + (LONG_LIST ? FIMG_KEYS * 8u : 0u) + VCACHE_SLOTS * 4u);
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
         sy = 0.0f;
@@ -541,7 +542,7 @@ struct FastWalker {
     //           entries written last. What falls off M's end is dead unless the closest of it ties with theta after the
     //           expansion's inserts: then the walk is handed to the exact walker, as with the short lists.
     static constexpr bool LONG = WalkList<S>::LONG;
-    static constexpr int LONG_STEPS = CAP >= 8192u ? 14 : CAP >= 4096u ? 13 : 12; // lower_bound over CAP + 1 outcomes: 2112 -> 12, 4160 -> 13, 8256 -> 14
+    static constexpr int LONG_STEPS = CAP >= 4096u ? 7 : 6; // steps of the 4-ary lower bound over CAP + 1 outcomes (worst case, by simulation: 2112 -> 6, 4160 / 8256 -> 7)
     static constexpr uint32_t FCAP = 63u;       // keys F may hold (a split of the union takes 0..63 of them: one per lane)
     static constexpr uint32_t FIMG_KEYS = 128u; // F's image: 64 entries + up to 32 candidates, padded
     uint64_t* fimg;     // LONG: F's image (behind M's)
@@ -551,16 +552,20 @@ struct FastWalker {
     uint64_t m_un_key;  // LONG: its key (KEY_INF: none)
     uint32_t lost_bits; // LONG: smallest distance bits among what flushes pushed off M's end since the last tie test
 
-    // number of M's entries below k (k differs per lane; every lane runs the same steps)
+    // number of M's entries below k (k differs per lane; every lane runs the same steps). A dependent LDS read is ~64
+    // clocks + the compare: three pivots per step (their reads in flight together) halve the steps of a binary search.
     __device__ __forceinline__ uint32_t m_lower_bound(uint64_t k) const {
         uint32_t lo = 0, hi = CAP;
 #pragma unroll 1
         for (int t = 0; t < LONG_STEPS; ++t) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const uint64_t v = mslot[mid < CAP ? mid : CAP - 1u];
-            const bool go = lo < hi, less = v < k;
-            lo = (go && less) ? mid + 1u : lo;
-            hi = (go && !less) ? mid : hi;
+            const uint32_t len = hi - lo, last = hi ? hi - 1u : 0u;
+            const uint32_t p1 = min(last, lo + (len >> 2)), p2 = min(last, lo + (len >> 1)), p3 = min(last, lo + ((3u * len) >> 2));
+            const uint64_t v1 = mslot[p1], v2 = mslot[p2], v3 = mslot[p3];
+            const bool go = lo < hi, l1 = v1 < k, l2 = v2 < k, l3 = v3 < k; // (ascending: l3 implies l2 implies l1)
+            const uint32_t nlo = l3 ? p3 + 1u : l2 ? p2 + 1u : l1 ? p1 + 1u : lo;
+            const uint32_t nhi = l3 ? hi : l2 ? p3 : l1 ? p2 : p1;
+            lo = go ? nlo : lo;
+            hi = go ? nhi : hi;
         }
         return lo;
     }
@@ -613,15 +618,18 @@ struct FastWalker {
     __device__ __forceinline__ void flush() {
         if (nF == 0u) return;
         const bool live = lane < nF;
-        const uint32_t r = m_lower_bound(fkey); // F is ascending, so are the ranks; lanes beyond nF hold KEY_INF: r = nM
+        uint32_t r = CAP; // F is ascending, so are the ranks
+        if (live) r = m_lower_bound(fkey);
         uint32_t lost = 0xFFFFFFFFu;
         if (nM) {
             const uint32_t w_first = readlane32(r, 0) >> 6, w_top = (nM - 1u) >> 6;
             uint32_t a_hi = nF; // F entries whose rank lies below the end of the window in hand (all of them, at the top)
+            uint64_t vnext = mslot[w_top * 64u + lane]; // (w <= S - 1: inside the image)
             for (uint32_t w = w_top + 1u; w-- > w_first;) {
                 const uint32_t a_lo = (uint32_t)__popcll(wave_ballot(live && r < w * 64u));
                 const uint32_t e = w * 64u + lane;
-                const uint64_t v = mslot[e]; // (w <= S - 1: inside the image)
+                const uint64_t v = vnext;
+                if (w > w_first) vnext = mslot[e - 64u]; // the window below travels while this one is placed (it lies wholly below what this one writes)
                 uint32_t c = a_lo;
                 for (uint32_t j = a_lo; j < a_hi; ++j) c += (e >= readlane32(r, j)) ? 1u : 0u; // F entries ranked inside this window
                 const uint32_t dest = e + c;
@@ -694,10 +702,15 @@ struct FastWalker {
     __device__ __forceinline__ uint64_t insert_fresh(uint64_t passm, const uint64_t ck, const bool twin_rows, uint64_t& cmin) {
         cmin = KEY_INF;
         if (passm == 0) return 0;
-        {   // in M already? the lower bound stops at the candidate's own node (same key up to the flag)
-            const uint32_t rm = m_lower_bound(ck);
-            const uint64_t at = mslot[rm < CAP ? rm : CAP - 1u];
-            passm &= ~wave_ballot(rm < CAP && (at | 1ull) == (ck | 1ull));
+        {   // in M already? the lower bound stops at the candidate's own node (same key up to the flag). Only the candidates'
+            // lanes search: a few lanes' reads of the image do not collide in the LDS banks the way 64 random ones do
+            bool in_m = false;
+            if (__builtin_amdgcn_inverse_ballot_w64(passm)) {
+                const uint32_t rm = m_lower_bound(ck);
+                const uint64_t at = mslot[rm < CAP ? rm : CAP - 1u];
+                in_m = rm < CAP && (at | 1ull) == (ck | 1ull);
+            }
+            passm &= ~wave_ballot(in_m);
         }
         if (twin_rows) {
             for (uint64_t it = passm; it; it &= it - 1) {
@@ -764,7 +777,7 @@ struct FastWalker {
     // candidate goes the exact way. Results do not depend on the cache.
     __device__ __forceinline__ static uint32_t vcache_slot(uint32_t id) { return (id ^ (id >> 9)) & (VCACHE_SLOTS - 1u); }
     __device__ __forceinline__ void vcache_reset(uint32_t first_id) {
-        if constexpr (NOVIS && !LONG_LIST) {
+        if constexpr (NOVIS) {
             uint4* t4 = reinterpret_cast<uint4*>(vcache);
             const uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
             for (uint32_t i = lane; i < VCACHE_SLOTS / 4u; i += 64) t4[i] = e;
@@ -962,6 +975,7 @@ struct FastWalker {
             xkey = readlane64(wkey(d0, entrypoint), 1) | 1ull;
         }
         L.set_first(xkey, lane); // M[0]: popped at once, flagged
+        vcache_reset(entrypoint);
         nM = 1;
         m_un = CAP;
         m_un_key = KEY_INF;
@@ -1002,6 +1016,7 @@ struct FastWalker {
             }
             pre_id = ypre != KEY_INF ? wkey_id(ypre) : xid;
             pre_nb = adjg[(size_t)pre_id * W + R];
+            const uint32_t cached = vcache[vcache_slot(nb)]; // what the cache of entered ids holds in this neighbor's slot
             asm volatile("" ::: "memory");
             PT_MARK(1); // row loads and the fetch-ahead issued
             const uint64_t fm = 0x5555555555555555ull & ~unused; // every neighbor is evaluated (valid ids come first)
@@ -1013,12 +1028,15 @@ struct FastWalker {
             PT_PIN(d);
             PT_MARK(4); // distances
             const uint32_t dbits = __float_as_uint(d);
-            uint64_t passm = filter_mask_long(fm << 1, dbits, ef); // odd lanes whose even partner holds an id
+            // odd lanes whose even partner holds an id; a node that entered the list before is visited (mod.rs:1026): the cache
+            // knows the recent ones -- most of the revisits -- and the look-ups in M and F find the rest
+            uint64_t passm = filter_mask_long((fm << 1) & ~wave_ballot(cached == nb), dbits, ef);
             if (nF + (uint32_t)__popcll(passm) > FCAP) flush(); // F must take them all: BEFORE they are ranked against M
             PT_MARK(10); // filter (and a flush)
             const uint64_t ck = ((uint64_t)dbits << 32) | (nb << 1);
             uint64_t cmin;
             passm = insert_fresh(passm, ck, twin_rows, cmin);           // pq.push, mod.rs:1029-1031
+            if (__builtin_amdgcn_inverse_ballot_w64(passm)) vcache[vcache_slot(nb)] = nb;
             PT_MARK(11); // look-ups, ranks, the candidates into F
             if (passm) {
                 if (cmin < ypre) { // it is expanded next: its adjacency row is wanted
@@ -1427,7 +1445,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S, WIDE)) void fas
 __host__ __device__ inline uint32_t fast_lds_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {
     // [query][the list's image][lists of up to 17 slots: the cache of entered ids][visited]
     // (lists beyond 1024 keys: M's image, then F's of 128 keys)
-    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (64u * S + (S >= 33u ? 0u : 32u)) * 8u + (S >= 33u ? 128u * 8u : VCACHE_SLOTS * 4u) + visited_slots * 4u;
+    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (64u * S + (S >= 33u ? 0u : 32u)) * 8u + (S >= 33u ? 128u * 8u : 0u) + VCACHE_SLOTS * 4u + visited_slots * 4u;
 }
 
 } // namespace granne_hip
