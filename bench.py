@@ -126,7 +126,7 @@ def parse():
                     help="WORLD_SIZE > 1: seconds the partitioned sub-record (taken after the line is printed) may take per rank")
     ap.add_argument("--force-partitioned", action="store_true", help="take the partitioned sub-record with one rank too (tests)")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--sweep-ef", default="50,100,200,400,800,1600,2048,4096", help="ef values of ef_sweep ('' = skip)")
+    ap.add_argument("--sweep-ef", default="50,100,200,400,800,1600,2048,4096,8192", help="ef values of ef_sweep ('' = skip)")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--full-line", action="store_true", help="print the full record on stdout (default: the compact line; the "
                     "full record goes to bench_extras.json and stderr)")
@@ -1461,7 +1461,7 @@ def run_partitioned(B, args):
     return out
 
 
-LINE_LIMIT = 6000  # bytes of the stdout line (the driver keeps the last 8 KB of stdout)
+LINE_LIMIT = 7000  # bytes of the stdout line (the driver keeps the last 8 KB of stdout)
 
 
 def _pick(d, keys):
@@ -1522,18 +1522,19 @@ def _compact_sub(rec):
     """A sub-record on the line: {workload, value, frac, cpu, bit_exact} and the one-batch forms; the rest is in the side file."""
     if not isinstance(rec, dict):
         return rec
-    c = {"workload": _short(rec.get("workload", ""), 110)}
-    c.update(_pick(rec, ("value", "recall_at_10", "ef_search", "slow_path_queries", "wall_s", "self_recall_at_1")))
+    c = {"workload": _short(rec.get("workload", ""), 96)}
+    c.update(_pick(rec, ("value", "recall_at_10", "ef_search", "self_recall_at_1")))
+    if rec.get("slow_path_queries"):
+        c["slow_path_queries"] = rec["slow_path_queries"]
     if isinstance(rec.get("roofline"), dict):
         c["frac"] = rec["roofline"].get("frac")
-        c["traffic_over_algorithmic"] = rec["roofline"].get("traffic_over_algorithmic")
+        if rec["roofline"].get("traffic_over_algorithmic") is not None:
+            c["traffic_over_algorithmic"] = rec["roofline"].get("traffic_over_algorithmic")
         ob = rec["roofline"].get("one_batch_per_launch") or {}
         c["frac_one_batch_per_launch"] = ob.get("frac")
-    for k in ("sequential", "one_batch_calls_in_flight", "steady"):
+    for k in ("sequential", "one_batch_calls_in_flight"):
         if isinstance(rec.get(k), dict):
             c[k] = rec[k].get("value")
-    if isinstance((rec.get("one_batch_calls_in_flight") or {}).get("depth8"), dict):
-        c["one_batch_calls_in_flight_depth8"] = rec["one_batch_calls_in_flight"]["depth8"].get("value")
     cb = rec.get("cpu_baseline")
     if isinstance(cb, dict):
         g = cb.get("gpu_matches_oracle") or {}
@@ -1553,7 +1554,7 @@ def compact_line(out, extras_path=None):
     line = _pick(out, keep)
     cfg = dict(out.get("config") or {})
     if "parallelism" in cfg:
-        cfg["parallelism"] = _short(cfg["parallelism"], 230)
+        cfg["parallelism"] = _short(cfg["parallelism"], 170)
     if "graph" in cfg:
         cfg["graph"] = _pick(cfg["graph"], ("builder", "num_neighbors", "max_search", "reinsert", "build_s", "reordered"))
     line["config"] = cfg

@@ -510,7 +510,7 @@ enum {
 };
 enum {
     GRANNE_HIP_WALKER_NONE = 0,          /* no search yet */
-    GRANNE_HIP_WALKER_REGISTER = 1,      /* walk_fast.h: layers of up to 32 ids, max_search up to 4096 (1024 for f32 dims other
+    GRANNE_HIP_WALKER_REGISTER = 1,      /* walk_fast.h: layers of up to 32 ids, max_search up to 8192 (1024 for f32 dims other
                                             than 100 / 200 and for int8 rows of 256 / 512 bytes) */
     GRANNE_HIP_WALKER_REGISTER_WIDE = 2, /* walk_fast.h, two passes per expansion: layers of up to 64 ids, max_search up to 1024 */
     GRANNE_HIP_WALKER_GENERAL = 3,       /* search_kernel.h: everything else up to max_search 256 */

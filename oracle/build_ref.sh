@@ -28,6 +28,13 @@ export CARGO_TARGET_DIR="$OUT/target"
 if ! cargo build --release --manifest-path "$HERE/ref_fixtures/Cargo.toml" ${CARGO_OFFLINE:+--offline}; then
   echo "build_ref: cargo could not build the fixture emitter (dependencies unavailable?): parity stays unpinned"; exit 0
 fi
+# the Rust side of the boundary (rust/granne-hip: GpuGranne, impl Index, ...) has only ever been checked by regular
+# expressions (tests/test_abi.py): where cargo exists, let the compiler read it
+if cargo check --manifest-path "$HERE/../rust/granne-hip/Cargo.toml" ${CARGO_OFFLINE:+--offline}; then
+  echo "build_ref: rust/granne-hip: cargo check ok"
+else
+  echo "build_ref: rust/granne-hip: cargo check FAILED (see above): the binding needs a maintainer's eye"
+fi
 rm -rf "$OUT/fixtures.tmp"
 if "$OUT/target/release/granne-ref-fixtures" "$OUT/fixtures.tmp"; then
   rm -rf "$OUT/fixtures" && mv "$OUT/fixtures.tmp" "$OUT/fixtures"

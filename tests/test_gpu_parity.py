@@ -383,11 +383,13 @@ def test_slow_path_equals_fast_path(ga, oracle):
         assert gix.last_slow_count() == 40
         assert_same(oix, gix, q, 300, 50)
         gix.set_option(_lib.OPT_FORCE_SLOW, 0)
-        assert_same(oix, gix, q, 300, 50)  # the register walker takes max_search up to 4096 (walk_fast.h)
+        assert_same(oix, gix, q, 300, 50)  # the register walker takes max_search up to 8192 (walk_fast.h)
         assert gix.last_slow_count() == 0
         assert_same(oix, gix, q, 1100, 50)
         assert gix.last_slow_count() == 0
-        assert_same(oix, gix, q, 4200, 50)  # beyond that: always the exact global-memory walker
+        assert_same(oix, gix, q, 4200, 50)
+        assert gix.last_slow_count() == 0
+        assert_same(oix, gix, q, 8300, 50)  # beyond that: always the exact global-memory walker
         assert gix.last_slow_count() == 40
 
 

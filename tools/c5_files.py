@@ -3,8 +3,8 @@
 granne_hip_index_save (granne's own index / elements formats), dropped, loaded back with granne_hip_index_load_files (mmap)
 and searched as one partitioned index (ef_search 200, batches of 4096).
 
-  python tools/r5_c5_files.py --shards 1            # the round trip of one shard: seconds, bytes, 4096 queries bit for bit
-  python tools/r5_c5_files.py --shards 8            # the whole 1B job on one GPU (265 GB of 288)
+  python tools/c5_files.py --shards 1            # the round trip of one shard: seconds, bytes, 4096 queries bit for bit
+  python tools/c5_files.py --shards 8            # the whole 1B job on one GPU (265 GB of 288)
 
 Results are compared with those of the same shard while it was the builder's in-memory index (whose equality with the CPU
 oracle bench.py's c5_shard record checks). Appends one JSON object per stage to gpurun_out/r5_c5_files.jsonl."""
