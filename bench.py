@@ -999,21 +999,32 @@ def rank0_after_the_timed_region(B, args, out, index, builder, elements, queries
         if plan["extras"] and args.dtype == "f32" and args.data == "uniform" and order is None:
             del index, builder, elements, queries
             torch.cuda.empty_cache()
-            out["c1"] = c1_record(B, args)
-            out["int8"] = sub_record(B, args, "i8", "uniform", n, dim, nq, args.ef, args.steps, args.warmup,
-                                     cpu_batches=args.cpu_batches, scaling=True)
+            def guarded(name, fn, *a, **kw):
+                """A sub-record that fails (a parity check that raises, an allocation that does not fit) says so IN the line
+                -- {"error": ...}, and on stderr -- and does not take the headline and the other sub-records with it."""
+                try:
+                    out[name] = fn(*a, **kw)
+                except Exception as e:  # noqa: BLE001
+                    import traceback
+                    log("sub-record %s FAILED: %s" % (name, traceback.format_exc()))
+                    out[name] = {"workload": name, "error": _short(repr(e), 300)}
+                    torch.cuda.empty_cache()
+
+            guarded("c1", c1_record, B, args)
+            guarded("int8", sub_record, B, args, "i8", "uniform", n, dim, nq, args.ef, args.steps, args.warmup,
+                    cpu_batches=args.cpu_batches, scaling=True)
             # the north star's bar -- >= 10x the CPU at recall@10 >= 0.95 -- on data a graph index CAN reach 0.95 on: two
             # documented generators (Bench.rows), each at the smallest max_search with recall >= 0.95, CPU beside it
-            out["secondary"] = sub_record(B, args, "f32", "latent", n, dim, nq, args.ef, args.steps, args.warmup,
-                                          cpu_batches=args.cpu_batches, find_ef=True)
-            out["secondary_mixture"] = sub_record(B, args, "f32", "mixture", n, dim, nq, args.ef, args.steps, args.warmup,
-                                                  cpu_batches=args.cpu_batches, find_ef=True)
+            guarded("secondary", sub_record, B, args, "f32", "latent", n, dim, nq, args.ef, args.steps, args.warmup,
+                    cpu_batches=args.cpu_batches, find_ef=True)
+            guarded("secondary_mixture", sub_record, B, args, "f32", "mixture", n, dim, nq, args.ef, args.steps, args.warmup,
+                    cpu_batches=args.cpu_batches, find_ef=True)
             if args.c4_elements:
-                out["c4_shard"] = sub_record(B, args, "f32", "uniform", args.c4_elements, 200, 4096, 50, 10, 3, cpu_batches=1,
-                                             recall_queries=1024)
+                guarded("c4_shard", sub_record, B, args, "f32", "uniform", args.c4_elements, 200, 4096, 50, 10, 3, cpu_batches=1,
+                        recall_queries=1024)
             if args.c5_elements:
-                out["c5_shard"] = sub_record(B, args, "i8", "uniform", args.c5_elements, 100, 4096, 200, 10, 2, cpu_batches=1,
-                                             recall_queries=1024)
+                guarded("c5_shard", sub_record, B, args, "i8", "uniform", args.c5_elements, 100, 4096, 200, 10, 2, cpu_batches=1,
+                        recall_queries=1024)
 
 
 def recall_target_record(B, args, out, oix, h_q, gt, k):
@@ -1523,6 +1534,9 @@ def _compact_sub(rec):
     if not isinstance(rec, dict):
         return rec
     c = {"workload": _short(rec.get("workload", ""), 96)}
+    if "error" in rec:
+        c["error"] = _short(rec["error"], 200)
+        return c
     c.update(_pick(rec, ("value", "recall_at_10", "ef_search", "self_recall_at_1")))
     if rec.get("slow_path_queries"):
         c["slow_path_queries"] = rec["slow_path_queries"]
@@ -1575,7 +1589,9 @@ def compact_line(out, extras_path=None):
     if isinstance(out.get("latency_nq1"), dict):
         line["latency_nq1_us"] = _pick(out["latency_nq1"], ("median", "p99"))
     c1 = out.get("c1")
-    if isinstance(c1, dict):
+    if isinstance(c1, dict) and "error" in c1:
+        line["c1"] = _pick(c1, ("workload", "error"))
+    elif isinstance(c1, dict):
         m1 = c1.get("members_1024") or {}
         line["c1"] = {"workload": _short(c1.get("workload", ""), 110), "value": m1.get("value"),
                       "cpu": (m1.get("cpu_baseline") or {}).get("value"),

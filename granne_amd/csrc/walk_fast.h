@@ -1031,15 +1031,21 @@ struct FastWalker {
             // odd lanes whose even partner holds an id; a node that entered the list before is visited (mod.rs:1026): the cache
             // knows the recent ones -- most of the revisits -- and the look-ups in M and F find the rest
             uint64_t passm = filter_mask_long((fm << 1) & ~wave_ballot(cached == nb), dbits, ef);
-            if (nF + (uint32_t)__popcll(passm) > FCAP) flush(); // F must take them all: BEFORE they are ranked against M
+            PT_ADD(6, (uint32_t)__popcll(passm));
+            if (nF + (uint32_t)__popcll(passm) > FCAP) {
+                flush(); // F must take them all: BEFORE they are ranked against M
+                PT_ADD(1, 1u); // (the diagnostics build counts flushes where the short lists count expansions without a candidate)
+            }
             PT_MARK(10); // filter (and a flush)
             const uint64_t ck = ((uint64_t)dbits << 32) | (nb << 1);
             uint64_t cmin;
             passm = insert_fresh(passm, ck, twin_rows, cmin);           // pq.push, mod.rs:1029-1031
             if (__builtin_amdgcn_inverse_ballot_w64(passm)) vcache[vcache_slot(nb)] = nb;
             PT_MARK(11); // look-ups, ranks, the candidates into F
+            PT_ADD(0, (uint32_t)__popcll(passm));
             if (passm) {
                 if (cmin < ypre) { // it is expanded next: its adjacency row is wanted
+                    PT_ADD(5, 1u);
                     pre_id = wkey_id(cmin);
                     uint32_t pv = pre_id;
                     asm("" : "+v"(pv));
