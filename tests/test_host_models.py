@@ -3,6 +3,8 @@
 * tools/model_unified.py: the walker's ONE sorted list with expanded flags and its once-per-expansion tie test
   (walk_fast.h, insert_sorted) against the reference's two heaps (src/index/mod.rs:999-1037) on tie-heavy graphs.
   The same list WITHOUT a visited set (wave_prims.h VisitedNone: candidates are looked up in the list) against the same.
+* tools/model_twolevel.py: the two-level list of max_search beyond 1024 (walk_fast.h, search_layer_long) against the two heaps,
+  and its device steps (4-ary lower bound, flush in place, theta by a split of two sorted arrays, the insert into F) lane for lane.
 * the builder's one-candidate form of add_and_limit_neighbors (builder_kernels.h, add_one_to_selected) against the
   full sort + select_neighbors pass (src/index/mod.rs:849-883, 923-959) over rows that fill, get limited, refill.
 """
@@ -170,76 +172,161 @@ def test_one_candidate_add_and_limit_equals_the_full_pass():
     assert short > 1000 and changed > 50, (short, changed)
 
 
-def test_long_list_merge_by_rank_and_prefix_shift_equals_a_sorted_merge():
-    """walk_fast.h, lists of 33 / 65 slots (rank_long / place_long): a candidate's rank is a lower_bound in the list (the
-    entry it stops at is its own node when the list holds it: same key up to the expanded flag), the second of two equal
-    candidates leaves, a candidate lands at rank + (candidates below it), an entry moves up by #{candidates with rank <=
-    its position} -- per 64-key slot a running count plus, only in the slots a rank falls into, a per-lane count -- what
-    falls off the end is reported, and the cached lower bound of the first unexpanded entry drops to the smallest place a
-    candidate took. Replayed against a plain merge of the two sorted sequences."""
-    rnd = random.Random(65)
+def test_two_level_list_walk_equals_two_heaps():
+    """walk_fast.h, max_search beyond 1024 (search_layer_long): the two-level list -- M sorted in LDS, F (up to 63 keys) in
+    registers, theta = the union's entry max_search-1, break <=> theta < d_next, flush when F cannot take an expansion's
+    candidates, the tie path of the filter after a flush, what falls off M's end dead unless it ties with theta
+    (tools/model_twolevel.py) -- against the reference's two heaps on tie-heavy graphs, twin rows included."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    spec = importlib.util.spec_from_file_location("model_twolevel", os.path.join(ROOT, "tools", "model_twolevel.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rnd = random.Random(66)
+    equal = bailed = flushed = 0
+    for it in range(700):
+        n = rnd.choice([5, 20, 80, 300, 1000])
+        deg = rnd.choice([2, 4, 8, 15, 30])
+        ef = rnd.choice([1, 2, 5, 10, 50, 100])
+        cap = max(rnd.choice([ef + 8, ef + 64, 2 * ef + 16]), ef + 1)
+        fcap = rnd.choice([max(deg, 31), 63])
+        adj = [rnd.sample(range(n), min(deg, n)) for _ in range(n)]
+        if it % 4 == 0:
+            for row in adj:
+                if len(row) >= 2 and rnd.random() < 0.3:
+                    row[-1] = row[0]
+        mode = rnd.choice(["float", "int_small", "int_tiny"])
+        dv = [rnd.random() if mode == "float" else rnd.randrange(50 if mode == "int_small" else 4) / 50.0 for _ in range(n)]
+        ep = rnd.randrange(n)
+        r0, c0 = m.reference(adj, dv.__getitem__, ep, ef)
+        r1, c1, fl = m.twolevel(adj, dv.__getitem__, ep, ef, cap, fcap)
+        flushed += 1 if fl else 0
+        if r1 is None:
+            bailed += 1
+            continue
+        assert r0 == r1 and c0[1:] == c1[1:] and c0[0] <= c1[0] <= c0[2] + 1, (it, mode, n, deg, ef, cap, fcap)
+        equal += 1
+    assert equal > 500 and bailed > 0 and flushed > 200
+
+
+def test_two_level_list_lane_for_lane():
+    """The device's steps on the two-level list, lane for lane (64 lanes, windows of 64 keys), against plain merges:
+    * m_lower_bound: the 4-ary lower bound with its fixed number of steps (6 for 2112 keys, 7 for 4160 / 8256);
+    * flush: every F entry's rank in M; M's windows moved up IN PLACE from the top down -- a window's shift is a_lo (the F
+      entries ranked below the window) plus, per lane, the F entries ranked inside it at or below the lane's entry -- F's
+      entries written last at rank + j; what lands beyond CAP is lost; the lower bound of the first unexpanded entry;
+    * update_theta: lane j tries "j keys of F and ef - j of M": exactly one lane is right;
+    * insert_fresh: ranks / shifts / `below` of the candidates in F, the look-up at rank and rank - 1, one scatter."""
+    import bisect
+    rnd = random.Random(67)
     INF = (1 << 64) - 1
-    for it in range(400):
-        S = rnd.choice([2, 3, 33])          # slots of 64 keys (the model does not care how many)
+
+    def key(d, i, f):
+        return (d << 32) | (i << 1) | f
+
+    def lower_bound_4ary(M, CAP, k, steps):
+        lo, hi = 0, CAP
+        for _ in range(steps):
+            ln, last = hi - lo, (hi - 1 if hi else 0)
+            p1, p2, p3 = min(last, lo + (ln >> 2)), min(last, lo + (ln >> 1)), min(last, lo + ((3 * ln) >> 2))
+            go, l1, l2, l3 = lo < hi, M[p1] < k, M[p2] < k, M[p3] < k
+            nlo = p3 + 1 if l3 else p2 + 1 if l2 else p1 + 1 if l1 else lo
+            nhi = hi if l3 else p3 if l2 else p2 if l1 else p1
+            if go:
+                lo, hi = nlo, nhi
+        assert lo == hi
+        return lo
+
+    for it in range(300):
+        S, steps = rnd.choice([(33, 6), (65, 7), (129, 7), (3, 6)])
         CAP = 64 * S
-        n_list = rnd.randrange(0, CAP + 1)
-        # keys: (dist bits << 32) | (id << 1) | expanded; few distinct distances -> many ties on distance
-        def key(d, i, f):
-            return (d << 32) | (i << 1) | f
-        ids = rnd.sample(range(1 << 20), n_list + 40)
-        entries = sorted(key(rnd.randrange(6 if it % 2 else 1 << 20), ids[j], rnd.randrange(2)) for j in range(n_list))
-        lst = entries + [INF] * (CAP - n_list)
-        fu_true = next((p for p, k in enumerate(lst) if k != INF and not (k & 1)), CAP)
-        fu_lb = rnd.randrange(0, fu_true + 1)  # any valid lower bound
-        # up to 32 candidates: fresh ids, some already in the list (revisits), some twice in the row
+        nM = rnd.choice([0, 1, 5, 64, 65, CAP // 2, CAP - 70, CAP - 1, CAP])
+        nF = rnd.randrange(0, 64)
+        few = it % 2  # few distinct distances: ties on distance, the ids decide
+        ids = rnd.sample(range(1 << 22), nM + nF + 40)
+        Mreal = sorted(key(rnd.randrange(6 if few else 1 << 20), ids[j], rnd.randrange(2)) for j in range(nM))
+        Freal = sorted(key(rnd.randrange(6 if few else 1 << 20), ids[nM + j], rnd.randrange(2)) for j in range(nF))
+        M = Mreal + [INF] * (CAP - nM)
+        F = Freal + [INF] * (64 - nF)
+        for k in Freal[:5] + [0, INF - 1]:
+            assert lower_bound_4ary(M, CAP, k, steps) == bisect.bisect_left(M, k)
+        # ---- update_theta
+        ef = rnd.randrange(1, max(2, min(CAP - 64, nM + nF + 5)))
+        union = sorted(Mreal + Freal)
+        if nM + nF >= ef:
+            ok = []
+            for j in range(64):
+                in_range = j <= nF and j <= ef and ef - j <= nM
+                i = ef - j if in_range else 0
+                Mi, Mi1 = M[min(i, CAP - 1)], M[i - 1 if i else 0]
+                Fj, Fj1 = F[j], (F[j - 1] if j else 0)
+                good = in_range and (j == 0 or Fj1 < Mi) and (i == 0 or Mi1 < Fj)
+                last = Mi1 if j == 0 else Fj1 if i == 0 else max(Fj1, Mi1)
+                if good:
+                    ok.append(last)
+            assert ok == [union[ef - 1]], (it, nM, nF, ef, len(ok))
+        # ---- insert_fresh on F: up to 32 candidates, some already in F (revisits)
+        room = 63 - nF
         cands = []
-        for j in range(rnd.randrange(0, 33)):
-            r = rnd.random()
-            if r < 0.2 and n_list:
-                cands.append(entries[rnd.randrange(n_list)] & ~1)          # a node the list holds (flag cleared: a candidate key)
-            elif r < 0.3 and cands:
-                cands.append(cands[rnd.randrange(len(cands))])             # the row names a node twice
+        for j in range(rnd.randrange(0, min(32, room) + 1)):
+            if rnd.random() < 0.2 and nF:
+                cands.append(Freal[rnd.randrange(nF)] & ~1)
             else:
-                cands.append(key(rnd.randrange(6 if it % 2 else 1 << 20), ids[n_list + j], 0))
-        # ---- the device's way
-        import bisect
-        rank, keep = [], []
-        for j, K in enumerate(cands):
-            r = bisect.bisect_left(lst, K)
-            known = r < CAP and (lst[r] | 1) == (K | 1)
-            twin = any(cands[i] == K for i in range(j))                     # an earlier lane with the same key (kept or not: then known too)
-            rank.append(r)
-            keep.append(not known and not twin)
-        kept = [j for j in range(len(cands)) if keep[j]]
-        mypos = {j: rank[j] + sum(1 for i in kept if cands[i] < cands[j]) for j in kept}
-        out = [None] * CAP
+                cands.append(key(rnd.randrange(6 if few else 1 << 20), ids[nM + nF + j], 0))
+        cands = list(dict.fromkeys(cands))
+        passm = list(range(len(cands)))
+        while True:
+            shift = [sum(1 for c in passm if F[l] > cands[c]) for l in range(64)]
+            rankv = {c: 64 - sum(1 for l in range(64) if F[l] > cands[c]) for c in passm}
+            below = {c: sum(1 for o in passm if cands[c] > cands[o]) for c in passm}
+            known = [c for c in passm if (rankv[c] < 64 and (F[min(rankv[c], 63)] | 1) == (cands[c] | 1)) or
+                     (F[rankv[c] - 1 if rankv[c] else 0] | 1) == (cands[c] | 1)]
+            if not known:
+                break
+            passm = [c for c in passm if c not in known]
+        img = [None] * 128
+        for l in range(64):
+            img[l + shift[l]] = F[l]
+        for c in passm:
+            assert img[rankv[c] + below[c]] is None
+            img[rankv[c] + below[c]] = cands[c]
+        fresh = sorted({K for K in cands if not any((e | 1) == (K | 1) for e in Freal)})
+        assert img[:64] == (sorted(Freal + fresh) + [INF] * 64)[:64], (it, nF, len(cands))
+        # ---- flush
+        live = list(range(nF))
+        r = [lower_bound_4ary(M, CAP, F[j], steps) for j in live]
+        out = list(M)
         lost = []
-        base = 0
-        for s in range(S):
-            in_slot = [j for j in kept if rank[j] >> 6 == s]
-            for lane in range(64):
-                e = 64 * s + lane
-                shift = base + sum(1 for j in in_slot if lane >= (rank[j] & 63))
-                if e + shift < CAP:
-                    assert out[e + shift] is None
-                    out[e + shift] = lst[e]
-                elif lst[e] != INF:
-                    lost.append(lst[e])
-            base += len(in_slot)
-        for j in kept:
-            if mypos[j] < CAP:
-                assert out[mypos[j]] is None
-                out[mypos[j]] = cands[j]
+        m_un = next((p for p in range(nM) if not (M[p] & 1)), CAP)
+        if nM and nF:
+            w_first, w_top = r[0] >> 6, (nM - 1) >> 6
+            a_hi = nF
+            for w in range(w_top, w_first - 1, -1):
+                a_lo = sum(1 for j in live if r[j] < w * 64)
+                window = [out[w * 64 + l] for l in range(64)]  # read before anything of this window is written
+                for l in range(64):
+                    e = w * 64 + l
+                    c = a_lo + sum(1 for j in range(a_lo, a_hi) if e >= r[j])
+                    if e < nM:
+                        if e + c < CAP:
+                            out[e + c] = window[l]
+                        else:
+                            lost.append(window[l])
+                a_hi = a_lo
+        dest = [r[j] + j for j in live]
+        for j in live:
+            if dest[j] < CAP:
+                out[dest[j]] = F[j]
             else:
-                lost.append(cands[j])
-        new_lb = min([fu_lb] + [mypos[j] for j in kept])
-        # ---- a plain merge
-        fresh = sorted({K for K in cands if not any((e | 1) == (K | 1) for e in entries)})
-        merged = sorted(entries + fresh) + [INF] * CAP
-        assert out == merged[:CAP], (it, S, n_list, len(cands))
-        assert sorted(lost) == sorted(k for k in merged[CAP:CAP + len(entries) + len(fresh)] if k != INF)
-        first_unexp = next((p for p, k in enumerate(out) if k != INF and not (k & 1)), CAP)
-        assert new_lb <= first_unexp and all(k & 1 for k in out[:new_lb])
+                lost.append(F[j])
+        merged = sorted(Mreal + Freal)
+        assert out[:min(CAP, nM + nF)] == merged[:CAP], (it, S, nM, nF)
+        assert all(k == INF for k in out[min(CAP, nM + nF):])
+        assert sorted(lost) == merged[CAP:]
+        fun = [j for j in live if not (F[j] & 1)]
+        lb = min([m_un if m_un < CAP else nM] + ([dest[fun[0]]] if fun else []))
+        first = next((p for p in range(min(CAP, nM + nF)) if not (out[p] & 1)), CAP)
+        assert lb <= first and all(k & 1 for k in out[:min(lb, CAP)])
 
 
 def test_rows_taken_in_two_passes_equal_two_heaps():
