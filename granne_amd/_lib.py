@@ -14,7 +14,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_OVERFLOW, ERR_IO = -1, -2, -3, -4, -5
 
 OPT_VISITED_SLOTS, OPT_FORCE_SLOW, OPT_SLOW_SLOTS, OPT_SLOW_BLOCKS, OPT_OVERFLOW_SLOTS = 1, 2, 3, 4, 5
-OPT_VISITED16, OPT_VISITED16_LG, OPT_LAST_WALKER, OPT_SEARCH_DEPTH, OPT_INLINE_TAILS = 6, 7, 8, 9, 10
+OPT_VISITED16, OPT_VISITED16_LG, OPT_LAST_WALKER, OPT_SEARCH_DEPTH, OPT_INLINE_TAILS, OPT_SEEN_MIN = 6, 7, 8, 9, 10, 11
 WALKER_NONE, WALKER_REGISTER, WALKER_REGISTER_WIDE, WALKER_GENERAL, WALKER_EXACT = 0, 1, 2, 3, 4
 SEARCH_DEPTH = 3  # GRANNE_HIP_SEARCH_DEPTH (the default of OPT_SEARCH_DEPTH)
 SEARCH_DEPTH_MAX = 16  # GRANNE_HIP_SEARCH_DEPTH_MAX

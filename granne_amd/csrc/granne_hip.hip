@@ -73,7 +73,7 @@ extern "C" int granne_hip_device_count(int* out_count) {
 
 // experiment knobs, read once per process
 struct EnvKnobs {
-    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, tail_blocks = -1, touch_max = -1, inline_tails = 1;
+    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, tail_blocks = -1, touch_max = -1, inline_tails = 1, seen_min = -1;
     EnvKnobs() {
         auto geti = [](const char* name, int dflt) {
             const char* e = getenv(name);
@@ -85,6 +85,7 @@ struct EnvKnobs {
         lds_pad = geti("GRANNE_HIP_LDS_PAD", 0);
         visited = geti("GRANNE_HIP_VISITED", 0); // GRANNE_HIP_OPT_VISITED16's values, where the option says auto
         inline_tails = geti("GRANNE_HIP_INLINE_TAILS", 1); // 0: no index keeps LayerDev::adjx (experiments: the layout before round 6)
+        seen_min = geti("GRANNE_HIP_SEEN_MIN", -1); // launches of at least this many walks skip revisits before their rows are fetched (-1: default)
         touch_max = geti("GRANNE_HIP_TOUCH_MAX", -1); // launches of up to this many queries touch rows ahead (-1: default)
     }
 };
@@ -151,6 +152,7 @@ struct granne_hip_index {
     uint64_t opt_visited16 = 0;      // 0 auto, 1 off, 2 always the 20-bit entries (tests)
     uint64_t opt_visited16_lg = 0;   // 0 auto, else log2(buckets)
     uint64_t opt_inline_tails = 1;   // GRANNE_HIP_OPT_INLINE_TAILS: keep LayerDev::adjx for the shapes that have one
+    uint64_t opt_seen_min = 2048;    // GRANNE_HIP_OPT_SEEN_MIN: launches of at least this many walks skip revisits before their rows are fetched
     std::atomic<uint64_t> last_slow_count{0};
     std::atomic<uint64_t> last_walker{0}; // GRANNE_HIP_OPT_LAST_WALKER
     // the exact scan of int8 rows (brute_force.h): 1 / |x| per row, made at the first scan
@@ -650,6 +652,9 @@ extern "C" int granne_hip_index_set_option(granne_hip_index* ix, int option, uin
         ix->opt_inline_tails = value;
         return finish_layers(ix, nullptr);
     }
+    case GRANNE_HIP_OPT_SEEN_MIN:
+        ix->opt_seen_min = value > 0xFFFFFFFFull ? 0xFFFFFFFFull : value;
+        return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_VISITED16_LG: // (retired with the bucket tables it sized: accepted, ignored)
         if (value > 12) return fail(GRANNE_HIP_ERR_INVALID, "value out of range");
         ix->opt_visited16_lg = value;
@@ -672,6 +677,7 @@ extern "C" int granne_hip_index_get_option(const granne_hip_index* ix, int optio
     case GRANNE_HIP_OPT_LAST_WALKER: *value = ix->last_walker.load(); return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_SEARCH_DEPTH: *value = ix->depth; return GRANNE_HIP_OK;
     case GRANNE_HIP_OPT_INLINE_TAILS: *value = (!ix->layers.empty() && ix->layers.back().d_adjx) ? 1 : 0; return GRANNE_HIP_OK;
+    case GRANNE_HIP_OPT_SEEN_MIN: *value = ix->opt_seen_min; return GRANNE_HIP_OK;
     default: return fail(GRANNE_HIP_ERR_INVALID, "unknown option %d", option);
     }
 }
@@ -696,6 +702,7 @@ struct SearchTarget {
     uint32_t max_dev_width;
     uint64_t opt_visited_slots, opt_force_slow, opt_slow_slots, opt_slow_blocks, opt_overflow_slots;
     uint64_t opt_visited16 = 0, opt_visited16_lg = 0;
+    uint64_t opt_seen_min = 0xFFFFFFFFull; // (a builder's searches: never -- its layers change between launches, its batches are its own)
     ScratchCache* scratch; // search_launch's per-stream scratch blocks
     std::atomic<uint64_t>* last_walker = nullptr; // which kernel the last launch took (an index's read-only option)
 };
@@ -719,6 +726,7 @@ static SearchTarget target_of(const granne_hip_index* ix) {
     T.opt_overflow_slots = ix->opt_overflow_slots;
     T.opt_visited16 = ix->opt_visited16;
     T.opt_visited16_lg = ix->opt_visited16_lg;
+    T.opt_seen_min = ix->opt_seen_min;
     T.scratch = &const_cast<granne_hip_index*>(ix)->scratch;
     T.last_walker = &const_cast<granne_hip_index*>(ix)->last_walker;
     return T;
@@ -756,6 +764,9 @@ template <int DT, int DIM, int S>
 static search_fn pick_fast_v(int v16) {
     if constexpr (S == 1 && !(DT == DT_F32 && DIM == 0) && !(DT == DT_I8 && DIM >= 256)) {
         if (v16 == 4) return fast_kernel<DT, DIM, S, false, 4>; // no visited set + rows touched ahead (few queries)
+    }
+    if constexpr (DT == DT_F32 && DIM != 0 && S <= 4) {
+        if (v16 == 5) return fast_kernel<DT, DIM, S, false, 5>; // no visited set + revisits skipped before their rows are fetched (many walks)
     }
     if (v16 >= 3) return fast_kernel<DT, DIM, S, false, 3>;
     return fast_kernel<DT, DIM, S>;
@@ -855,12 +866,17 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         const uint32_t touch_max = knobs().touch_max >= 0 ? (uint32_t)knobs().touch_max : 256u; // (round 5: +4 % at 256 queries, -10 % at 1024: profiles/r5_touch.txt)
         const bool touch_shape = fastS == 1 && !fast_generic(ix) && !(ix->dtype == GRANNE_HIP_I8 && ix->row_bytes != 128);
         P.v16 = (touch_shape && nq <= touch_max) ? 4 : 3;
+        // launches of many walks are bound by bandwidth: their walkers skip revisits BEFORE the rows are fetched (walk_fast.h, SEEN)
+        const uint64_t seen_min = knobs().seen_min >= 0 ? (uint64_t)knobs().seen_min : ix->opt_seen_min; // (GRANNE_HIP_SEEN_MIN overrides the option: experiments)
+        // (f32 rows: the walkers per CU are bound by registers there, 8 KB of cache each fit; int8 walkers are four times as many
+        //  and lose more to the look-up than the few revisits of their rows cost: measured, profiles/r6_seen_ab.txt)
+        if (fastS <= 4 && !fast_wide(ix) && !fast_generic(ix) && ix->dtype == GRANNE_HIP_F32 && nq >= seen_min) P.v16 = 5;
         P.visited_slots = P.upper_slots = 0;
         P.maxc = 0;
         P.lrow_bytes = 16;
         P.stage_bytes = 0;
         P.adjspec_bytes = 0;
-        P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, 0u);
+        P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, 0u, P.v16 == 5);
         const uint32_t least = lds_query_bytes(ix->row_bytes) + 64u * 8u; // int8 query staging; a tail block (slow_kernel.h)
         if (P.lds_bytes < least) P.lds_bytes = least;
         return P;

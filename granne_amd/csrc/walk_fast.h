@@ -89,6 +89,7 @@ __device__ __forceinline__ uint32_t wkey_id(uint64_t k) { return ((uint32_t)k) >
 __device__ __forceinline__ float wkey_dist(uint64_t k) { return __uint_as_float((uint32_t)(k >> 32)); }
 constexpr uint32_t WPOS_NONE = 0xFFFFFFFFu;
 constexpr uint32_t VCACHE_SLOTS = 512; // FastWalker::vcache (power of two, 2 KB of LDS per walker)
+constexpr uint32_t VCACHE_SLOTS_SEEN = 2048; // ... of the walkers that skip revisits before their rows are fetched (SEEN: 8 KB; f32 rows -- 12 walkers per CU)
 constexpr uint64_t WALK_MAX_ELEMENTS = 1ull << 31; // ids must fit 31 bits
 
 __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) { // set bits of m below this lane
@@ -279,8 +280,16 @@ struct FastWalker {
     // 128-byte line, data dropped -- so that, when that node is expanded next (half of the time), its rows come from L2.
     // With a thousand walks in a launch the same touches cost throughput and are not compiled in.
     static constexpr bool TOUCH = V16 == 4;
+    // V16 == 5, launches of many walks (the bandwidth-bound shapes): the cache of ids is consulted BEFORE the row loads and
+    // holds every id the walk EVALUATED (not only the ones that entered the list): a hit is the reference's
+    // `!visited.insert(n)` (mod.rs:1026) -- the neighbor is skipped, its row is not fetched. A miss (never seen, or pushed
+    // out of its slot) means nothing: the row is evaluated (again). On i.i.d.-uniform data 3.6 % of the rows a walk
+    // fetches are revisits, on clustered data 40 %; the look-up's LDS round trip sits between the adjacency row and the
+    // row loads, which a lone wave per SIMD would pay for on every expansion -- hence only for the launches that are
+    // bound by bandwidth, not by one wave's latency.
+    static constexpr bool SEEN = V16 == 5;
     static_assert(!WIDE || V16 == 3, "layers of 64 ids: walked without a visited set only");
-    static_assert(V16 == 0 || V16 == 3 || V16 == 4, "the exact 32-bit table, or no visited set (4: + rows touched ahead)");
+    static_assert(V16 == 0 || V16 == 3 || V16 == 4 || V16 == 5, "the exact 32-bit table, or no visited set (4: + rows touched ahead, 5: + revisits skipped before their rows are fetched)");
     typename std::conditional<V16 == 0, VisitedSet, VisitedNone>::type vis;
     WalkList<S> L;
     WalkStats st;
@@ -310,7 +319,7 @@ struct FastWalker {
         m_un = 0;
         m_un_key = KEY_INF;
         lost_bits = 0xFFFFFFFFu;
-        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u + (LONG_LIST ? FIMG_KEYS * 8u : 0u) + VCACHE_SLOTS * 4u);
+        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u + (LONG_LIST ? FIMG_KEYS * 8u : 0u) + VSLOTS * 4u);
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
         sy = 0.0f;
@@ -775,12 +784,16 @@ struct FastWalker {
     // loop: a hit means "this node entered the list earlier in this walk of the layer", i.e. the reference's visited set
     // holds it and skips it (mod.rs:1026); a miss (never entered, or evicted by a colliding id) means nothing -- the
     // candidate goes the exact way. Results do not depend on the cache.
-    __device__ __forceinline__ static uint32_t vcache_slot(uint32_t id) { return (id ^ (id >> 9)) & (VCACHE_SLOTS - 1u); }
+    static constexpr uint32_t VSLOTS = (V16 == 5) ? VCACHE_SLOTS_SEEN : VCACHE_SLOTS;
+    __device__ __forceinline__ static uint32_t vcache_slot(uint32_t id) {
+        if constexpr (V16 == 5) return (id ^ (id >> 11) ^ (id >> 22)) & (VSLOTS - 1u);
+        else return (id ^ (id >> 9)) & (VSLOTS - 1u);
+    }
     __device__ __forceinline__ void vcache_reset(uint32_t first_id) {
         if constexpr (NOVIS) {
             uint4* t4 = reinterpret_cast<uint4*>(vcache);
             const uint4 e = make_uint4(ID_EMPTY, ID_EMPTY, ID_EMPTY, ID_EMPTY);
-            for (uint32_t i = lane; i < VCACHE_SLOTS / 4u; i += 64) t4[i] = e;
+            for (uint32_t i = lane; i < VSLOTS / 4u; i += 64) t4[i] = e;
             asm volatile("" ::: "memory");
             if (lane == 0) vcache[vcache_slot(first_id)] = first_id;
         }
@@ -1162,7 +1175,19 @@ struct FastWalker {
             const uint64_t unused = wave_ballot(nb == ID_EMPTY);
             const uint32_t nvalid = unused ? ((uint32_t)__builtin_ctzll(unused) >> 1) : 32u;
             st.n_adj += nvalid;
-            {   // pairs past the row's end re-read its first neighbor (the same lines as pair 0: no traffic of their own; an
+            [[maybe_unused]] uint64_t seenm = 0; // SEEN: the pairs whose id the walk has evaluated before (both lanes of a pair)
+            if constexpr (SEEN) {
+                const bool seen = vcache[vcache_slot(nb)] == nb; // (the entry point is in the cache; UNUSED never is)
+                seenm = wave_ballot(seen);
+                if (!seen && nb != ID_EMPTY) { // rows of new ids only: a revisit's -- and an empty pair's -- loads are not issued
+                    const uint8_t* tails = nullptr;
+                    if constexpr (XT) {
+                        if (adjx) tails = adjx + (size_t)xid * Ly.adjx_stride + 128u + R * XTAILB;
+                    }
+                    issue_rows(nb, rr, tails);
+                }
+            } else {
+                // pairs past the row's end re-read its first neighbor (the same lines as pair 0: no traffic of their own; an
                 // empty row: the node itself) -- chosen per lane, nothing scalar waits for a vector result
                 uint32_t fill = readlane32(nb, 0);
                 asm("" : "+v"(fill));
@@ -1185,14 +1210,18 @@ struct FastWalker {
                 next_nb = adjg[(size_t)yid * W + R];
             }
             [[maybe_unused]] uint32_t cached = ID_EMPTY; // what the cache holds in this neighbor's slot (arrives under the row loads)
-            if constexpr (NOVIS) cached = vcache[vcache_slot(nb)];
+            if constexpr (NOVIS && !SEEN) cached = vcache[vcache_slot(nb)];
+            if constexpr (SEEN) { // every id this expansion evaluates is seen from now on (lanes of one slot: the last one wins)
+                if (nb != ID_EMPTY && !__builtin_amdgcn_inverse_ballot_w64(seenm)) vcache[vcache_slot(nb)] = nb;
+            }
             asm volatile("" ::: "memory"); // the fetch-ahead and the look-up are issued here, not where their results are used
             __builtin_amdgcn_sched_barrier(0);
             PT_MARK(1); // row loads and the fetch-ahead issued
 
             // visited set under the loads, then the distances (mod.rs:1026-1027)
             uint64_t fm; // even lanes whose id is evaluated for the first time (no set: every neighbor)
-            if constexpr (NOVIS) fm = 0x5555555555555555ull & ~unused; // (valid ids come first, mod.rs:540-552)
+            if constexpr (SEEN) fm = 0x5555555555555555ull & ~unused & ~seenm;
+            else if constexpr (NOVIS) fm = 0x5555555555555555ull & ~unused; // (valid ids come first, mod.rs:540-552)
             else fm = wave_ballot(vis.insert(nb, h == 0u && R < nvalid, p.ovf));
             PT_MARK(2); // visited set (under the loads)
             PT_WAIT_VM();
@@ -1232,7 +1261,7 @@ struct FastWalker {
             const uint64_t ck = ((uint64_t)dbits << 32) | ck_lo;
             Ranked rk;
             passm = twin_rows ? rank_candidates<true>(passm, ck_lo, dbits, rk) : rank_candidates<false>(passm, ck_lo, dbits, rk);
-            if constexpr (NOVIS) {
+            if constexpr (NOVIS && !SEEN) {
                 if (__builtin_amdgcn_inverse_ballot_w64(passm)) vcache[vcache_slot(nb)] = nb;
             }
             const uint32_t m = (uint32_t)__popcll(passm);
@@ -1448,10 +1477,10 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S, WIDE)) void fas
     }
 }
 
-__host__ __device__ inline uint32_t fast_lds_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots) {
+__host__ __device__ inline uint32_t fast_lds_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots, bool seen = false) {
     // [query][the list's image][lists of up to 17 slots: the cache of entered ids][visited]
     // (lists beyond 1024 keys: M's image, then F's of 128 keys)
-    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (64u * S + (S >= 33u ? 0u : 32u)) * 8u + (S >= 33u ? 128u * 8u : 0u) + VCACHE_SLOTS * 4u + visited_slots * 4u;
+    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (64u * S + (S >= 33u ? 0u : 32u)) * 8u + (S >= 33u ? 128u * 8u : 0u) + (seen ? VCACHE_SLOTS_SEEN : VCACHE_SLOTS) * 4u + visited_slots * 4u;
 }
 
 } // namespace granne_hip

@@ -95,6 +95,7 @@ extern "C" {
 }
 pub const GRANNE_HIP_OPT_SEARCH_DEPTH: c_int = 9;
 pub const GRANNE_HIP_OPT_INLINE_TAILS: c_int = 10;
+pub const GRANNE_HIP_OPT_SEEN_MIN: c_int = 11;
 pub const GRANNE_HIP_SHARDED_OPT_DEPTH: c_int = 1;
 pub const GRANNE_HIP_SHARDED_OPT_EXCHANGE: c_int = 2;
 pub const GRANNE_HIP_SHARDED_EXCHANGE_PEER: u64 = 0;

@@ -1025,3 +1025,44 @@ def test_two_level_lists_on_ties_twins_and_short_graphs(ga, oracle, int8):
     g3 = ga.Granne("angular_int" if int8 else "angular", small, o3.layers)
     assert_same(o3, g3, q[:12], 1500, 700)
     assert_same(o3, g3, q[:12], 8000, 10)
+
+
+@pytest.mark.parametrize("dim", [100, 200])
+def test_revisits_skipped_before_their_rows_are_fetched(ga, oracle, dim):
+    """GRANNE_HIP_OPT_SEEN_MIN (walk_fast.h, SEEN): launches of many f32 walks consult a cache of the ids a walk has
+    evaluated BEFORE they fetch a neighbor's row and skip a hit -- the reference's `!visited.insert(n)` (mod.rs:1026) for the
+    recent part of the visited set; a miss means nothing. Forced on for every launch here (the default asks for 2048 walks):
+    ids, distance bits, expansions and adjacency counts are the oracle's on clustered data (most neighbors are revisits), on
+    rows that name a neighbor twice, with and without the walkers' copy of the layers; the evaluations counted lie between
+    the oracle's distinct nodes and what the walker without the cache evaluates."""
+    from granne_amd import _lib
+    rng = np.random.default_rng(900 + dim)
+    centers = random_floats(rng, 40, dim)
+    raw = centers[rng.integers(0, 40, 6000)] + 0.05 * random_floats(rng, 6000, dim)
+    el = prep(oracle, raw.astype(np.float32), False)
+    q = prep(oracle, (centers[rng.integers(0, 40, 200)] + 0.05 * random_floats(rng, 200, dim)).astype(np.float32), False)
+    oix = oracle.build_index(el, num_neighbors=30, max_search=40, n_threads=4)
+    layers = [l.copy() for l in oix.layers]
+    for i in range(0, len(layers[-1]), 9):  # rows that name their first neighbor twice
+        row = layers[-1][i]
+        nv = int((row != 0xFFFFFFFF).sum())
+        if nv >= 3:
+            row[nv - 1] = row[0]
+    oix = oracle.Index(el, layers)
+    gix = ga.Granne("angular", el, layers)
+    assert gix.get_option(_lib.OPT_SEEN_MIN) == 2048
+    for tails in (1, 0):
+        gix.set_option(_lib.OPT_INLINE_TAILS, tails)
+        for ms in (1, 30, 60, 61, 124, 200, 252, 300):  # (one, two and four slots skip revisits; longer lists walk as before)
+            gix.set_option(_lib.OPT_SEEN_MIN, 0xFFFFFFFF)
+            ids0, ds0, cnt0, st0 = gix.search_batch(q, ms, 10, stats=True)
+            gix.set_option(_lib.OPT_SEEN_MIN, 0)
+            ids, ds, cnt, st = gix.search_batch(q, ms, 10, stats=True)
+            oi, od, oc, octr = oix.search_batch(q, ms, 10)
+            assert (cnt == oc).all() and (ids == oi).all() and ds.tobytes() == od.tobytes(), (tails, ms)
+            assert (ids0 == oi).all() and ds0.tobytes() == od.tobytes()
+            assert_counters(st, octr, exact=False)
+            assert (st[:, 0] <= st0[:, 0]).all()
+            if 1 < ms <= 252:
+                assert st[:, 0].sum() < 0.9 * st0[:, 0].sum(), (ms, st[:, 0].sum(), st0[:, 0].sum())  # the cache does skip rows here
+    gix.set_option(_lib.OPT_SEEN_MIN, 2048)
