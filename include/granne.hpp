@@ -203,6 +203,19 @@ public:
     }
     void write_index(const std::string& path) const { check(granne_hip_index_save(h_.get(), path.c_str(), nullptr)); }
     void write_elements(const std::string& path) const { check(granne_hip_index_save(h_.get(), nullptr, path.c_str())); }
+    // Index::write_index into a writer (src/index/mod.rs:67-70): the bytes of the index file
+    std::vector<uint8_t> index_bytes() const {
+        void* p = nullptr;
+        uint64_t n = 0;
+        check(granne_hip_index_encode(h_.get(), &p, &n));
+        std::vector<uint8_t> out(static_cast<const uint8_t*>(p), static_cast<const uint8_t*>(p) + n);
+        granne_hip_bytes_free(p);
+        return out;
+    }
+    // the walkers' copy of the layers with the neighbors' row tails next to the ids (f32 100-d / 200-d: whole-line reads)
+    void set_inline_tails(bool keep) { check(granne_hip_index_set_option(h_.get(), GRANNE_HIP_OPT_INLINE_TAILS, keep ? 1 : 0)); }
+    // from how many walks per launch revisits are skipped before their rows are fetched (f32; 0 = always)
+    void set_seen_min(uint64_t walks) { check(granne_hip_index_set_option(h_.get(), GRANNE_HIP_OPT_SEEN_MIN, walks)); }
     granne_hip_index* raw() const { return h_.get(); }
 
 private:

@@ -380,6 +380,12 @@ impl<E: GpuElements> GpuGranne<E> {
     pub fn set_inline_tails(&mut self, keep: bool) -> std::io::Result<()> {
         check(unsafe { granne_hip_index_set_option(self.handle, GRANNE_HIP_OPT_INLINE_TAILS, keep as u64) })
     }
+    /// `GRANNE_HIP_OPT_SEEN_MIN`: f32 launches of at least this many walks skip a revisited neighbor BEFORE its row is
+    /// fetched (a cache of the ids the walk has evaluated; a miss means nothing, so results do not depend on it). Default
+    /// 2048; 0 = every launch; `u32::MAX as u64` = never.
+    pub fn set_seen_min(&mut self, walks: u64) -> std::io::Result<()> {
+        check(unsafe { granne_hip_index_set_option(self.handle, GRANNE_HIP_OPT_SEEN_MIN, walks) })
+    }
     // ---- the Index trait's accessors (src/index/mod.rs:54-71); `impl Index for GpuGranne` below forwards to them
     pub fn len(&self) -> usize { unsafe { granne_hip_index_len(self.handle) as usize } }
     pub fn num_layers(&self) -> usize { unsafe { granne_hip_index_num_layers(self.handle) as usize } }

@@ -4,6 +4,8 @@
 //   with_borrowed_elements (config)     src/index/tests.rs:64-82
 //   incremental build_partial           src/index/tests.rs:134-168
 //   write_and_load                      src/index/tests.rs:337-394
+#include <fstream>
+#include <iterator>
 #include <algorithm>
 #include <cstdio>
 #include <random>
@@ -81,6 +83,19 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < 50; ++i) {
             auto a = index.search(index.get_element(i * 3), 20, 5), b = loaded.search(index.get_element(i * 3), 20, 5);
             REQUIRE(a == b);
+        }
+        // Index::write_index into a writer (src/index/mod.rs:67-70): the same bytes as the file; the walkers' options change no result
+        {
+            auto blob = index.index_bytes();
+            std::ifstream f(tmp + "/cpp_index.granne", std::ios::binary);
+            std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            REQUIRE(blob == file && blob.size() > 1024);
+            auto before = index.search(index.get_element(9), 20, 5);
+            index.set_inline_tails(false);
+            index.set_seen_min(0);
+            REQUIRE(index.search(index.get_element(9), 20, 5) == before);
+            index.set_inline_tails(true);
+            index.set_seen_min(2048);
         }
     }
     {   // reorder_index (src/index/reorder.rs:299-322)
