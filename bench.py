@@ -594,7 +594,20 @@ class Bench:
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1)
             n, dim = (n or len(index)), index.dim
-            if dtype == "f32":
+            if dtype == "f32" and os.environ.get("GRANNE_HIP_BF_B16", "1") != "0":
+                kpad = 112 if dim <= 112 else 208 if dim <= 208 else 256
+                flops = 3.0 * 2.0 * nq * n * kpad  # what the matrix cores execute: three bf16 instructions per product, K padded
+                timing.update({"kernel": "bf_b16_kernel (f32 rows as two bf16 pieces each: 3 x v_mfma_f32_32x32x16_bf16 per 16 components) "
+                                         "+ merge + exact re-ranking", "ms": round(ms, 3),
+                               "value": round(nq / (ms * 1e-3), 1), "value_unit": "queries/s at recall 1.0 (exact scan)",
+                               "bound": "mfma", "achieved": round(flops / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                               "frac": round(flops / ms / 1e9 / 2500.0, 4), "queries": nq, "elements": n, "dim": dim,
+                               "useful_f32_equivalent_tflops": round(2.0 * nq * n * dim / ms / 1e9, 1),
+                               "note": "3 * 2 * nq * n * K flops the matrix cores execute (K = dim padded to %d) / wall of the whole "
+                                       "operator (HIP events); peak = dense bf16 MFMA (MI355X_MICROARCH.md); round 5 scored on the f32 "
+                                       "matrix path: 17.2 ms = 0.76 of ITS 157.3 TFLOP/s peak; the scan now waits for LDS (every wave reads "
+                                       "the whole element tile) and for the tile's conversion as much as for the matrix cores" % kpad})
+            elif dtype == "f32":
                 flops = 2.0 * nq * n * dim
                 timing.update({"kernel": "bf_f32_kernel (v_mfma_f32_32x32x2_f32) + merge + exact re-ranking", "ms": round(ms, 3),
                                "value": round(nq / (ms * 1e-3), 1), "value_unit": "queries/s at recall 1.0 (exact scan)",

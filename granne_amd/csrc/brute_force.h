@@ -338,6 +338,139 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
     else bf_write_list(P, L, blk.range, q, qlive, h);
 }
 
+// f32 rows scored on the bf16 matrix path (round 6): the f32 scan above is MFMA-bound at 0.76 of the f32 matrix peak
+// (157 TFLOP/s: 17.2 ms per 1024 x 10M x 100) while the bf16 path is 16 x as wide. A scan only SELECTS candidates (their
+// distances are recomputed exactly afterwards), so its score needs to be accurate to a small fraction of the gap between
+// the k-th and the (k + BF_EXTRA)-th best, not to the last bit: every component is split into two bf16 pieces,
+// x = xh + xl (xh = bf16(x), xl = bf16(x - xh): 16 bits of mantissa between them), and a product is three matrix
+// instructions, xh qh + xh ql + xl qh, accumulated in f32 -- what is dropped (xl ql and the pieces' own rounding) is below
+// 2^-15 of |x||q| per product: ~3e-6 of a unit-vector dot in the typical case, 3e-5 at worst, against gaps of 1e-3 and
+// more between neighbours of rank 10 and 16 in the benchmark's sets. Same tile / range / priming / list structure as the
+// f32 scan; per 16 components three v_mfma_f32_32x32x16_bf16 (96 cycles) where that one issues eight 32x32x2 (512).
+// KG = groups of 8 components per lane half (the two halves of the wave take the two halves of the vector: 16 KG >= dim).
+typedef __bf16 bf_b16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf_b16x4 __attribute__((ext_vector_type(4)));
+template <int KG, int R, bool PRIME = false>
+__global__ __launch_bounds__(BF_THREADS) void bf_b16_kernel(const BruteParams P) {
+    extern __shared__ __align__(16) uint8_t smem_bf[];
+    constexpr uint32_t ET = 32u * R;                // elements per tile
+    constexpr uint32_t COMPS = 16u * KG;            // components per (zero padded) row
+    constexpr uint32_t STRIDE_B = 2u * COMPS + 16u; // bytes per LDS row of one piece: an odd number of 16-byte units
+    uint8_t* tile_hi = smem_bf;
+    uint8_t* tile_lo = smem_bf + (size_t)ET * STRIDE_B;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t col = lane & 31u, h = lane >> 5;
+    const BfBlock blk = bf_block();
+    const uint32_t q = blk.qt * BF_QT + wave * 32u + col;
+    const bool qlive = q < P.nq;
+
+    // the lane's half of its query as bf16 pieces, in registers for the whole scan
+    bf_b16x8 qh[KG], ql[KG];
+    {
+        const float* qp = reinterpret_cast<const float*>(P.queries) + (size_t)(qlive ? q : 0u) * P.dim;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t c = h * 8u * KG + (uint32_t)g * 8u + (uint32_t)j;
+                const float v = (qlive && c < P.dim) ? qp[c] : 0.0f;
+                const __bf16 hi = (__bf16)v;
+                qh[g][j] = hi;
+                ql[g][j] = (__bf16)(v - (float)hi);
+            }
+        }
+    }
+    BfList<PRIME ? 1 : BF_KMAX> L;
+    L.init();
+    float tau = bf_start_tau(P, q, qlive);
+    [[maybe_unused]] float best = -3.0e38f;
+
+    const uint64_t r0 = (uint64_t)blk.range * P.per_range;
+    const uint64_t r1 = r0 + P.per_range < P.n ? r0 + P.per_range : P.n;
+    const uint32_t row_f4 = P.row_bytes / 16u;      // float4 units of a device row that hold data
+    constexpr uint32_t UNITS = COMPS / 4u;          // float4 units per (padded) row
+    constexpr uint32_t NPF = (ET * UNITS + BF_THREADS - 1u) / BF_THREADS;
+    float4 pf[NPF];
+    auto fetch = [&](uint64_t e0) {
+#pragma unroll
+        for (uint32_t j = 0; j < NPF; ++j) {
+            const uint32_t u = tid + BF_THREADS * j;
+            const uint32_t row = u / UNITS, c4 = u - row * UNITS;
+            pf[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (u < ET * UNITS && e0 + row < r1 && c4 < row_f4)
+                pf[j] = *reinterpret_cast<const float4*>(P.elements + (e0 + row) * P.row_stride + c4 * 16u);
+        }
+    };
+    fetch(r0);
+    for (uint64_t e0 = r0; e0 < r1; e0 += ET) {
+        __syncthreads(); // the previous tile has been consumed
+#pragma unroll
+        for (uint32_t j = 0; j < NPF; ++j) { // split into the two pieces on the way to LDS
+            const uint32_t u = tid + BF_THREADS * j;
+            const uint32_t row = u / UNITS, c4 = u - row * UNITS;
+            if (u < ET * UNITS) {
+                bf_b16x4 hi, lo;
+                const float v[4] = {pf[j].x, pf[j].y, pf[j].z, pf[j].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    hi[t] = (__bf16)v[t];
+                    lo[t] = (__bf16)(v[t] - (float)hi[t]);
+                }
+                *reinterpret_cast<bf_b16x4*>(tile_hi + (size_t)row * STRIDE_B + c4 * 8u) = hi;
+                *reinterpret_cast<bf_b16x4*>(tile_lo + (size_t)row * STRIDE_B + c4 * 8u) = lo;
+            }
+        }
+        __syncthreads();
+        if (e0 + ET < r1) fetch(e0 + ET);
+        bf_f32x16 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][v] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const size_t off = (size_t)(r * 32 + col) * STRIDE_B + (h * 8u * KG + (uint32_t)g * 8u) * 2u;
+                const bf_b16x8 ah = *reinterpret_cast<const bf_b16x8*>(tile_hi + off);
+                const bf_b16x8 al = *reinterpret_cast<const bf_b16x8*>(tile_lo + off);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[g], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[g], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[g], acc[r], 0, 0, 0);
+            }
+        }
+        // result block r: acc[r][v] ~ dot(element e0 + r*32 + 8*(v/4) + 4*h + v%4, query `col` of this wave)
+        const bool whole = e0 + ET <= r1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if constexpr (PRIME) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                    best = (whole || e < r1) ? __builtin_fmaxf(best, acc[r][v]) : best;
+                }
+                continue;
+            }
+            float mx = acc[r][0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) mx = __builtin_fmaxf(mx, acc[r][v]);
+            if (__ballot(mx > tau)) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float sc = acc[r][v];
+                    const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                    if (sc > tau && (whole || e < r1)) {
+                        L.insert(sc, (uint32_t)e);
+                        tau = __builtin_fmaxf(tau, L.worst());
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (PRIME) bf_write_max(P, best, blk.range, q, qlive, h);
+    else bf_write_list(P, L, blk.range, q, qlive, h);
+}
+
 // int8: device rows of up to 128 bytes (dims up to 128; the scan refuses longer rows). K = 32 per MFMA
 // (v_mfma_i32_32x32x32_i8, gfx950): lanes 0-31 carry bytes 0-15 of a 32-byte group, lanes 32-63 bytes 16-31.
 // Score = dot / (|x| |q|) with the exact integer dot.

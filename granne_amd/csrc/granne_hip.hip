@@ -73,7 +73,7 @@ extern "C" int granne_hip_device_count(int* out_count) {
 
 // experiment knobs, read once per process
 struct EnvKnobs {
-    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, tail_blocks = -1, touch_max = -1, inline_tails = 1, seen_min = -1;
+    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, tail_blocks = -1, touch_max = -1, inline_tails = 1, seen_min = -1, bf_b16 = 1;
     EnvKnobs() {
         auto geti = [](const char* name, int dflt) {
             const char* e = getenv(name);
@@ -85,6 +85,7 @@ struct EnvKnobs {
         lds_pad = geti("GRANNE_HIP_LDS_PAD", 0);
         visited = geti("GRANNE_HIP_VISITED", 0); // GRANNE_HIP_OPT_VISITED16's values, where the option says auto
         inline_tails = geti("GRANNE_HIP_INLINE_TAILS", 1); // 0: no index keeps LayerDev::adjx (experiments: the layout before round 6)
+        bf_b16 = geti("GRANNE_HIP_BF_B16", 1); // 0: the exact scan of f32 rows scores on the f32 matrix path (round 5's: 5 x slower, scores to the last bits)
         seen_min = geti("GRANNE_HIP_SEEN_MIN", -1); // launches of at least this many walks skip revisits before their rows are fetched (-1: default)
         touch_max = geti("GRANNE_HIP_TOUCH_MAX", -1); // launches of up to this many queries touch rows ahead (-1: default)
     }
@@ -1650,6 +1651,21 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         fn = bf_i8_kernel<4>;
         fn_prime = bf_i8_kernel<4, true>;
         lds = BF_I8_SUB * (32u * R * (128u + 16u) + 32u * R * 4u + 2u * R * 4u);
+    } else if (knobs().bf_b16 && ix->dim <= 112) { // f32 rows on the bf16 matrix path, three instructions per product (brute_force.h)
+        R = 4;
+        fn = bf_b16_kernel<7, 4>;
+        fn_prime = bf_b16_kernel<7, 4, true>;
+        lds = 2u * 32u * R * (2u * 16u * 7u + 16u);
+    } else if (knobs().bf_b16 && ix->dim <= 208) {
+        R = 2;
+        fn = bf_b16_kernel<13, 2>;
+        fn_prime = bf_b16_kernel<13, 2, true>;
+        lds = 2u * 32u * R * (2u * 16u * 13u + 16u);
+    } else if (knobs().bf_b16) {
+        R = 1;
+        fn = bf_b16_kernel<16, 1>;
+        fn_prime = bf_b16_kernel<16, 1, true>;
+        lds = 2u * 32u * R * (2u * 16u * 16u + 16u);
     } else if (ix->dim <= 104) {
         R = 4;
         fn = bf_f32_kernel<52, 4>;

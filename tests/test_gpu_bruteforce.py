@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 from tests.conftest import random_floats  # noqa: E402
 
-TOL = 2e-6  # |distance(returned j-th) - distance(true j-th)|: an f32 dot over <= 256 terms of magnitude <= 1
+TOL = 2e-6  # int8 rows (exact integer dots; an f32 dot over <= 256 terms of magnitude <= 1): |distance(returned j-th) - distance(true j-th)|
+TOL_F32 = 4e-5  # f32 rows are scored as two bf16 pieces each (three matrix instructions per product, brute_force.h): what is dropped is below 2^-15 of |x||q| per product
 
 
 def exact_topk(oracle, el, q, k):
@@ -46,11 +47,12 @@ def test_brute_force_matches_a_scalar_scan(oracle, int8, dim, n):
             keys = list(zip(ds[qi].tolist(), ids[qi].tolist()))
             assert keys == sorted(keys) and len(set(ids[qi].tolist())) == k
         # and they are the k smallest up to the MFMA's rounding
-        assert np.abs(ds - want_d).max() <= TOL
+        tol = TOL if int8 else TOL_F32
+        assert np.abs(ds - want_d).max() <= tol
         same = (ids == want_i.astype(np.uint64))
         assert same.mean() > 0.98  # ties / near-ties only
         for qi, j in zip(*np.nonzero(~same)):
-            assert abs(float(ds[qi, j]) - float(want_d[qi, j])) <= TOL
+            assert abs(float(ds[qi, j]) - float(want_d[qi, j])) <= tol
 
 
 @pytest.mark.parametrize("int8,dim,n,nq", [(True, 100, 300_000, 300), (False, 100, 300_000, 70), (False, 200, 150_000, 40),
@@ -76,11 +78,12 @@ def test_primed_scan_with_the_shared_threshold_matches_the_scalar_scan(oracle, i
         assert (cnt == k).all()
         live = np.ones(nq, bool)
         live[6] = False
-        assert np.abs(ds[live] - want_d[live]).max() <= TOL
+        tol = TOL if int8 else TOL_F32
+        assert np.abs(ds[live] - want_d[live]).max() <= tol
         same = ids[live] == want_i[live]
         assert same.mean() > 0.98
         for qi, j in zip(*np.nonzero(~same)):
-            assert abs(float(ds[live][qi, j]) - float(want_d[live][qi, j])) <= TOL
+            assert abs(float(ds[live][qi, j]) - float(want_d[live][qi, j])) <= tol
         for qi in (0, 5, nq - 1):  # the reference's distances for the returned ids
             got = np.array([oracle.dist(el[int(e)], q[qi]) for e in ids[qi]], np.float32)
             assert got.tobytes() == ds[qi].tobytes()

@@ -5,7 +5,7 @@ lines = []
 # bench.py also walks its timed batches once with the exact visited tables (the counting pass: fast_kernel<.., 1> / <.., 2>);
 # the launches summarised here are the timed form's (fast_kernel<.., 3>: no visited set) whenever the trace holds any
 import re
-TIMED_RE = re.compile(r"(false|true), [34](, (false|true))?>")  # V16 = 3 / 4: no visited set
+TIMED_RE = re.compile(r"(false|true), [345](, (false|true))?>")  # V16 = 3 / 4 / 5: no visited set (5: revisits skipped before their rows are fetched)
 # the launches of interest by their walker count: PROF_WALKERS walker blocks + up to 64 tail blocks, 64 threads each
 # (default: one batch of 1024; round 4's timed shape is --steps x 1024 walkers in one launch, shards 10 x 4096)
 WALKERS = int(os.environ.get("PROF_WALKERS", "1024"))
