@@ -350,8 +350,12 @@ __global__ __launch_bounds__(BF_THREADS) void bf_f32_kernel(const BruteParams P)
 // KG = groups of 8 components per lane half (the two halves of the wave take the two halves of the vector: 16 KG >= dim).
 typedef __bf16 bf_b16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf_b16x4 __attribute__((ext_vector_type(4)));
+// (Blocks of 256 threads -- two per CU with barriers of their own, so that one block's conversion runs under the other's
+// matrix instructions -- were tried: 11.2 ms where the block of eight waves takes 7.3; every block converts and stores the
+// whole tile, and eight blocks instead of four stream every range.)
+constexpr uint32_t BF_B16_THREADS = 512, BF_B16_QT = 256;
 template <int KG, int R, bool PRIME = false>
-__global__ __launch_bounds__(BF_THREADS) void bf_b16_kernel(const BruteParams P) {
+__global__ __launch_bounds__(BF_B16_THREADS) void bf_b16_kernel(const BruteParams P) {
     extern __shared__ __align__(16) uint8_t smem_bf[];
     constexpr uint32_t ET = 32u * R;                // elements per tile
     constexpr uint32_t COMPS = 16u * KG;            // components per (zero padded) row
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(BF_THREADS) void bf_b16_kernel(const BruteParams P)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, h = lane >> 5;
     const BfBlock blk = bf_block();
-    const uint32_t q = blk.qt * BF_QT + wave * 32u + col;
+    const uint32_t q = blk.qt * BF_B16_QT + wave * 32u + col;
     const bool qlive = q < P.nq;
 
     // the lane's half of its query as bf16 pieces, in registers for the whole scan
@@ -389,12 +393,12 @@ __global__ __launch_bounds__(BF_THREADS) void bf_b16_kernel(const BruteParams P)
     const uint64_t r1 = r0 + P.per_range < P.n ? r0 + P.per_range : P.n;
     const uint32_t row_f4 = P.row_bytes / 16u;      // float4 units of a device row that hold data
     constexpr uint32_t UNITS = COMPS / 4u;          // float4 units per (padded) row
-    constexpr uint32_t NPF = (ET * UNITS + BF_THREADS - 1u) / BF_THREADS;
+    constexpr uint32_t NPF = (ET * UNITS + BF_B16_THREADS - 1u) / BF_B16_THREADS;
     float4 pf[NPF];
     auto fetch = [&](uint64_t e0) {
 #pragma unroll
         for (uint32_t j = 0; j < NPF; ++j) {
-            const uint32_t u = tid + BF_THREADS * j;
+            const uint32_t u = tid + BF_B16_THREADS * j;
             const uint32_t row = u / UNITS, c4 = u - row * UNITS;
             pf[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (u < ET * UNITS && e0 + row < r1 && c4 < row_f4)
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(BF_THREADS) void bf_b16_kernel(const BruteParams P)
         __syncthreads(); // the previous tile has been consumed
 #pragma unroll
         for (uint32_t j = 0; j < NPF; ++j) { // split into the two pieces on the way to LDS
-            const uint32_t u = tid + BF_THREADS * j;
+            const uint32_t u = tid + BF_B16_THREADS * j;
             const uint32_t row = u / UNITS, c4 = u - row * UNITS;
             if (u < ET * UNITS) {
                 bf_b16x4 hi, lo;
@@ -427,17 +431,26 @@ __global__ __launch_bounds__(BF_THREADS) void bf_b16_kernel(const BruteParams P)
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[r][v] = 0.0f;
+        // the fragments of the next (step, block) are read while the matrix cores work on this one (left alone the scheduler
+        // sinks every read to just before its instruction, and each waits for LDS; a whole step ahead -- 2 x R fragments of
+        // each piece -- spilled: 10.1 ms where this takes less)
+        const size_t off0 = (size_t)col * STRIDE_B + (size_t)h * 16u * KG;
+        bf_b16x8 ah[2], al[2];
+        ah[0] = *reinterpret_cast<const bf_b16x8*>(tile_hi + off0);
+        al[0] = *reinterpret_cast<const bf_b16x8*>(tile_lo + off0);
 #pragma unroll
-        for (int g = 0; g < KG; ++g) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const size_t off = (size_t)(r * 32 + col) * STRIDE_B + (h * 8u * KG + (uint32_t)g * 8u) * 2u;
-                const bf_b16x8 ah = *reinterpret_cast<const bf_b16x8*>(tile_hi + off);
-                const bf_b16x8 al = *reinterpret_cast<const bf_b16x8*>(tile_lo + off);
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[g], acc[r], 0, 0, 0);
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[g], acc[r], 0, 0, 0);
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[g], acc[r], 0, 0, 0);
+        for (int i = 0; i < KG * R; ++i) {
+            const int g = i / R, r = i % R;
+            if (i + 1 < KG * R) {
+                const int gn = (i + 1) / R, rn = (i + 1) % R;
+                ah[(i + 1) & 1] = *reinterpret_cast<const bf_b16x8*>(tile_hi + off0 + (size_t)rn * 32u * STRIDE_B + (size_t)gn * 16u);
+                al[(i + 1) & 1] = *reinterpret_cast<const bf_b16x8*>(tile_lo + off0 + (size_t)rn * 32u * STRIDE_B + (size_t)gn * 16u);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], qh[g], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], ql[g], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], qh[g], acc[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // result block r: acc[r][v] ~ dot(element e0 + r*32 + 8*(v/4) + 4*h + v%4, query `col` of this wave)
         const bool whole = e0 + ET <= r1;

@@ -1643,7 +1643,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     const uint64_t n = ix->n_elements;
     const uint32_t kk = k + BF_EXTRA < BF_KMAX ? k + BF_EXTRA : BF_KMAX;
     // element ranges: the lists of up to 64 ranges are merged; a range is a whole number of tiles
-    uint32_t R = 4, lds = 0;
+    uint32_t R = 4, lds = 0, qt = BF_QT, threads = BF_THREADS;
     void (*fn)(const BruteParams) = nullptr;
     void (*fn_prime)(const BruteParams) = nullptr; // the same scan keeping only the best score per (range, query)
     if (ix->dtype == GRANNE_HIP_I8) {
@@ -1656,16 +1656,19 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         fn = bf_b16_kernel<7, 4>;
         fn_prime = bf_b16_kernel<7, 4, true>;
         lds = 2u * 32u * R * (2u * 16u * 7u + 16u);
+        qt = BF_B16_QT, threads = BF_B16_THREADS;
     } else if (knobs().bf_b16 && ix->dim <= 208) {
         R = 2;
         fn = bf_b16_kernel<13, 2>;
         fn_prime = bf_b16_kernel<13, 2, true>;
         lds = 2u * 32u * R * (2u * 16u * 13u + 16u);
+        qt = BF_B16_QT, threads = BF_B16_THREADS;
     } else if (knobs().bf_b16) {
         R = 1;
         fn = bf_b16_kernel<16, 1>;
         fn_prime = bf_b16_kernel<16, 1, true>;
         lds = 2u * 32u * R * (2u * 16u * 16u + 16u);
+        qt = BF_B16_QT, threads = BF_B16_THREADS;
     } else if (ix->dim <= 104) {
         R = 4;
         fn = bf_f32_kernel<52, 4>;
@@ -1754,7 +1757,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         Gs = (Q.n + Q.per_range - 1) / Q.per_range;
         if (Gs >= kk) {
             if (lds > 64u * 1024u) HIP_TRY(hipFuncSetAttribute((const void*)fn_prime, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fn_prime, dim3((nq + BF_QT - 1) / BF_QT, (uint32_t)Gs), dim3(BF_THREADS), lds, s, Q);
+            hipLaunchKernelGGL(fn_prime, dim3((nq + qt - 1) / qt, (uint32_t)Gs), dim3(threads), lds, s, Q);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(bf_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, (const float*)P.part_d, (uint32_t)Gs, nq, kk,
                                (float*)(scratch + o_tau));
@@ -1765,7 +1768,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
             P.share_hist = (uint32_t*)(scratch + o_share);
         }
     }
-    hipLaunchKernelGGL(fn, dim3((nq + BF_QT - 1) / BF_QT, (uint32_t)G), dim3(BF_THREADS), lds, s, P);
+    hipLaunchKernelGGL(fn, dim3((nq + qt - 1) / qt, (uint32_t)G), dim3(threads), lds, s, P);
     HIP_TRY(hipGetLastError());
     int rc = merge_launch((const uint8_t*)P.part_ids, (const uint8_t*)P.part_d, (const uint8_t*)P.part_c, (uint64_t)nq * kk * 8,
                           (uint64_t)nq * kk * 4, (uint64_t)nq * 4, zeros, (uint32_t)G, nq, kk, (uint64_t*)(scratch + o_mid),
