@@ -18,8 +18,9 @@
 //            the reference's arithmetic, bit for bit -- and the k best by (distance, id) are returned. Distances are
 //            therefore the reference's; the id SET can differ from a scalar scan only where two elements' distances to
 //            the query differ by less than the MFMA's rounding (~1e-6) at the k + BF_EXTRA boundary.
-// Roofline: f32 is MFMA-bound (2 * nq * n * dim flops at 157 TFLOP/s dense f32: 13 ms for 1024 x 10M x 100), int8 is
-// HBM-bound. bench.py reports the achieved rate; profiles/ holds the MFMA-busy counter.
+// Roofline: the f32 FORM is MFMA-bound (2 * nq * n * dim flops at 157 TFLOP/s dense f32: 13 ms for 1024 x 10M x 100; 17 ms
+// measured); f32 rows are scored on the bf16 matrix path since round 6 (bf_b16_kernel: 6.6 ms); int8 is HBM-bound.
+// bench.py reports the achieved rate; profiles/ holds the MFMA-busy counter.
 #pragma once
 
 #include "util_kernels.h"
