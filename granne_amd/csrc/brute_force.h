@@ -353,7 +353,9 @@ typedef __bf16 bf_b16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf_b16x4 __attribute__((ext_vector_type(4)));
 // (Blocks of 256 threads -- two per CU with barriers of their own, so that one block's conversion runs under the other's
 // matrix instructions -- were tried: 11.2 ms where the block of eight waves takes 7.3; every block converts and stores the
-// whole tile, and eight blocks instead of four stream every range.)
+// whole tile, and eight blocks instead of four stream every range. Two tiles in LDS with the next tile's conversion
+// interleaved into the matrix loop, one barrier per tile: 7.2 ms where this form takes 6.6 -- the conversion then waits
+// for the tile's loads inside the loop, and a second set of load registers does not fit.)
 constexpr uint32_t BF_B16_THREADS = 512, BF_B16_QT = 256;
 template <int KG, int R, bool PRIME = false>
 __global__ __launch_bounds__(BF_B16_THREADS) void bf_b16_kernel(const BruteParams P) {
