@@ -783,14 +783,16 @@ static search_fn pick_fast_s(uint32_t S, bool trail, int v16) {
     default:
         if constexpr ((DT == DT_F32 && DIM == 0) || (DT == DT_I8 && DIM >= 256)) {
             // streamed f32 dims and int8 rows of 256 / 512 bytes: lists of up to 17 x 64 keys (max_search 1024)
-            return v16 >= 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
+            if constexpr (walk_list_is_long(17, false)) return fast_kernel<DT, DIM, 17, false, 3>; // (a two-level list: no exact set)
+            else return v16 >= 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
         } else {
             // lists of 33 / 65 slots (max_search up to 2048 / 4096) exist without a visited set only: plan_launch sends
             // such a search there whatever the option says (an exact set of ~40 x max_search ids fits no LDS)
             if (S == 33) return fast_kernel<DT, DIM, 33, false, 3>;
             if (S == 65) return fast_kernel<DT, DIM, 65, false, 3>;
             if (S == 129) return fast_kernel<DT, DIM, 129, false, 3>;
-            return v16 >= 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
+            if constexpr (walk_list_is_long(17, false)) return fast_kernel<DT, DIM, 17, false, 3>;
+            else return v16 >= 3 ? fast_kernel<DT, DIM, 17, false, 3> : fast_kernel<DT, DIM, 17>;
         }
     }
 }
@@ -861,7 +863,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
     // table in LDS + a global overflow table): n_dist is then the reference's count of distinct evaluated nodes.
     const int vmode = ix->opt_visited16 ? ix->opt_visited16 : knobs().visited;
     const bool none = vmode == 4 || vmode == 0;
-    const bool longest = fastS >= 33 || fast_wide(ix); // (lists of 33 / 65 slots, and 64-id layers: instantiated without a set only, whatever the options say)
+    const bool longest = walk_list_is_long((int)fastS, fast_wide(ix)) || fast_wide(ix); // (lists of 33 / 65 slots, and 64-id layers: instantiated without a set only, whatever the options say)
     if (fastS >= 1 && !trail && ((none && !ix->opt_visited_slots) || longest) && ix->n_elements <= WALK_MAX_ELEMENTS) { // (fast_shape's bound)
         // a launch of a few queries leaves the chip idle: its walkers touch the next node's rows ahead (walk_fast.h, TOUCH)
         const uint32_t touch_max = knobs().touch_max >= 0 ? (uint32_t)knobs().touch_max : 256u; // (round 5: +4 % at 256 queries, -10 % at 1024: profiles/r5_touch.txt)
@@ -877,7 +879,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         P.lrow_bytes = 16;
         P.stage_bytes = 0;
         P.adjspec_bytes = 0;
-        P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, 0u, P.v16 == 5);
+        P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, 0u, P.v16 == 5, fast_wide(ix));
         const uint32_t least = lds_query_bytes(ix->row_bytes) + 64u * 8u; // int8 query staging; a tail block (slow_kernel.h)
         if (P.lds_bytes < least) P.lds_bytes = least;
         return P;
@@ -909,7 +911,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         P.lrow_bytes = 16;
         P.stage_bytes = 0;
         P.adjspec_bytes = 0;
-        P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, P.visited_slots);
+        P.lds_bytes = fast_lds_bytes(ix->dtype == GRANNE_HIP_I8, fast_generic(ix), ix->dim, ix->row_bytes, fastS, P.visited_slots, false, fast_wide(ix));
         return P;
     }
     // the general walker (search_kernel.h): int8 keeps its speculative adjacency rows in registers (Walker::REGSPEC),

@@ -109,12 +109,18 @@ __device__ __forceinline__ uint32_t from_prev_lane_or_zero(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 }
 
-template <int S>
+// From how many slots on a list is the two-level list of FastWalker::search_layer_long (M in LDS only, F in registers).
+#ifndef GRANNE_HIP_LONG_MIN
+#define GRANNE_HIP_LONG_MIN 33
+#endif
+constexpr bool walk_list_is_long(int S, bool wide) { return S >= GRANNE_HIP_LONG_MIN && !wide; } // (layers of 64 ids: two passes per expansion, the short lists only)
+
+template <int S, bool LONGF = walk_list_is_long(S, false)>
 struct WalkList : SortedList<S> {
     using SortedList<S>::key;
     static constexpr uint32_t CAP = 64u * S;
 
-    static constexpr bool LONG = S >= 33; // lists beyond 1024 keys live in LDS only (FastWalker::search_layer_long): `key` stays unused
+    static constexpr bool LONG = LONGF; // the two-level lists live in LDS only (FastWalker::search_layer_long): `key` stays unused
     // position of the first entry whose expanded flag is clear (KEY_INF has it set)
     __device__ __forceinline__ bool first_unexpanded(uint32_t& pos) const {
 #pragma unroll
@@ -140,7 +146,7 @@ struct WalkList : SortedList<S> {
     // the registers means selecting a register by a run-time slot: short lists do it with a tree of uniform branches (two
     // readlanes at the leaf), lists of S >= 8 read the image: one broadcast ds_read instead of 4*S scalar selects.
     static constexpr bool MIRROR = S >= 8;
-    static constexpr uint32_t IMAGE_KEYS = CAP + (S >= 33 ? 0u : 32u);
+    static constexpr uint32_t IMAGE_KEYS = CAP + (LONG ? 0u : 32u);
     uint64_t* mir;
     template <int LO, int HI>
     __device__ __forceinline__ uint64_t get_rec(uint32_t slot, uint32_t l) const {
@@ -259,7 +265,8 @@ struct FastWalker {
     static constexpr uint32_t XTAILB = (uint32_t)TU * 16u;
     static_assert(F32 || DIM == 0 || DIM == 256 || DIM == 512, "fast int8 rows: 128, 256 or 512 bytes");
     static constexpr uint32_t CAP = 64u * S;
-    static constexpr bool LONG_LIST = S >= 33;
+    using List = WalkList<S, walk_list_is_long(S, WIDE)>;
+    static constexpr bool LONG_LIST = List::LONG;
     static constexpr int NT = ROWB ? (int)((ROWB + 255u) / 256u) : 1; // TOUCH: lines of a row per lane of its pair
     static_assert(!F32 || GEN || (DIM % 4 == 0 && DIM >= 32), "fast f32 rows: dim a multiple of 4, at least one chunk");
 
@@ -291,7 +298,7 @@ struct FastWalker {
     static_assert(!WIDE || V16 == 3, "layers of 64 ids: walked without a visited set only");
     static_assert(V16 == 0 || V16 == 3 || V16 == 4 || V16 == 5, "the exact 32-bit table, or no visited set (4: + rows touched ahead, 5: + revisits skipped before their rows are fetched)");
     typename std::conditional<V16 == 0, VisitedSet, VisitedNone>::type vis;
-    WalkList<S> L;
+    List L;
     WalkStats st;
     bool bail;
     uint32_t theta; // distance bits of list entry max_search-1 (0xFFFFFFFF while the list is shorter): kept by insert()
@@ -312,14 +319,14 @@ struct FastWalker {
         lds_q = smem;
         mslot = reinterpret_cast<uint64_t*>(smem + qb);
         // [query][the list's image (lists beyond 1024 keys: M)][those lists: F's image][the cache of entered ids][visited]
-        fimg = reinterpret_cast<uint64_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u);
-        vcache = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u + (LONG_LIST ? FIMG_KEYS * 8u : 0u));
+        fimg = reinterpret_cast<uint64_t*>(smem + qb + List::IMAGE_KEYS * 8u);
+        vcache = reinterpret_cast<uint32_t*>(smem + qb + List::IMAGE_KEYS * 8u + (LONG_LIST ? FIMG_KEYS * 8u : 0u));
         fkey = KEY_INF;
         nF = nM = 0;
         m_un = 0;
         m_un_key = KEY_INF;
         lost_bits = 0xFFFFFFFFu;
-        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + WalkList<S>::IMAGE_KEYS * 8u + (LONG_LIST ? FIMG_KEYS * 8u : 0u) + VSLOTS * 4u);
+        vis_tab = reinterpret_cast<uint32_t*>(smem + qb + List::IMAGE_KEYS * 8u + (LONG_LIST ? FIMG_KEYS * 8u : 0u) + VSLOTS * 4u);
         st.n_dist = st.n_expand = st.n_adj = 0;
         bail = false;
         sy = 0.0f;
@@ -550,7 +557,7 @@ struct FastWalker {
     //           PLACE from the top down (a window's shift is uniform except where an F entry's rank falls into it), F's
     //           entries written last. What falls off M's end is dead unless the closest of it ties with theta after the
     //           expansion's inserts: then the walk is handed to the exact walker, as with the short lists.
-    static constexpr bool LONG = WalkList<S>::LONG;
+    static constexpr bool LONG = List::LONG;
     static constexpr int LONG_STEPS = CAP >= 4096u ? 7 : 6; // steps of the 4-ary lower bound over CAP + 1 outcomes (worst case, by simulation: 2112 -> 6, 4160 / 8256 -> 7)
     static constexpr uint32_t FCAP = 63u;       // keys F may hold (a split of the union takes 0..63 of them: one per lane)
     static constexpr uint32_t FIMG_KEYS = 128u; // F's image: 64 entries + up to 32 candidates, padded
@@ -1456,7 +1463,7 @@ constexpr int fast_waves_per_simd(int DT, int DIM, int S, bool WIDE = false) {
     // lists of 2112 / 4160 keys: 2 registers per 64 keys + the merge's bookkeeping; 17 / 33 KB of LDS mirror each. Two
     // walkers per SIMD for the 33-slot lists (256 registers: measured 137 k against 97 k queries/s at max_search 1600 when the
     // allocation crept to 259), one for the 65-slot ones
-    if (S >= 33) return 2; // the two-level lists (M in LDS only): 17 / 33 / 66 KB of LDS each bound the walkers per CU before the registers do
+    if (walk_list_is_long(S, WIDE)) return S >= 33 ? 2 : 3; // the two-level lists (M in LDS only): 17 / 33 / 66 KB of LDS each bound the walkers per CU before the registers do (17 slots: 9 KB)
     if (DT == DT_I8 && DIM >= 256) return DIM == 256 ? 3 : 2; // 2 / 4 blocks of row data and of query per lane
     if (DT == DT_I8) return S == 1 ? 5 : S <= 4 ? 4 : S == 8 ? 3 : 2;
     if (DIM == 0) return 2; // the streamed walker keeps a group of chunks, the tail and the accumulators: ~210 VGPRs
@@ -1477,10 +1484,11 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(DT, DIM, S, WIDE)) void fas
     }
 }
 
-__host__ __device__ inline uint32_t fast_lds_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots, bool seen = false) {
+__host__ __device__ inline uint32_t fast_lds_bytes(bool i8, bool gen, uint32_t dim, uint32_t row_bytes, uint32_t S, uint32_t visited_slots, bool seen = false, bool wide = false) {
+    const bool lng = walk_list_is_long((int)S, wide);
     // [query][the list's image][lists of up to 17 slots: the cache of entered ids][visited]
     // (lists beyond 1024 keys: M's image, then F's of 128 keys)
-    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (64u * S + (S >= 33u ? 0u : 32u)) * 8u + (S >= 33u ? 128u * 8u : 0u) + (seen ? VCACHE_SLOTS_SEEN : VCACHE_SLOTS) * 4u + visited_slots * 4u;
+    return fast_query_bytes(i8, gen, dim, row_bytes, S) + (64u * S + (lng ? 0u : 32u)) * 8u + (lng ? 128u * 8u : 0u) + (seen ? VCACHE_SLOTS_SEEN : VCACHE_SLOTS) * 4u + visited_slots * 4u;
 }
 
 } // namespace granne_hip
