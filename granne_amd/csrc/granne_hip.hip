@@ -313,7 +313,22 @@ static int make_inline_tails(granne_hip_index* ix, hipStream_t s) {
     for (auto& L : ix->layers) {
         L.adjx_stride = 128u + 32u * tu * 16u;
         const size_t bytes = (size_t)L.len * L.adjx_stride;
-        HIP_TRY(hipMalloc((void**)&L.d_adjx, bytes ? bytes : 16));
+        if (hipMalloc((void**)&L.d_adjx, bytes ? bytes : 16) != hipSuccess) {
+            // The copy is an accelerator, not part of the index: an index that fits without it (a 200M x 100-d shard: 128 GB
+            // of copy) is made without it -- the walkers then read the tails from the rows' own last line.
+            (void)hipGetLastError();
+            L.d_adjx = nullptr;
+            for (auto& M : ix->layers) {
+                if (M.d_adjx) {
+                    (void)hipStreamSynchronize(s);
+                    (void)hipFree(M.d_adjx);
+                    ix->hbm_bytes -= (uint64_t)M.len * M.adjx_stride;
+                    M.d_adjx = nullptr;
+                }
+                M.adjx_stride = 0;
+            }
+            return GRANNE_HIP_OK;
+        }
         ix->hbm_bytes += bytes;
         if (L.len)
             hipLaunchKernelGGL(inline_tails_kernel, dim3(grid_for(L.len * 32u * (1u + tu), 256)), dim3(256), 0, s, L.d_adj,

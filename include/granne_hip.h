@@ -505,7 +505,8 @@ enum {
                                          lines only -- three per 100-d neighbor instead of four. Costs 128 + 32 x tail bytes
                                          per node and layer (6.9 GB at 10M x 100-d) of HBM; results are the same bits.
                                          1 = keep it [default], 0 = drop it (the tails are read from the rows). Setting it
-                                         (re)makes or frees the copy: not while a search of the index is running.
+                                         (re)makes or frees the copy: not while a search of the index is running. An index
+                                         whose copy does not fit in HBM is made without it (no error).
                                          get_option returns 1 only when the index actually holds the copy */
     GRANNE_HIP_OPT_SEEN_MIN = 11      /* f32 walks of max_search up to 252 on layers of 32 ids: launches of at least this many
                                          walks (queries x batches) consult a cache of the ids the walk has EVALUATED before
