@@ -1508,6 +1508,15 @@ def _finite(o):
     return o
 
 
+def _oracle_match(g):
+    """bit-exactness from a record's `gpu_matches_oracle`, in either of its two forms: one index (ids and distance bits) or a
+    partitioned one (every shard against the oracle + the merged result against the numpy merge of the ORACLE's results)"""
+    g = g or {}
+    if "ids_bit_exact" in g:
+        return bool(g.get("ids_bit_exact") and g.get("dists_bit_exact"))
+    return bool(g.get("those_shards_bit_exact_on_every_rank") and g.get("merged_equals_numpy_merge_of_ORACLE_shard_results"))
+
+
 def _compact_roofline(r):
     if not isinstance(r, dict):
         return r
@@ -1537,8 +1546,7 @@ def _compact_cpu(cb):
         c["thread_sweep"] = {str(t["threads"]): t["value"] for t in cb["thread_sweep"]}
     c["sample"] = _short(cb.get("sample", ""), 200)
     g = cb.get("gpu_matches_oracle") or {}
-    c["gpu_matches_oracle"] = {"bit_exact": bool(g.get("ids_bit_exact") and g.get("dists_bit_exact")),
-                               "queries": g.get("queries_checked")}
+    c["gpu_matches_oracle"] = {"bit_exact": _oracle_match(g), "queries": g.get("queries_checked")}
     return c
 
 
@@ -1567,7 +1575,7 @@ def _compact_sub(rec):
         g = cb.get("gpu_matches_oracle") or {}
         c["cpu"] = cb.get("value")
         c["cpu_cores"] = cb.get("cores")
-        c["bit_exact"] = bool(g.get("ids_bit_exact") and g.get("dists_bit_exact"))
+        c["bit_exact"] = _oracle_match(g)
         c["checked"] = g.get("queries_checked")
     return c
 

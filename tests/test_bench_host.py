@@ -217,3 +217,19 @@ def test_the_line_of_an_n_gpu_run_carries_roofline_and_cpu_baseline():
 def test_the_secondary_generators_are_named_in_their_labels():
     mix = bench.workload_label(10_000_000, 100, "f32", "mixture", 1024, 100, 10)
     assert "mixture of %d Gaussians" % bench.MIX_CENTERS in mix and not mix.startswith("C2")
+
+
+def test_compact_line_reads_both_forms_of_the_parity_record():
+    """`gpu_matches_oracle` of one index (ids + distance bits) and of a partitioned run (every shard + the merged result):
+    the compact line's `bit_exact` must say true for both when they are (round 6: the partitioned form read as false)."""
+    one = {"ids_bit_exact": True, "dists_bit_exact": True, "queries_checked": 16}
+    part = {"shards_checked_against_oracle_per_rank": 4, "those_shards_bit_exact_on_every_rank": True,
+            "merged_equals_numpy_merge_of_shard_results": True, "merged_equals_numpy_merge_of_ORACLE_shard_results": True,
+            "queries_checked": 4096}
+    assert bench._oracle_match(one) and bench._oracle_match(part)
+    assert not bench._oracle_match(dict(one, dists_bit_exact=False))
+    assert not bench._oracle_match(dict(part, merged_equals_numpy_merge_of_ORACLE_shard_results=False))
+    assert not bench._oracle_match({})
+    cb = {"value": 1.0, "unit": "queries/s", "cores": 16, "kind": "port", "sample": "s", "gpu_matches_oracle": part}
+    assert bench._compact_cpu(cb)["gpu_matches_oracle"] == {"bit_exact": True, "queries": 4096}
+    assert bench._compact_sub({"workload": "w", "value": 1.0, "cpu_baseline": cb})["bit_exact"] is True
