@@ -983,9 +983,7 @@ def rank0_after_the_timed_region(B, args, out, index, builder, elements, queries
             bf = {}
             gt = B.ground_truth(index, queries[b0 * nq:(b0 + 1) * nq], k, args.dtype, timing=bf)
             out["brute_force"] = bf
-            got = m["ids"][b0]
-            if order is not None:  # ground truth is in build ids, results in reordered ids
-                got = torch.from_numpy(order.astype(np.int64)).cuda()[got.clamp_min(0)]
+            got = m["ids"][b0]  # (after --reorder both the scan's and the walk's ids are the reordered index's)
             out["recall_at_10"] = round(B.recall(gt, got, k), 4)
             efs = [int(x) for x in args.sweep_ef.split(",") if x]
             if plan["ef_sweep"] and efs and order is None:
