@@ -194,13 +194,24 @@ class Bench:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         # GRANNE_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-reduce) with one rank
         self.use_dist = self.world > 1 or bool(os.environ.get("GRANNE_BENCH_FORCE_DIST"))
+        # GRANNE_BENCH_BACKEND=gloo: the ranks of an N > 1 run SHARE the devices that exist (rank r on device r % count) and
+        # talk over gloo -- a LOGIC test of the N-rank control flow on a box with fewer GPUs (rendezvous, barriers, the maximum
+        # over ranks, rank 0's extras while the others wait, the line); RCCL refuses two ranks on one device. Never a measurement:
+        # the line says so (`shared_devices`).
+        self.backend = os.environ.get("GRANNE_BENCH_BACKEND", "nccl")
+        self.shared_devices = self.backend != "nccl" and self.world > torch.cuda.device_count()
+        if self.backend != "nccl":
+            self.local_rank %= max(1, torch.cuda.device_count())
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             os.environ.setdefault("RANK", str(self.rank))
             os.environ.setdefault("WORLD_SIZE", str(self.world))
             torch.cuda.set_device(self.local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend=self.backend)
         if args.gpus != self.world and self.rank == 0:
             log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, self.world))
         torch.cuda.set_device(self.local_rank)
@@ -364,7 +375,7 @@ class Bench:
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if contract and self.use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)  # MAX over ranks
             elapsed = float(t.item())
         if int(status[0].item()) != 0:
@@ -949,6 +960,9 @@ def run_replica(B, args):
         "roofline": B.roofline(m, wl_key, value / world, nq),
         "kernel_sources_sha": csrc_sha(),
     }
+    if getattr(B, "shared_devices", False):
+        out["shared_devices"] = ("LOGIC TEST, not a measurement: %d ranks share %d device(s) over %s (GRANNE_BENCH_BACKEND)"
+                                 % (world, torch.cuda.device_count(), B.backend))
 
     # ---- the partitioned exchange over RCCL as a sub-record: with ONE rank (--force-partitioned) here, in the line; with
     # N > 1 ranks only after the line is out (main, partitioned_after_the_line) -- a collective that one rank fails to
@@ -1581,7 +1595,7 @@ def _compact_sub(rec):
 def compact_line(out, extras_path=None):
     """The ONE stdout line: the contract's keys, `config`, `roofline`, `cpu_baseline` and a few figures per sub-record,
     under LINE_LIMIT bytes whatever the full record holds (which goes to bench_extras.json and stderr)."""
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+    keep = ("metric", "value", "unit", "n_gpus", "shared_devices", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "batches_per_call", "library_calls", "inflight_batches", "slow_path_queries", "recall_at_10",
             "speedup_vs_cpu", "kernel_sources_sha")
     line = _pick(out, keep)
