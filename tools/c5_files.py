@@ -7,7 +7,7 @@ and searched as one partitioned index (ef_search 200, batches of 4096).
   python tools/c5_files.py --shards 8            # the whole 1B job on one GPU (265 GB of 288)
 
 Results are compared with those of the same shard while it was the builder's in-memory index (whose equality with the CPU
-oracle bench.py's c5_shard record checks). Appends one JSON object per stage to gpurun_out/r5_c5_files.jsonl."""
+oracle bench.py's c5_shard record checks). Appends one JSON object per stage to gpurun_out/r6_c5_files.jsonl."""
 import argparse
 import json
 import os
@@ -38,7 +38,7 @@ from granne_amd import sharded  # noqa: E402
 from oracle.merge import merge_topk_numpy  # noqa: E402
 
 os.makedirs(a.dir, exist_ok=True)
-OUT = os.path.join(ROOT, "gpurun_out", "r5_c5_files.jsonl")
+OUT = os.path.join(ROOT, "gpurun_out", "r6_c5_files.jsonl")
 os.makedirs(os.path.dirname(OUT), exist_ok=True)
 
 
