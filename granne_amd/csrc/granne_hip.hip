@@ -781,7 +781,7 @@ static search_fn pick_fast_v(int v16) {
     if constexpr (S == 1 && !(DT == DT_F32 && DIM == 0) && !(DT == DT_I8 && DIM >= 256)) {
         if (v16 == 4) return fast_kernel<DT, DIM, S, false, 4>; // no visited set + rows touched ahead (few queries)
     }
-    if constexpr (DT == DT_F32 && DIM != 0 && S <= 4) {
+    if constexpr (DT == DT_F32 && S <= 4) {
         if (v16 == 5) return fast_kernel<DT, DIM, S, false, 5>; // no visited set + revisits skipped before their rows are fetched (many walks)
     }
     if (v16 >= 3) return fast_kernel<DT, DIM, S, false, 3>;
@@ -888,7 +888,7 @@ static LaunchPlan plan_launch(const SearchTarget* ix, uint32_t ef, uint32_t nq, 
         const uint64_t seen_min = knobs().seen_min >= 0 ? (uint64_t)knobs().seen_min : ix->opt_seen_min; // (GRANNE_HIP_SEEN_MIN overrides the option: experiments)
         // (f32 rows: the walkers per CU are bound by registers there, 8 KB of cache each fit; int8 walkers are four times as many
         //  and lose more to the look-up than the few revisits of their rows cost: measured, profiles/r6_seen_ab.txt)
-        if (fastS <= 4 && !fast_wide(ix) && !fast_generic(ix) && ix->dtype == GRANNE_HIP_F32 && nq >= seen_min) P.v16 = 5;
+        if (fastS <= 4 && !fast_wide(ix) && ix->dtype == GRANNE_HIP_F32 && nq >= seen_min) P.v16 = 5; // (every f32 dim: unrolled and streamed)
         P.visited_slots = P.upper_slots = 0;
         P.maxc = 0;
         P.lrow_bytes = 16;

@@ -1186,7 +1186,13 @@ struct FastWalker {
             if constexpr (SEEN) {
                 const bool seen = vcache[vcache_slot(nb)] == nb; // (the entry point is in the cache; UNUSED never is)
                 seenm = wave_ballot(seen);
-                if (!seen && nb != ID_EMPTY) { // rows of new ids only: a revisit's -- and an empty pair's -- loads are not issued
+                if constexpr (GEN) {
+                    // the streamed walker loads a row's later chunks inside finish_rows, for every lane: a revisit's and an
+                    // empty pair's lanes follow the first NEW neighbor's row instead (lines that pair fetches anyway)
+                    const uint64_t newm = wave_ballot(!seen && nb != ID_EMPTY);
+                    const uint32_t fill = newm ? readlane32(nb, (uint32_t)__builtin_ctzll(newm)) : xid;
+                    issue_rows((!seen && nb != ID_EMPTY) ? nb : fill, rr);
+                } else if (!seen && nb != ID_EMPTY) { // rows of new ids only: a revisit's -- and an empty pair's -- loads are not issued
                     const uint8_t* tails = nullptr;
                     if constexpr (XT) {
                         if (adjx) tails = adjx + (size_t)xid * Ly.adjx_stride + 128u + R * XTAILB;

@@ -1027,13 +1027,14 @@ def test_two_level_lists_on_ties_twins_and_short_graphs(ga, oracle, int8):
     assert_same(o3, g3, q[:12], 8000, 10)
 
 
-@pytest.mark.parametrize("dim", [100, 200])
+@pytest.mark.parametrize("dim", [100, 200, 96, 300])
 def test_revisits_skipped_before_their_rows_are_fetched(ga, oracle, dim):
     """GRANNE_HIP_OPT_SEEN_MIN (walk_fast.h, SEEN): launches of many f32 walks consult a cache of the ids a walk has
     evaluated BEFORE they fetch a neighbor's row and skip a hit -- the reference's `!visited.insert(n)` (mod.rs:1026) for the
     recent part of the visited set; a miss means nothing. Forced on for every launch here (the default asks for 2048 walks):
     ids, distance bits, expansions and adjacency counts are the oracle's on clustered data (most neighbors are revisits), on
-    rows that name a neighbor twice, with and without the walkers' copy of the layers; the evaluations counted lie between
+    rows that name a neighbor twice, with and without the walkers' copy of the layers (100-d / 200-d: the unrolled walkers; 96-d
+    / 300-d: the streamed one, whose revisits follow the first new neighbor's row); the evaluations counted lie between
     the oracle's distinct nodes and what the walker without the cache evaluates."""
     from granne_amd import _lib
     rng = np.random.default_rng(900 + dim)
