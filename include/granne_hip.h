@@ -508,7 +508,7 @@ enum {
                                          (re)makes or frees the copy: not while a search of the index is running. An index
                                          whose copy does not fit in HBM is made without it (no error).
                                          get_option returns 1 only when the index actually holds the copy */
-    GRANNE_HIP_OPT_SEEN_MIN = 11      /* f32 walks of max_search up to 252 on layers of 32 ids: launches of at least this many
+    GRANNE_HIP_OPT_SEEN_MIN = 11      /* f32 walks (every dim) of max_search up to 252 on layers of 32 ids: launches of at least this many
                                          walks (queries x batches) consult a cache of the ids the walk has EVALUATED before
                                          they fetch a neighbor's row, and skip a hit -- the reference's `!visited.insert(n)`
                                          (src/index/mod.rs:1026) for the recent part of the visited set; a miss means nothing
