@@ -693,6 +693,329 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
     else bf_write_list(P, L, blk.range, q, qlive, h, qinv);
 }
 
+// ---- int8 rows of 128 bytes: the tiles travel HBM -> LDS by LDS-DMA into a ring, two query sets per wave (round 6) ----
+// What bounded bf_i8_kernel (profiles/r5_bruteforce_i8_*): a stage's rows went HBM -> registers -> LDS between two
+// barriers, with ONE stage in flight per block -- the staging alone took 1.1 ms of the 2.6 ms scan, the matrix work 0.6, and
+// the two did not overlap (waves parked 56 %). Here
+//   * a tile (128 rows = 16 KB) is written to LDS by the memory system itself (global_load_lds_dwordx4: 1 KB per wave
+//     instruction, no registers, no ds_write), into a ring of BF_RING_STAGES tiles: three tiles (48 KB per CU) are on
+//     their way while one is scored, ONE barrier per tile, and a wave waits for its own part of the next tile only
+//     (s_waitcnt vmcnt(N) counted by hand: the compiler does not see the transfers -- they are issued from asm -- and so
+//     does not drain them before every LDS read, which is what it does for the builtin);
+//   * LDS-DMA writes a wave's 64 x 16 bytes in lane order, so a row cannot be padded: the 16-byte chunk c of tile row r
+//     stands in slot c ^ ((r >> 1) & 7) of the row's 128 bytes (the swizzle is applied to the SOURCE address of each
+//     lane and to the fragment reads): the 16 lanes that ds_read_b128 serves per cycle hit 16 different slots of the
+//     256-byte bank row;
+//   * a wave holds TWO sets of 32 queries (64 per wave, 512 per block): every fragment read from LDS feeds two matrix
+//     instructions, and half as many blocks stream every range (L2 -> LDS traffic halves with it);
+//   * the rows' 1 / |x| and the block bounds (inv_gmax) ride in a ring of their own (one 4-byte LDS-DMA per wave and
+//     tile, 16 + 2 lanes): one block in eleven passes its bound and reads its norms, and an ordinary vector load there
+//     made the compiler wait for everything the ring has in flight (5.3 ms);
+//   * the running top-16 lists live in LDS, ONE per query for both lane halves (64 KB): 64 registers back, and the
+//     threshold of a query is that of both halves' rows.
+// The priming pass stays bf_i8_kernel<4, true>. Rows shorter than 128 bytes keep bf_i8_kernel.
+constexpr uint32_t BF_RING_THREADS = 512, BF_RING_QT = 512, BF_RING_STAGES = 4, BF_RING_ROWS = 128;
+constexpr uint32_t BF_RING_TILE_BYTES = BF_RING_ROWS * 128u;
+typedef const __attribute__((address_space(4))) float* bf_cptr_f32;
+// (volatile accesses through a generic pointer stay FLAT instructions -- counted by vmcnt, so each made the compiler wait for
+// the whole ring: the lists' pointers carry their address space)
+typedef volatile __attribute__((address_space(3))) float* bf_lds_f32;
+typedef volatile __attribute__((address_space(3))) uint32_t* bf_lds_u32;
+
+// 64 lanes x 16 bytes from base + voff (per lane) to LDS at lds_dst + 16 * lane (lds_dst, base: wave-uniform)
+__device__ __forceinline__ void bf_dma16(uint32_t lds_dst, const uint8_t* base, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+
+// the active lanes' 4 bytes from base + voff (per lane) to LDS at lds_dst + 4 * lane
+__device__ __forceinline__ void bf_dma4(uint32_t lds_dst, const float* base, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+
+// the lane's half of query q as the B operand of four K = 32 steps, and 1 / |q|
+__device__ __forceinline__ void bf_i8_load_query(const BruteParams& P, uint32_t q, bool qlive, uint32_t h, bf_i32x4 (&qr)[4], float& qinv) {
+    const uint8_t* qp = P.queries + (size_t)(qlive ? q : 0u) * P.dim;
+    const uint32_t last = P.dim - 1u;
+    int dy = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t c = (uint32_t)g * 32u + h * 16u + (uint32_t)w * 4u + (uint32_t)b;
+                const uint32_t raw = qp[c < last ? c : last];
+                const uint32_t keep = (qlive && c < P.dim) ? 0xFFu : 0u;
+                v |= (raw & keep) << (8 * b);
+            }
+            qr[g][w] = (int)v;
+            dy = dot4_i8(v, v, dy);
+        }
+    }
+    dy += __shfl_xor(dy, 32, 64);
+    qinv = dy > 0 ? 1.0f / __builtin_sqrtf((float)dy) : 0.0f;
+}
+
+// the smallest score of query ql's 16 entries and where it stands
+__device__ __forceinline__ float bf_ring_worst(bf_lds_f32 ls, uint32_t ql, uint32_t& pos) {
+    float sv[BF_KMAX];
+#pragma unroll
+    for (int i = 0; i < (int)BF_KMAX; ++i) sv[i] = ls[(uint32_t)i * BF_RING_QT + ql];
+    float m = sv[0];
+    pos = 0;
+#pragma unroll
+    for (int i = 1; i < (int)BF_KMAX; ++i) {
+        const bool lower = sv[i] < m;
+        m = lower ? sv[i] : m;
+        pos = lower ? (uint32_t)i : pos;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const BruteParams P) {
+    extern __shared__ __align__(16) uint8_t smem_bf[];
+    constexpr uint32_t NS = BF_RING_STAGES, TR = BF_RING_ROWS, TB = BF_RING_TILE_BYTES;
+    static_assert(NS == 4, "the waits below are written for three tiles in flight");
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t col = lane & 31u, h = lane >> 5;
+    const BfBlock blk = bf_block();
+    uint32_t q[2];
+    bool qlive[2];
+    bf_i32x4 qr[2][4];
+    float qinv[2], tau[2];
+    BfShare share[2];
+    // the running top-16 of the block's 512 queries: entry i of query ql at [i][ql], ONE list per query for both lane halves
+    bf_lds_f32 ls = (bf_lds_f32)(smem_bf + NS * TB);
+    bf_lds_u32 li = (bf_lds_u32)(smem_bf + NS * TB + BF_KMAX * BF_RING_QT * 4u);
+    bf_lds_f32 lw = (bf_lds_f32)(smem_bf + NS * TB + BF_KMAX * BF_RING_QT * 8u);       // [ql] the list's worst score ...
+    bf_lds_u32 lp = (bf_lds_u32)(smem_bf + NS * TB + BF_KMAX * BF_RING_QT * 8u + BF_RING_QT * 4u); // ... and where it stands
+    // the tiles' norms, a ring like the rows': per tile 8 x [16 x 1 / |x| of rows 16 w ..][inv_gmax of block w, both lane halves][2 unused]
+    constexpr uint32_t NB = 8u * 80u;
+    const uint32_t norms0 = NS * TB + BF_KMAX * BF_RING_QT * 8u + BF_RING_QT * 8u;
+    uint32_t ql[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        ql[s] = wave * 64u + (uint32_t)s * 32u + col;
+        q[s] = blk.qt * BF_RING_QT + ql[s];
+        qlive[s] = q[s] < P.nq;
+        bf_i8_load_query(P, q[s], qlive[s], h, qr[s], qinv[s]);
+        if (h == 0u) {
+#pragma unroll
+            for (int i = 0; i < (int)BF_KMAX; ++i) {
+                ls[(uint32_t)i * BF_RING_QT + ql[s]] = -3.0e38f;
+                li[(uint32_t)i * BF_RING_QT + ql[s]] = 0xFFFFFFFFu;
+            }
+            lw[ql[s]] = -3.0e38f;
+            lp[ql[s]] = 0u;
+        }
+        tau[s] = bf_start_tau(P, q[s], qlive[s]);
+        tau[s] = (tau[s] > -1.0e38f && qinv[s] > 0.0f) ? bf_next_below(tau[s] / qinv[s]) : -3.0e38f;
+        share[s].init(P, qlive[s], tau[s]);
+    }
+    const uint64_t r0 = (uint64_t)blk.range * P.per_range;
+    const uint64_t r1 = r0 + P.per_range < P.n ? r0 + P.per_range : P.n;
+    const uint32_t T = r0 < r1 ? (uint32_t)((r1 - r0 + TR - 1u) / TR) : 0u;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem_bf;
+    // LDS-DMA, three instructions per wave and tile. Rows: tile rows 16 wave + 8 j + (lane >> 3), slot lane & 7. Norms: lanes
+    // 0-15 the rows' 1 / |x|, lanes 16-17 of waves 0-3 the block bound of row block `wave` (lane half lane - 16).
+    const uint32_t n_pad = (uint32_t)((P.n + 31u) & ~31ull); // (the host takes this path for sets below 2^29 rows: 32-bit offsets)
+    const bool dnorm = lane < (wave < 4u ? 18u : 16u);
+    const uint32_t drow = wave * 16u + (lane >> 3), dslot = lane & 7u;
+    const uint32_t dc0 = dslot ^ ((drow >> 1) & 7u), dc1 = dslot ^ (((drow + 8u) >> 1) & 7u);
+    auto issue = [&](uint32_t t) {
+        const uint64_t e0 = r0 + (uint64_t)t * TR;
+        const uint8_t* base = P.elements + e0 * 128u;
+        const uint32_t dst = lds0 + (t & (NS - 1u)) * TB + wave * 2048u;
+        uint32_t v0 = drow * 128u + dc0 * 16u, v1 = (drow + 8u) * 128u + dc1 * 16u;
+        if (e0 + TR > P.n) { // the set's last rows: a row past the end reads the last row instead (its scores are never taken)
+            const uint32_t lastr = (uint32_t)(P.n - 1u - e0);
+            v0 = (drow < lastr ? drow : lastr) * 128u + dc0 * 16u;
+            v1 = (drow + 8u < lastr ? drow + 8u : lastr) * 128u + dc1 * 16u;
+        }
+        bf_dma16(dst, base, v0);
+        bf_dma16(dst + 1024u, base, v1);
+        if (dnorm) { // (inv_gmax stands behind inv_norm's n_pad entries in one allocation)
+            const uint32_t e32 = (uint32_t)e0, row = e32 + wave * 16u + lane;
+            const uint32_t idx = lane < 16u ? (row < n_pad ? row : n_pad - 1u) : n_pad + (e32 >> 5) * 2u + wave * 2u + (lane - 16u);
+            bf_dma4(lds0 + norms0 + (t & (NS - 1u)) * NB + wave * 80u, P.inv_norm, idx * 4u);
+        }
+    };
+    // fragment reads: row rb * 32 + col, chunk 2 g + h -> slot (2 g + h) ^ ((col >> 1) & 7)
+    uint32_t aoff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) aoff[g] = col * 128u + (((2u * (uint32_t)g + h) ^ ((col >> 1) & 7u)) << 4);
+
+    for (uint32_t t = 0; t + 1u < NS && t < T; ++t) issue(t);
+    for (uint32_t t = 0; t < T; ++t) {
+        // this wave's part of tile t has landed: at most the parts of the tiles after it are still on their way
+        const uint32_t rem = T - 1u - t;
+#if GRANNE_BF_EXP == 6
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        if (rem >= 2u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (rem == 1u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __syncthreads(); // every wave's part has; and every wave is done with tile t - 1, whose slot the next transfer takes
+#if GRANNE_BF_EXP != 6 // (diagnostic builds: 4 = no block passes its bound, 5 = no epilogue, 6 = no transfers after the first three tiles)
+        if (t + NS - 1u < T) issue(t + NS - 1u);
+#endif
+        if (P.share_hist) {
+            tau[0] = __builtin_fmaxf(tau[0], share[0].poll(P, q[0], h));
+            tau[1] = __builtin_fmaxf(tau[1], share[1].poll(P, q[1], h));
+        }
+        const uint64_t es = r0 + (uint64_t)t * TR;
+        const uint8_t* tile = smem_bf + (t & (NS - 1u)) * TB;
+        const uint32_t lim = r1 - es < TR ? (uint32_t)(r1 - es) : TR; // rows of this tile inside the range (the set's last tile: < 128)
+        const float* norms = reinterpret_cast<const float*>(smem_bf + norms0 + (t & (NS - 1u)) * NB);
+        float gmv4[4]; // the bound of the lane's 16 rows of each row block
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gmv4[i] = norms[i * 20 + 16 + (int)h];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            bf_i32x16 acc[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[s][r][v] = 0;
+            bf_i32x4 afrag[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) afrag[0][r] = *reinterpret_cast<const bf_i32x4*>(tile + aoff[0] + (uint32_t)(p * 2 + r) * 4096u);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+                        afrag[(g + 1) & 1][r] = *reinterpret_cast<const bf_i32x4*>(tile + aoff[g + 1] + (uint32_t)(p * 2 + r) * 4096u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        acc[s][r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[g & 1][r], qr[s][g], acc[s][r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t rb = (uint32_t)(p * 2 + r);
+                if (rb * 32u >= lim) continue; // a block wholly past the set's end (rows past it inside a block: their norm is NaN)
+                const float gmv = gmv4[rb];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+#if GRANNE_BF_EXP == 5
+                    if (acc[s][r][0] == 0x7fffffff) tau[s] = 0.0f;
+                    continue;
+#endif
+                    int im = 0;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) im = max(im, acc[s][r][v]);
+#if GRANNE_BF_EXP == 4
+                    if (im == 0x7fffffff) tau[s] = gmv;
+                    continue;
+#endif
+                    if (!__ballot((float)im * gmv > tau[s])) continue;
+                    // One block in fifty comes here -- but a block of eight waves meets at a barrier per tile, and with ~3 of
+                    // these per tile among them the tile takes as long as its slowest wave: this path is written for LATENCY.
+                    // (A loop over the 16 scores with a norm read, a compare and a branch each: 3,000+ clocks per visit, the
+                    // scan 2.8 ms; without this path 0.5.) The float scores of the lane's 16 rows at once (four reads of the
+                    // norms in flight together; a row past the set's end has a NaN there and compares false), one bit each:
+                    uint32_t cm = 0;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const uint32_t rw = rb * 32u + 8u * (uint32_t)g4 + 4u * h;
+                        const float4 iv = *reinterpret_cast<const float4*>(norms + (rw >> 4) * 20u + (rw & 15u));
+                        cm |= ((float)acc[s][r][g4 * 4 + 0] * iv.x > tau[s] ? 1u : 0u) << (g4 * 4 + 0);
+                        cm |= ((float)acc[s][r][g4 * 4 + 1] * iv.y > tau[s] ? 1u : 0u) << (g4 * 4 + 1);
+                        cm |= ((float)acc[s][r][g4 * 4 + 2] * iv.z > tau[s] ? 1u : 0u) << (g4 * 4 + 2);
+                        cm |= ((float)acc[s][r][g4 * 4 + 3] * iv.w > tau[s] ? 1u : 0u) << (g4 * 4 + 3);
+                    }
+                    // the candidates, one per lane and round (1.5 per visit): the insert exists once per place
+#pragma unroll 1
+                    while (__ballot(cm != 0u)) {
+                        const bool want = cm != 0u;
+                        const uint32_t v = want ? (uint32_t)__builtin_ctz(cm) : 0u;
+                        cm &= cm - 1u;
+                        int a = acc[s][r][0]; // (the index differs between lanes: a ladder of selects)
+#pragma unroll
+                        for (int j = 1; j < 16; ++j) a = v == (uint32_t)j ? acc[s][r][j] : a;
+                        const uint32_t rw = rb * 32u + 8u * (v >> 2) + 4u * h + (v & 3u);
+                        const float sc = (float)a * norms[(rw >> 4) * 20u + (rw & 15u)];
+                        // the list is a SET of 16 (put in order once, at the end): an element takes the place of the worst one,
+                        // the new worst is looked up (16 independent reads, no chain of shifts) and kept beside the list. The
+                        // two lane halves of a query share its list: they take their turns (a wave's LDS operations complete
+                        // in order).
+#pragma unroll 1
+                        for (uint32_t hh = 0; hh < 2u; ++hh) {
+                            if (h == hh && want) {
+                                tau[s] = __builtin_fmaxf(tau[s], lw[ql[s]]); // (the other half may have put something in)
+                                if (sc > tau[s]) {
+                                    uint32_t wpos = lp[ql[s]];
+                                    ls[wpos * BF_RING_QT + ql[s]] = sc;
+                                    li[wpos * BF_RING_QT + ql[s]] = (uint32_t)es + rw;
+                                    const float worst = bf_ring_worst(ls, ql[s], wpos);
+                                    lw[ql[s]] = worst;
+                                    lp[ql[s]] = wpos;
+                                    tau[s] = __builtin_fmaxf(tau[s], worst);
+                                    if (share[s].on()) share[s].count(P, q[s], sc);
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                    tau[s] = __builtin_fmaxf(tau[s], lw[ql[s]]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (qlive[s] && h == 0u) { // the set in order: an entry's rank among the 16 is its place in the list
+            const size_t list = (size_t)blk.range * P.nq + q[s];
+            float sv[BF_KMAX];
+            uint32_t iv[BF_KMAX];
+#pragma unroll
+            for (int i = 0; i < (int)BF_KMAX; ++i) {
+                sv[i] = ls[(uint32_t)i * BF_RING_QT + ql[s]];
+                iv[i] = li[(uint32_t)i * BF_RING_QT + ql[s]];
+            }
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int i = 0; i < (int)BF_KMAX; ++i) {
+                const bool ok = iv[i] != 0xFFFFFFFFu;
+                uint32_t rank = 0; // entries that stand before this one: a larger score, or the same score and a smaller id
+#pragma unroll
+                for (int j = 0; j < (int)BF_KMAX; ++j)
+                    rank += (j != i && iv[j] != 0xFFFFFFFFu && (sv[j] > sv[i] || (sv[j] == sv[i] && iv[j] < iv[i]))) ? 1u : 0u;
+                if (ok && rank < P.kk) {
+                    P.part_ids[list * P.kk + rank] = (uint64_t)iv[i];
+                    const float d = 1.0f - sv[i] * qinv[s];
+                    P.part_d[list * P.kk + rank] = d > 0.0f ? d : 0.0f;
+                }
+                cnt += ok ? 1u : 0u;
+            }
+            cnt = cnt < P.kk ? cnt : P.kk;
+            for (uint32_t i = cnt; i < P.kk; ++i) {
+                P.part_ids[list * P.kk + i] = ~0ull;
+                P.part_d[list * P.kk + i] = __builtin_inff();
+            }
+            P.part_c[list] = cnt;
+        }
+    }
+}
+
 // 1 / |x| of every int8 row (0 for a zero row), once per index: eight lanes per 128-byte row
 __global__ void inv_norm_rows_kernel(const uint8_t* __restrict__ elements, uint64_t n, uint32_t row_bytes, float* __restrict__ out) {
     const uint32_t c = threadIdx.x & 7u, units = row_bytes / 16u;
@@ -706,7 +1029,8 @@ __global__ void inv_norm_rows_kernel(const uint8_t* __restrict__ elements, uint6
         dx += __shfl_xor(dx, 1, 64);
         dx += __shfl_xor(dx, 2, 64);
         dx += __shfl_xor(dx, 4, 64);
-        if (c == 0u && row < n) out[row] = dx > 0 ? 1.0f / __builtin_sqrtf((float)dx) : 0.0f;
+        // (rows n .. n_pad - 1: NaN -- bf_i8_ring_kernel scores a whole 32-row block and drops what does not compare)
+        if (c == 0u) out[row] = row < n ? (dx > 0 ? 1.0f / __builtin_sqrtf((float)dx) : 0.0f) : __builtin_nanf("");
     }
 }
 

@@ -73,7 +73,7 @@ extern "C" int granne_hip_device_count(int* out_count) {
 
 // experiment knobs, read once per process
 struct EnvKnobs {
-    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, tail_blocks = -1, touch_max = -1, inline_tails = 1, seen_min = -1, bf_b16 = 1;
+    int visited_cap = 0, front_eighths = 0, maxc = 0, lds_pad = 0, visited = 0, tail_blocks = -1, touch_max = -1, inline_tails = 1, seen_min = -1, bf_b16 = 1, bf_ring = 1;
     EnvKnobs() {
         auto geti = [](const char* name, int dflt) {
             const char* e = getenv(name);
@@ -85,6 +85,7 @@ struct EnvKnobs {
         lds_pad = geti("GRANNE_HIP_LDS_PAD", 0);
         visited = geti("GRANNE_HIP_VISITED", 0); // GRANNE_HIP_OPT_VISITED16's values, where the option says auto
         inline_tails = geti("GRANNE_HIP_INLINE_TAILS", 1); // 0: no index keeps LayerDev::adjx (experiments: the layout before round 6)
+        bf_ring = geti("GRANNE_HIP_BF_RING", 1); // 0: the exact scan of 128-byte int8 rows stages its tiles through registers (round 5's bf_i8_kernel)
         bf_b16 = geti("GRANNE_HIP_BF_B16", 1); // 0: the exact scan of f32 rows scores on the f32 matrix path (round 5's: 5 x slower, scores to the last bits)
         seen_min = geti("GRANNE_HIP_SEEN_MIN", -1); // launches of at least this many walks skip revisits before their rows are fetched (-1: default)
         touch_max = geti("GRANNE_HIP_TOUCH_MAX", -1); // launches of up to this many queries touch rows ahead (-1: default)
@@ -220,7 +221,7 @@ static uint32_t inline_tail_units(uint32_t dim, int dtype) {
 // the scan's per-row norms: inv_norm [n_pad], then inv_gmax [n_pad / 32][2] (brute_force.h)
 static inline uint64_t inv_norm_bytes(uint64_t n) {
     const uint64_t n_pad = (n + 31u) & ~31ull;
-    return (n_pad + n_pad / 16 + 1) * 4;
+    return (n_pad + n_pad / 16 + 1 + 16) * 4; // (+16: bf_i8_ring_kernel reads a tile's eight inv_gmax entries in one scalar load, past the last block's too)
 }
 
 static int grid_for(uint64_t work, int block) {
@@ -1661,6 +1662,8 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     const uint32_t kk = k + BF_EXTRA < BF_KMAX ? k + BF_EXTRA : BF_KMAX;
     // element ranges: the lists of up to 64 ranges are merged; a range is a whole number of tiles
     uint32_t R = 4, lds = 0, qt = BF_QT, threads = BF_THREADS;
+    uint32_t prime_lds = 0, prime_qt = 0, prime_threads = 0; // 0: the scan's own
+    uint64_t max_ranges = 64;
     void (*fn)(const BruteParams) = nullptr;
     void (*fn_prime)(const BruteParams) = nullptr; // the same scan keeping only the best score per (range, query)
     if (ix->dtype == GRANNE_HIP_I8) {
@@ -1668,6 +1671,15 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         fn = bf_i8_kernel<4>;
         fn_prime = bf_i8_kernel<4, true>;
         lds = BF_I8_SUB * (32u * R * (128u + 16u) + 32u * R * 4u + 2u * R * 4u);
+        if (knobs().bf_ring && ix->row_bytes == 128u && ix->row_stride == 128u && n < (1ull << 29)) {
+            // tiles by LDS-DMA into a ring, 64 queries per wave (brute_force.h, bf_i8_ring_kernel); the priming pass stays
+            prime_lds = lds, prime_qt = qt, prime_threads = threads;
+            fn = bf_i8_ring_kernel;
+            lds = BF_RING_STAGES * BF_RING_TILE_BYTES + BF_KMAX * BF_RING_QT * 8u + BF_RING_QT * 8u + BF_RING_STAGES * 8u * 80u;
+            qt = BF_RING_QT, threads = BF_RING_THREADS;
+            // 512 queries per block: half as many blocks per range, so twice the ranges fill the chip (merged in two steps)
+            if ((uint64_t)((nq + qt - 1) / qt) * 64u < 256u) max_ranges = 128;
+        }
     } else if (knobs().bf_b16 && ix->dim <= 112) { // f32 rows on the bf16 matrix path, three instructions per product (brute_force.h)
         R = 4;
         fn = bf_b16_kernel<7, 4>;
@@ -1704,7 +1716,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     }
     const uint64_t tile = 32ull * R;
     uint64_t G = (n + tile - 1) / tile;
-    if (G > 64) G = 64;
+    if (G > max_ranges) G = max_ranges;
     if (G < 1) G = 1;
     uint64_t per_range = (n + G - 1) / G;
     per_range = (per_range + tile - 1) / tile * tile;
@@ -1773,8 +1785,9 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         Q.per_range = ((Q.n + Gs - 1) / Gs + tile - 1) / tile * tile;
         Gs = (Q.n + Q.per_range - 1) / Q.per_range;
         if (Gs >= kk) {
-            if (lds > 64u * 1024u) HIP_TRY(hipFuncSetAttribute((const void*)fn_prime, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(fn_prime, dim3((nq + qt - 1) / qt, (uint32_t)Gs), dim3(threads), lds, s, Q);
+            const uint32_t plds = prime_qt ? prime_lds : lds, pqt = prime_qt ? prime_qt : qt, pthreads = prime_qt ? prime_threads : threads;
+            if (plds > 64u * 1024u) HIP_TRY(hipFuncSetAttribute((const void*)fn_prime, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+            hipLaunchKernelGGL(fn_prime, dim3((nq + pqt - 1) / pqt, (uint32_t)Gs), dim3(pthreads), plds, s, Q);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(bf_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, (const float*)P.part_d, (uint32_t)Gs, nq, kk,
                                (float*)(scratch + o_tau));
@@ -1787,9 +1800,31 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     }
     hipLaunchKernelGGL(fn, dim3((nq + qt - 1) / qt, (uint32_t)G), dim3(threads), lds, s, P);
     HIP_TRY(hipGetLastError());
-    int rc = merge_launch((const uint8_t*)P.part_ids, (const uint8_t*)P.part_d, (const uint8_t*)P.part_c, (uint64_t)nq * kk * 8,
+    int rc = 0;
+    if (G > 64) {
+        // more lists than the merge has lanes: ranges 0..63 and 64.. are merged into two lists of their own, then those two
+        const uint8_t* pi = (const uint8_t*)P.part_ids;
+        const uint8_t* pd = (const uint8_t*)P.part_d;
+        const uint8_t* pc = (const uint8_t*)P.part_c;
+        const uint64_t si = (uint64_t)nq * kk * 8, sd = (uint64_t)nq * kk * 4, sc = (uint64_t)nq * 4;
+        uint8_t* half = nullptr; // [2] x (ids, dists, counts)
+        const size_t hi = 0, hd = 2 * si, hc = hd + 2 * sd, hbytes = hc + 2 * sc;
+        HIP_TRY(hipMallocAsync((void**)&half, hbytes, s));
+        Release release_half{half, s};
+        for (uint32_t part = 0; part < 2 && rc == 0; ++part) {
+            const uint32_t first = part * 64u, count = part == 0 ? 64u : (uint32_t)G - 64u;
+            rc = merge_launch(pi + first * si, pd + first * sd, pc + first * sc, si, sd, sc, zeros, count, nq, kk,
+                              (uint64_t*)(half + hi + part * si), (float*)(half + hd + part * sd),
+                              (uint32_t*)(half + hc + part * sc), ix->device, stream);
+        }
+        if (rc == 0)
+            rc = merge_launch(half + hi, half + hd, half + hc, si, sd, sc, zeros, 2, nq, kk, (uint64_t*)(scratch + o_mid),
+                              (float*)(scratch + o_md), (uint32_t*)(scratch + o_mc), ix->device, stream);
+    } else {
+        rc = merge_launch((const uint8_t*)P.part_ids, (const uint8_t*)P.part_d, (const uint8_t*)P.part_c, (uint64_t)nq * kk * 8,
                           (uint64_t)nq * kk * 4, (uint64_t)nq * 4, zeros, (uint32_t)G, nq, kk, (uint64_t*)(scratch + o_mid),
                           (float*)(scratch + o_md), (uint32_t*)(scratch + o_mc), ix->device, stream);
+    }
     if (rc) return rc;
     // the candidates' distances in the reference's own arithmetic, then the k best by (distance, id)
     const uint32_t pairs = nq * kk;
