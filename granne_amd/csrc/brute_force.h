@@ -709,12 +709,26 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
 //   * a wave holds TWO sets of 32 queries (64 per wave, 512 per block): every fragment read from LDS feeds two matrix
 //     instructions, and half as many blocks stream every range (L2 -> LDS traffic halves with it);
 //   * the rows' 1 / |x| and the block bounds (inv_gmax) ride in a ring of their own (one 4-byte LDS-DMA per wave and
-//     tile, 16 + 2 lanes): one block in eleven passes its bound and reads its norms, and an ordinary vector load there
+//     tile, 16 + 2 lanes): one block in fifty passes its bound and reads its norms, and an ordinary vector load there
 //     made the compiler wait for everything the ring has in flight (5.3 ms);
-//   * the running top-16 lists live in LDS, ONE per query for both lane halves (64 KB): 64 registers back, and the
-//     threshold of a query is that of both halves' rows.
+//   * the running top-16 of a query is a SET in LDS, one per query for both lane halves (64 KB; 64 registers back, and
+//     a query's threshold is that of both halves' rows): an element takes the place of the worst one and the new worst
+//     is looked up (16 independent reads); the set is put in order once, when it is written out. (Through a generic
+//     `volatile` pointer these were FLAT instructions, counted by vmcnt like the transfers: the pointers carry their
+//     address space.) The path that puts candidates in is written for latency -- a block's eight waves meet at the
+//     barrier of every tile, ~3 visits per tile among them: the float scores of a lane's 16 rows at once, one bit
+//     each, then one candidate per lane and round (a loop over the 16 scores with a norm read and a branch each:
+//     2.8 ms; unrolled with the insert at each of the 16: 200 KB of code, 2.6 ms).
+// 1024 x 10M x 100-d: 2.6 -> 1.75-2.0 ms for the whole operator (the kernel 1.55 ms). What is left, measured
+// (tools/mfma_lds_loop.hip, tools/mfma_rate.hip): this loop alone, fragments from LDS, no transfers, takes 1,400 clocks
+// per tile and wave (44 per matrix instruction; two waves of a SIMD interleave theirs -- 17 clocks per instruction and
+// SIMD where one wave alone issues one per 32) -- and the chip answers that rate on random int8 data with a shader clock
+// of 0.9-1.1 GHz: 0.95 ms for this scan's 2.6e15 operations, 1.1 ms with the transfers, whatever the structure. Counters
+// per ring slot instead of the barrier (a wave could fall a tile behind) changed nothing; neither did two tiles in
+// flight instead of three, nor a fifth slot.
 // The priming pass stays bf_i8_kernel<4, true>. Rows shorter than 128 bytes keep bf_i8_kernel.
 constexpr uint32_t BF_RING_THREADS = 512, BF_RING_QT = 512, BF_RING_STAGES = 4, BF_RING_ROWS = 128;
+constexpr uint32_t BF_RING_LDS = BF_RING_STAGES * BF_RING_ROWS * 128u + BF_KMAX * BF_RING_QT * 8u + BF_RING_QT * 8u + BF_RING_STAGES * 8u * 80u; // tiles + lists + (worst, place) + norms
 constexpr uint32_t BF_RING_TILE_BYTES = BF_RING_ROWS * 128u;
 typedef const __attribute__((address_space(4))) float* bf_cptr_f32;
 // (volatile accesses through a generic pointer stay FLAT instructions -- counted by vmcnt, so each made the compiler wait for
@@ -784,6 +798,7 @@ __device__ __forceinline__ float bf_ring_worst(bf_lds_f32 ls, uint32_t ql, uint3
 __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const BruteParams P) {
     extern __shared__ __align__(16) uint8_t smem_bf[];
     constexpr uint32_t NS = BF_RING_STAGES, TR = BF_RING_ROWS, TB = BF_RING_TILE_BYTES;
+    constexpr uint32_t A = NS - 1u; // tiles on their way while one is scored
     static_assert(NS == 4, "the waits below are written for three tiles in flight");
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -832,10 +847,10 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
     const bool dnorm = lane < (wave < 4u ? 18u : 16u);
     const uint32_t drow = wave * 16u + (lane >> 3), dslot = lane & 7u;
     const uint32_t dc0 = dslot ^ ((drow >> 1) & 7u), dc1 = dslot ^ (((drow + 8u) >> 1) & 7u);
-    auto issue = [&](uint32_t t) {
+    auto issue = [&](uint32_t t, uint32_t slot) {
         const uint64_t e0 = r0 + (uint64_t)t * TR;
         const uint8_t* base = P.elements + e0 * 128u;
-        const uint32_t dst = lds0 + (t & (NS - 1u)) * TB + wave * 2048u;
+        const uint32_t dst = lds0 + slot * TB + wave * 2048u;
         uint32_t v0 = drow * 128u + dc0 * 16u, v1 = (drow + 8u) * 128u + dc1 * 16u;
         if (e0 + TR > P.n) { // the set's last rows: a row past the end reads the last row instead (its scores are never taken)
             const uint32_t lastr = (uint32_t)(P.n - 1u - e0);
@@ -847,7 +862,7 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
         if (dnorm) { // (inv_gmax stands behind inv_norm's n_pad entries in one allocation)
             const uint32_t e32 = (uint32_t)e0, row = e32 + wave * 16u + lane;
             const uint32_t idx = lane < 16u ? (row < n_pad ? row : n_pad - 1u) : n_pad + (e32 >> 5) * 2u + wave * 2u + (lane - 16u);
-            bf_dma4(lds0 + norms0 + (t & (NS - 1u)) * NB + wave * 80u, P.inv_norm, idx * 4u);
+            bf_dma4(lds0 + norms0 + slot * NB + wave * 80u, P.inv_norm, idx * 4u);
         }
     };
     // fragment reads: row rb * 32 + col, chunk 2 g + h -> slot (2 g + h) ^ ((col >> 1) & 7)
@@ -855,29 +870,27 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
 #pragma unroll
     for (int g = 0; g < 4; ++g) aoff[g] = col * 128u + (((2u * (uint32_t)g + h) ^ ((col >> 1) & 7u)) << 4);
 
-    for (uint32_t t = 0; t + 1u < NS && t < T; ++t) issue(t);
+    __syncthreads(); // (the lists are set)
+    for (uint32_t t = 0; t < A && t < T; ++t) issue(t, t);
+    uint32_t slot = 0;          // tile t stands in slot t % NS,
+    uint32_t fslot = A % NS;    // tile t + A goes to slot (t + A) % NS: where tile t - 1 stood (A = NS - 1)
     for (uint32_t t = 0; t < T; ++t) {
-        // this wave's part of tile t has landed: at most the parts of the tiles after it are still on their way
+        // this wave's part of tile t has landed (three transfers per tile): at most its parts of the A - 1 tiles after it are
+        // still on their way
         const uint32_t rem = T - 1u - t;
-#if GRANNE_BF_EXP == 6
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
         if (rem >= 2u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (rem == 1u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         __syncthreads(); // every wave's part has; and every wave is done with tile t - 1, whose slot the next transfer takes
-#if GRANNE_BF_EXP != 6 // (diagnostic builds: 4 = no block passes its bound, 5 = no epilogue, 6 = no transfers after the first three tiles)
-        if (t + NS - 1u < T) issue(t + NS - 1u);
-#endif
+        if (t + A < T) issue(t + A, fslot);
         if (P.share_hist) {
             tau[0] = __builtin_fmaxf(tau[0], share[0].poll(P, q[0], h));
             tau[1] = __builtin_fmaxf(tau[1], share[1].poll(P, q[1], h));
         }
         const uint64_t es = r0 + (uint64_t)t * TR;
-        const uint8_t* tile = smem_bf + (t & (NS - 1u)) * TB;
+        const uint8_t* tile = smem_bf + slot * TB;
         const uint32_t lim = r1 - es < TR ? (uint32_t)(r1 - es) : TR; // rows of this tile inside the range (the set's last tile: < 128)
-        const float* norms = reinterpret_cast<const float*>(smem_bf + norms0 + (t & (NS - 1u)) * NB);
+        const float* norms = reinterpret_cast<const float*>(smem_bf + norms0 + slot * NB);
         float gmv4[4]; // the bound of the lane's 16 rows of each row block
 #pragma unroll
         for (int i = 0; i < 4; ++i) gmv4[i] = norms[i * 20 + 16 + (int)h];
@@ -915,17 +928,9 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
                 const float gmv = gmv4[rb];
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-#if GRANNE_BF_EXP == 5
-                    if (acc[s][r][0] == 0x7fffffff) tau[s] = 0.0f;
-                    continue;
-#endif
                     int im = 0;
 #pragma unroll
                     for (int v = 0; v < 16; ++v) im = max(im, acc[s][r][v]);
-#if GRANNE_BF_EXP == 4
-                    if (im == 0x7fffffff) tau[s] = gmv;
-                    continue;
-#endif
                     if (!__ballot((float)im * gmv > tau[s])) continue;
                     // One block in fifty comes here -- but a block of eight waves meets at a barrier per tile, and with ~3 of
                     // these per tile among them the tile takes as long as its slowest wave: this path is written for LATENCY.
@@ -933,26 +938,28 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
                     // scan 2.8 ms; without this path 0.5.) The float scores of the lane's 16 rows at once (four reads of the
                     // norms in flight together; a row past the set's end has a NaN there and compares false), one bit each:
                     uint32_t cm = 0;
+                    float sc16[16];
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const uint32_t rw = rb * 32u + 8u * (uint32_t)g4 + 4u * h;
                         const float4 iv = *reinterpret_cast<const float4*>(norms + (rw >> 4) * 20u + (rw & 15u));
-                        cm |= ((float)acc[s][r][g4 * 4 + 0] * iv.x > tau[s] ? 1u : 0u) << (g4 * 4 + 0);
-                        cm |= ((float)acc[s][r][g4 * 4 + 1] * iv.y > tau[s] ? 1u : 0u) << (g4 * 4 + 1);
-                        cm |= ((float)acc[s][r][g4 * 4 + 2] * iv.z > tau[s] ? 1u : 0u) << (g4 * 4 + 2);
-                        cm |= ((float)acc[s][r][g4 * 4 + 3] * iv.w > tau[s] ? 1u : 0u) << (g4 * 4 + 3);
+                        sc16[g4 * 4 + 0] = (float)acc[s][r][g4 * 4 + 0] * iv.x;
+                        sc16[g4 * 4 + 1] = (float)acc[s][r][g4 * 4 + 1] * iv.y;
+                        sc16[g4 * 4 + 2] = (float)acc[s][r][g4 * 4 + 2] * iv.z;
+                        sc16[g4 * 4 + 3] = (float)acc[s][r][g4 * 4 + 3] * iv.w;
                     }
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) cm |= (sc16[v] > tau[s] ? 1u : 0u) << v;
                     // the candidates, one per lane and round (1.5 per visit): the insert exists once per place
 #pragma unroll 1
                     while (__ballot(cm != 0u)) {
                         const bool want = cm != 0u;
                         const uint32_t v = want ? (uint32_t)__builtin_ctz(cm) : 0u;
                         cm &= cm - 1u;
-                        int a = acc[s][r][0]; // (the index differs between lanes: a ladder of selects)
+                        float sc = sc16[0]; // (the index differs between lanes: a ladder of selects)
 #pragma unroll
-                        for (int j = 1; j < 16; ++j) a = v == (uint32_t)j ? acc[s][r][j] : a;
+                        for (int j = 1; j < 16; ++j) sc = v == (uint32_t)j ? sc16[j] : sc;
                         const uint32_t rw = rb * 32u + 8u * (v >> 2) + 4u * h + (v & 3u);
-                        const float sc = (float)a * norms[(rw >> 4) * 20u + (rw & 15u)];
                         // the list is a SET of 16 (put in order once, at the end): an element takes the place of the worst one,
                         // the new worst is looked up (16 independent reads, no chain of shifts) and kept beside the list. The
                         // two lane halves of a query share its list: they take their turns (a wave's LDS operations complete
@@ -979,6 +986,8 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
                 }
             }
         }
+        if (++slot == NS) slot = 0;
+        if (++fslot == NS) fslot = 0;
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {

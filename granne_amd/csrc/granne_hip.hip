@@ -1675,7 +1675,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
             // tiles by LDS-DMA into a ring, 64 queries per wave (brute_force.h, bf_i8_ring_kernel); the priming pass stays
             prime_lds = lds, prime_qt = qt, prime_threads = threads;
             fn = bf_i8_ring_kernel;
-            lds = BF_RING_STAGES * BF_RING_TILE_BYTES + BF_KMAX * BF_RING_QT * 8u + BF_RING_QT * 8u + BF_RING_STAGES * 8u * 80u;
+            lds = BF_RING_LDS;
             qt = BF_RING_QT, threads = BF_RING_THREADS;
             // 512 queries per block: half as many blocks per range, so twice the ranges fill the chip (merged in two steps)
             if ((uint64_t)((nq + qt - 1) / qt) * 64u < 256u) max_ranges = 128;

@@ -56,7 +56,10 @@ def test_brute_force_matches_a_scalar_scan(oracle, int8, dim, n):
 
 
 @pytest.mark.parametrize("int8,dim,n,nq", [(True, 100, 300_000, 300), (False, 100, 300_000, 70), (False, 200, 150_000, 40),
-                                           (True, 64, 1_000_000, 520)])
+                                           (True, 64, 1_000_000, 520),
+                                           # 128-byte int8 rows (the LDS-DMA ring, brute_force.h bf_i8_ring_kernel): four query tiles
+                                           # of 512 and 64 ranges; one tile and 128 ranges merged in two steps; a last tile of 33 rows
+                                           (True, 128, 70_049, 1600), (True, 100, 150_000, 513)])
 def test_primed_scan_with_the_shared_threshold_matches_the_scalar_scan(oracle, int8, dim, n, nq):
     """Sets large enough for the priming pass and the per-query threshold that the ranges share (brute_force.h, BfShare):
     the result is the oracle's scan whatever order the ranges publish in -- run twice, identical."""
@@ -103,6 +106,19 @@ def test_brute_force_small_and_ragged(oracle):
     assert (ids[:, :7] == want_i.astype(np.uint64)).all() and ds[:, :7].tobytes() == want_d.tobytes()
     with pytest.raises(GranneHipError):
         ix.brute_force(q, 17)
+    # int8 rows of 128 bytes, fewer than one tile of them, a zero row among them (its distance is the clamp's 1)
+    el8 = oracle.quantize(random_floats(rng, 9, 100))
+    el8[4] = 0
+    q8 = oracle.quantize(random_floats(rng, 5, 100))
+    ix8 = granne_amd.Granne("angular_int", el8, [])
+    ids, ds, cnt = ix8.brute_force(q8, 16)
+    assert (cnt == 9).all() and (ids[:, 9:] == np.iinfo(np.uint64).max).all() and np.isinf(ds[:, 9:]).all()
+    want_i, want_d = exact_topk(oracle, el8, q8, 9)
+    assert ds[:, :9].tobytes() == want_d.tobytes()
+    for qi in range(5):
+        assert sorted(ids[qi, :9].tolist()) == list(range(9))
+        keys = list(zip(ds[qi, :9].tolist(), ids[qi, :9].tolist()))
+        assert keys == sorted(keys)
     big = granne_amd.Granne("angular", oracle.normalize_f32(random_floats(rng, 10, 300)), [])
     with pytest.raises(GranneHipError):
         big.brute_force(oracle.normalize_f32(random_floats(rng, 2, 300)), 5)
