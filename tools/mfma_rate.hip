@@ -36,19 +36,26 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int* sink, int iters) {
 }
 int main() {
     uint64_t* out; int* sink;
-    hipMalloc(&out, 64); hipMalloc(&sink, 64);
+    (void)hipMalloc(&out, 64); (void)hipMalloc(&sink, 64);
     const int iters = 4096;
     const char* names[3] = {"v_mfma_i32_32x32x32_i8", "v_mfma_f32_32x32x16_bf16", "v_mfma_i32_16x16x64_i8"};
     for (int kind = 0; kind < 3; ++kind)
         for (int threads : {256, 512}) {
-            for (int rep = 0; rep < 2; ++rep) {
+            hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            float ms = 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipEventRecord(e0, 0);
                 if (kind == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 0, 0, out, sink, iters);
                 if (kind == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, out, sink, iters);
                 if (kind == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(threads), 0, 0, out, sink, iters);
-                hipDeviceSynchronize();
+                (void)hipEventRecord(e1, 0);
+                (void)hipDeviceSynchronize();
+                (void)hipEventElapsedTime(&ms, e0, e1);
             }
-            uint64_t c; hipMemcpy(&c, out, 8, hipMemcpyDeviceToHost);
-            printf("%s, %d waves per SIMD: %.1f clocks per instruction and wave, %.1f per SIMD\n", names[kind], threads / 256, (double)c / (iters * 16.0), (double)c / (iters * 16.0) / (threads / 256));
+            uint64_t c; (void)hipMemcpy(&c, out, 8, hipMemcpyDeviceToHost);
+            const double ops_per = kind == 0 ? 65536.0 : 32768.0, total = ops_per * iters * 16.0 * (threads / 64) * 256;
+            printf("%s, %d waves per SIMD: %.1f clocks per instruction and wave, %.1f per SIMD; kernel %.3f ms = %.2f GHz, %.0f T(FL)OP/s on the whole chip (operands: small integers / constants)\n",
+                   names[kind], threads / 256, (double)c / (iters * 16.0), (double)c / (iters * 16.0) / (threads / 256), ms, (double)c / (ms * 1e6), total / (ms * 1e9));
         }
     return 0;
 }
