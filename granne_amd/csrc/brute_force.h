@@ -356,6 +356,9 @@ typedef __bf16 bf_b16x4 __attribute__((ext_vector_type(4)));
 // whole tile, and eight blocks instead of four stream every range. Two tiles in LDS with the next tile's conversion
 // interleaved into the matrix loop, one barrier per tile: 7.2 ms where this form takes 6.6 -- the conversion then waits
 // for the tile's loads inside the loop, and a second set of load registers does not fit.)
+#ifndef GRANNE_BF_B16_AHEAD
+#define GRANNE_BF_B16_AHEAD 1 // fragment pairs read ahead of the matrix instructions (2: +8 registers, the same 6.2-6.8 ms)
+#endif
 constexpr uint32_t BF_B16_THREADS = 512, BF_B16_QT = 256;
 template <int KG, int R, bool PRIME = false>
 __global__ __launch_bounds__(BF_B16_THREADS) void bf_b16_kernel(const BruteParams P) {
@@ -438,21 +441,25 @@ __global__ __launch_bounds__(BF_B16_THREADS) void bf_b16_kernel(const BruteParam
         // sinks every read to just before its instruction, and each waits for LDS; a whole step ahead -- 2 x R fragments of
         // each piece -- spilled: 10.1 ms where this takes less)
         const size_t off0 = (size_t)col * STRIDE_B + (size_t)h * 16u * KG;
-        bf_b16x8 ah[2], al[2];
-        ah[0] = *reinterpret_cast<const bf_b16x8*>(tile_hi + off0);
-        al[0] = *reinterpret_cast<const bf_b16x8*>(tile_lo + off0);
+        constexpr int AHEAD = KG == 13 ? 1 : GRANNE_BF_B16_AHEAD, NF = KG * R; // (KG = 13: a second step ahead spills)
+        bf_b16x8 ah[AHEAD + 1], al[AHEAD + 1];
 #pragma unroll
-        for (int i = 0; i < KG * R; ++i) {
+        for (int i = 0; i < AHEAD && i < NF; ++i) {
+            ah[i] = *reinterpret_cast<const bf_b16x8*>(tile_hi + off0 + (size_t)(i % R) * 32u * STRIDE_B + (size_t)(i / R) * 16u);
+            al[i] = *reinterpret_cast<const bf_b16x8*>(tile_lo + off0 + (size_t)(i % R) * 32u * STRIDE_B + (size_t)(i / R) * 16u);
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
             const int g = i / R, r = i % R;
-            if (i + 1 < KG * R) {
-                const int gn = (i + 1) / R, rn = (i + 1) % R;
-                ah[(i + 1) & 1] = *reinterpret_cast<const bf_b16x8*>(tile_hi + off0 + (size_t)rn * 32u * STRIDE_B + (size_t)gn * 16u);
-                al[(i + 1) & 1] = *reinterpret_cast<const bf_b16x8*>(tile_lo + off0 + (size_t)rn * 32u * STRIDE_B + (size_t)gn * 16u);
+            if (i + AHEAD < NF) {
+                const int gn = (i + AHEAD) / R, rn = (i + AHEAD) % R;
+                ah[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const bf_b16x8*>(tile_hi + off0 + (size_t)rn * 32u * STRIDE_B + (size_t)gn * 16u);
+                al[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const bf_b16x8*>(tile_lo + off0 + (size_t)rn * 32u * STRIDE_B + (size_t)gn * 16u);
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], qh[g], acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], ql[g], acc[r], 0, 0, 0);
-            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], qh[g], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i % (AHEAD + 1)], qh[g], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i % (AHEAD + 1)], ql[g], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i % (AHEAD + 1)], qh[g], acc[r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // result block r: acc[r][v] ~ dot(element e0 + r*32 + 8*(v/4) + 4*h + v%4, query `col` of this wave)
