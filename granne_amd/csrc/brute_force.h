@@ -355,7 +355,8 @@ typedef __bf16 bf_b16x4 __attribute__((ext_vector_type(4)));
 // matrix instructions -- were tried: 11.2 ms where the block of eight waves takes 7.3; every block converts and stores the
 // whole tile, and eight blocks instead of four stream every range. Two tiles in LDS with the next tile's conversion
 // interleaved into the matrix loop, one barrier per tile: 7.2 ms where this form takes 6.6 -- the conversion then waits
-// for the tile's loads inside the loop, and a second set of load registers does not fit.)
+// for the tile's loads inside the loop, and a second set of load registers does not fit. Two query sets per wave with the
+// lists as sets in LDS, bf_i8_ring_kernel's shape without the LDS-DMA: 6.6-7.0 ms at 245 registers, no gain, dropped.)
 #ifndef GRANNE_BF_B16_AHEAD
 #define GRANNE_BF_B16_AHEAD 1 // fragment pairs read ahead of the matrix instructions (2: +8 registers, the same 6.2-6.8 ms)
 #endif
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
 // flight instead of three, nor a fifth slot.
 // The priming pass stays bf_i8_kernel<4, true>. Rows shorter than 128 bytes keep bf_i8_kernel.
 constexpr uint32_t BF_RING_THREADS = 512, BF_RING_QT = 512, BF_RING_STAGES = 4, BF_RING_ROWS = 128;
-constexpr uint32_t BF_RING_LDS = BF_RING_STAGES * BF_RING_ROWS * 128u + BF_KMAX * BF_RING_QT * 8u + BF_RING_QT * 8u + BF_RING_STAGES * 8u * 80u; // tiles + lists + (worst, place) + norms
+constexpr uint32_t BF_RING_LDS = BF_RING_STAGES * BF_RING_ROWS * 128u + (BF_KMAX * 512u * 8u + 512u * 8u) + BF_RING_STAGES * 8u * 80u; // tiles + sets (BF_SET_BYTES) + norms
 constexpr uint32_t BF_RING_TILE_BYTES = BF_RING_ROWS * 128u;
 typedef const __attribute__((address_space(4))) float* bf_cptr_f32;
 // (volatile accesses through a generic pointer stay FLAT instructions -- counted by vmcnt, so each made the compiler wait for
@@ -786,21 +787,122 @@ __device__ __forceinline__ void bf_i8_load_query(const BruteParams& P, uint32_t 
     qinv = dy > 0 ? 1.0f / __builtin_sqrtf((float)dy) : 0.0f;
 }
 
-// the smallest score of query ql's 16 entries and where it stands
-__device__ __forceinline__ float bf_ring_worst(bf_lds_f32 ls, uint32_t ql, uint32_t& pos) {
-    float sv[BF_KMAX];
-#pragma unroll
-    for (int i = 0; i < (int)BF_KMAX; ++i) sv[i] = ls[(uint32_t)i * BF_RING_QT + ql];
-    float m = sv[0];
-    pos = 0;
-#pragma unroll
-    for (int i = 1; i < (int)BF_KMAX; ++i) {
-        const bool lower = sv[i] < m;
-        m = lower ? sv[i] : m;
-        pos = lower ? (uint32_t)i : pos;
+// The running top-16 of a block's 512 queries as SETS in LDS (bf_i8_ring_kernel): entry i of query ql
+// at [i][ql], ONE set per query for both lane halves (64 KB), beside it the set's worst score and its place (4 KB). An
+// element takes the place of the worst one and the new worst is looked up -- 16 independent reads, no chain of shifts; the
+// set is put in order once, when it is written out.
+constexpr uint32_t BF_SET_QT = 512;                                          // queries per block
+static_assert(BF_SET_QT == BF_RING_QT, "the ring kernel's blocks hold BF_SET_QT queries");
+constexpr uint32_t BF_SET_BYTES = BF_KMAX * BF_SET_QT * 8u + BF_SET_QT * 8u; // scores + ids + (worst, place)
+struct BfSets {
+    bf_lds_f32 ls; // [BF_KMAX][BF_SET_QT] scores (no particular order)
+    bf_lds_u32 li; // [BF_KMAX][BF_SET_QT] element ids
+    bf_lds_f32 lw; // [BF_SET_QT] the set's smallest score ...
+    bf_lds_u32 lp; // ... and which entry holds it
+    __device__ __forceinline__ void at(uint8_t* lds) {
+        ls = (bf_lds_f32)lds;
+        li = (bf_lds_u32)(lds + BF_KMAX * BF_SET_QT * 4u);
+        lw = (bf_lds_f32)(lds + BF_KMAX * BF_SET_QT * 8u);
+        lp = (bf_lds_u32)(lds + BF_KMAX * BF_SET_QT * 8u + BF_SET_QT * 4u);
     }
-    return m;
-}
+    __device__ __forceinline__ void clear(uint32_t ql) {
+#pragma unroll
+        for (int i = 0; i < (int)BF_KMAX; ++i) {
+            ls[(uint32_t)i * BF_SET_QT + ql] = -3.0e38f;
+            li[(uint32_t)i * BF_SET_QT + ql] = 0xFFFFFFFFu;
+        }
+        lw[ql] = -3.0e38f;
+        lp[ql] = 0u;
+    }
+    // the smallest score of query ql's 16 entries and where it stands
+    __device__ __forceinline__ float worst(uint32_t ql, uint32_t& pos) const {
+        float sv[BF_KMAX];
+#pragma unroll
+        for (int i = 0; i < (int)BF_KMAX; ++i) sv[i] = ls[(uint32_t)i * BF_SET_QT + ql];
+        float m = sv[0];
+        pos = 0;
+#pragma unroll
+        for (int i = 1; i < (int)BF_KMAX; ++i) {
+            const bool lower = sv[i] < m;
+            m = lower ? sv[i] : m;
+            pos = lower ? (uint32_t)i : pos;
+        }
+        return m;
+    }
+    // The scores sc16[v] of the lane's 16 rows of a 32-row block (row 8 (v / 4) + 4 h + v % 4; id0 = the id of the block's
+    // row 0; a score that must not enter is NaN or -inf) against query ql's threshold `tau`: what beats it enters the set.
+    // Written for LATENCY -- a block's eight waves meet at a barrier per tile and a few of them come here per tile, so the
+    // tile takes as long as its slowest visit: one bit per score, then one candidate per lane and round (1.5 per visit;
+    // the index differs between lanes: a ladder of selects); the insert exists once per place. The two lane halves of a
+    // query share its set and take their turns (a wave's LDS operations complete in order). `share`: the int8 scan's
+    // histogram of inserts, or null.
+    template <typename Scores> // float[16] or a 16-float vector
+    __device__ __forceinline__ void candidates(const BruteParams& P, const Scores& sc16, float& tau, uint32_t ql, uint32_t q, uint32_t h,
+                                               uint32_t id0, BfShare* share) const {
+        uint32_t cm = 0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) cm |= (sc16[v] > tau ? 1u : 0u) << v;
+#pragma unroll 1
+        while (__ballot(cm != 0u)) {
+            const bool want = cm != 0u;
+            const uint32_t v = want ? (uint32_t)__builtin_ctz(cm) : 0u;
+            cm &= cm - 1u;
+            float sc = sc16[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) sc = v == (uint32_t)j ? sc16[j] : sc;
+#pragma unroll 1
+            for (uint32_t hh = 0; hh < 2u; ++hh) {
+                if (h == hh && want) {
+                    tau = __builtin_fmaxf(tau, lw[ql]); // (the other half may have put something in)
+                    if (sc > tau) {
+                        uint32_t wpos = lp[ql];
+                        ls[wpos * BF_SET_QT + ql] = sc;
+                        li[wpos * BF_SET_QT + ql] = id0 + 8u * (v >> 2) + 4u * h + (v & 3u);
+                        const float w = worst(ql, wpos);
+                        lw[ql] = w;
+                        lp[ql] = wpos;
+                        tau = __builtin_fmaxf(tau, w);
+                        if (share && share->on()) share->count(P, q, sc);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        tau = __builtin_fmaxf(tau, lw[ql]);
+    }
+    // the set of query ql in order -- an entry's rank among the 16 is its place -- as list (range, q); scores x scale
+    __device__ __forceinline__ void write(const BruteParams& P, uint32_t ql, uint32_t range, uint32_t q, float scale) const {
+        const size_t list = (size_t)range * P.nq + q;
+        float sv[BF_KMAX];
+        uint32_t iv[BF_KMAX];
+#pragma unroll
+        for (int i = 0; i < (int)BF_KMAX; ++i) {
+            sv[i] = ls[(uint32_t)i * BF_SET_QT + ql];
+            iv[i] = li[(uint32_t)i * BF_SET_QT + ql];
+        }
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < (int)BF_KMAX; ++i) {
+            const bool ok = iv[i] != 0xFFFFFFFFu;
+            uint32_t rank = 0; // entries that stand before this one: a larger score, or the same score and a smaller id
+#pragma unroll
+            for (int j = 0; j < (int)BF_KMAX; ++j)
+                rank += (j != i && iv[j] != 0xFFFFFFFFu && (sv[j] > sv[i] || (sv[j] == sv[i] && iv[j] < iv[i]))) ? 1u : 0u;
+            if (ok && rank < P.kk) {
+                P.part_ids[list * P.kk + rank] = (uint64_t)iv[i];
+                const float d = 1.0f - sv[i] * scale;
+                P.part_d[list * P.kk + rank] = d > 0.0f ? d : 0.0f;
+            }
+            cnt += ok ? 1u : 0u;
+        }
+        cnt = cnt < P.kk ? cnt : P.kk;
+        for (uint32_t i = cnt; i < P.kk; ++i) {
+            P.part_ids[list * P.kk + i] = ~0ull;
+            P.part_d[list * P.kk + i] = __builtin_inff();
+        }
+        P.part_c[list] = cnt;
+    }
+};
 
 __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const BruteParams P) {
     extern __shared__ __align__(16) uint8_t smem_bf[];
@@ -816,14 +918,11 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
     bf_i32x4 qr[2][4];
     float qinv[2], tau[2];
     BfShare share[2];
-    // the running top-16 of the block's 512 queries: entry i of query ql at [i][ql], ONE list per query for both lane halves
-    bf_lds_f32 ls = (bf_lds_f32)(smem_bf + NS * TB);
-    bf_lds_u32 li = (bf_lds_u32)(smem_bf + NS * TB + BF_KMAX * BF_RING_QT * 4u);
-    bf_lds_f32 lw = (bf_lds_f32)(smem_bf + NS * TB + BF_KMAX * BF_RING_QT * 8u);       // [ql] the list's worst score ...
-    bf_lds_u32 lp = (bf_lds_u32)(smem_bf + NS * TB + BF_KMAX * BF_RING_QT * 8u + BF_RING_QT * 4u); // ... and where it stands
+    BfSets sets; // the running top-16 of the block's 512 queries
+    sets.at(smem_bf + NS * TB);
     // the tiles' norms, a ring like the rows': per tile 8 x [16 x 1 / |x| of rows 16 w ..][inv_gmax of block w, both lane halves][2 unused]
     constexpr uint32_t NB = 8u * 80u;
-    const uint32_t norms0 = NS * TB + BF_KMAX * BF_RING_QT * 8u + BF_RING_QT * 8u;
+    const uint32_t norms0 = NS * TB + BF_SET_BYTES;
     uint32_t ql[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -831,15 +930,7 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
         q[s] = blk.qt * BF_RING_QT + ql[s];
         qlive[s] = q[s] < P.nq;
         bf_i8_load_query(P, q[s], qlive[s], h, qr[s], qinv[s]);
-        if (h == 0u) {
-#pragma unroll
-            for (int i = 0; i < (int)BF_KMAX; ++i) {
-                ls[(uint32_t)i * BF_RING_QT + ql[s]] = -3.0e38f;
-                li[(uint32_t)i * BF_RING_QT + ql[s]] = 0xFFFFFFFFu;
-            }
-            lw[ql[s]] = -3.0e38f;
-            lp[ql[s]] = 0u;
-        }
+        if (h == 0u) sets.clear(ql[s]);
         tau[s] = bf_start_tau(P, q[s], qlive[s]);
         tau[s] = (tau[s] > -1.0e38f && qinv[s] > 0.0f) ? bf_next_below(tau[s] / qinv[s]) : -3.0e38f;
         share[s].init(P, qlive[s], tau[s]);
@@ -939,12 +1030,10 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
 #pragma unroll
                     for (int v = 0; v < 16; ++v) im = max(im, acc[s][r][v]);
                     if (!__ballot((float)im * gmv > tau[s])) continue;
-                    // One block in fifty comes here -- but a block of eight waves meets at a barrier per tile, and with ~3 of
-                    // these per tile among them the tile takes as long as its slowest wave: this path is written for LATENCY.
+                    // One block in fifty comes here: the float scores of the lane's 16 rows at once (four reads of the norms in
+                    // flight together; a row past the set's end has a NaN there and compares false), then BfSets::candidates.
                     // (A loop over the 16 scores with a norm read, a compare and a branch each: 3,000+ clocks per visit, the
-                    // scan 2.8 ms; without this path 0.5.) The float scores of the lane's 16 rows at once (four reads of the
-                    // norms in flight together; a row past the set's end has a NaN there and compares false), one bit each:
-                    uint32_t cm = 0;
+                    // scan 2.8 ms.)
                     float sc16[16];
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
@@ -955,41 +1044,7 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
                         sc16[g4 * 4 + 2] = (float)acc[s][r][g4 * 4 + 2] * iv.z;
                         sc16[g4 * 4 + 3] = (float)acc[s][r][g4 * 4 + 3] * iv.w;
                     }
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) cm |= (sc16[v] > tau[s] ? 1u : 0u) << v;
-                    // the candidates, one per lane and round (1.5 per visit): the insert exists once per place
-#pragma unroll 1
-                    while (__ballot(cm != 0u)) {
-                        const bool want = cm != 0u;
-                        const uint32_t v = want ? (uint32_t)__builtin_ctz(cm) : 0u;
-                        cm &= cm - 1u;
-                        float sc = sc16[0]; // (the index differs between lanes: a ladder of selects)
-#pragma unroll
-                        for (int j = 1; j < 16; ++j) sc = v == (uint32_t)j ? sc16[j] : sc;
-                        const uint32_t rw = rb * 32u + 8u * (v >> 2) + 4u * h + (v & 3u);
-                        // the list is a SET of 16 (put in order once, at the end): an element takes the place of the worst one,
-                        // the new worst is looked up (16 independent reads, no chain of shifts) and kept beside the list. The
-                        // two lane halves of a query share its list: they take their turns (a wave's LDS operations complete
-                        // in order).
-#pragma unroll 1
-                        for (uint32_t hh = 0; hh < 2u; ++hh) {
-                            if (h == hh && want) {
-                                tau[s] = __builtin_fmaxf(tau[s], lw[ql[s]]); // (the other half may have put something in)
-                                if (sc > tau[s]) {
-                                    uint32_t wpos = lp[ql[s]];
-                                    ls[wpos * BF_RING_QT + ql[s]] = sc;
-                                    li[wpos * BF_RING_QT + ql[s]] = (uint32_t)es + rw;
-                                    const float worst = bf_ring_worst(ls, ql[s], wpos);
-                                    lw[ql[s]] = worst;
-                                    lp[ql[s]] = wpos;
-                                    tau[s] = __builtin_fmaxf(tau[s], worst);
-                                    if (share[s].on()) share[s].count(P, q[s], sc);
-                                }
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                    }
-                    tau[s] = __builtin_fmaxf(tau[s], lw[ql[s]]);
+                    sets.candidates(P, sc16, tau[s], ql[s], q[s], h, (uint32_t)es + rb * 32u, &share[s]);
                 }
             }
         }
@@ -997,39 +1052,8 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
         if (++fslot == NS) fslot = 0;
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        if (qlive[s] && h == 0u) { // the set in order: an entry's rank among the 16 is its place in the list
-            const size_t list = (size_t)blk.range * P.nq + q[s];
-            float sv[BF_KMAX];
-            uint32_t iv[BF_KMAX];
-#pragma unroll
-            for (int i = 0; i < (int)BF_KMAX; ++i) {
-                sv[i] = ls[(uint32_t)i * BF_RING_QT + ql[s]];
-                iv[i] = li[(uint32_t)i * BF_RING_QT + ql[s]];
-            }
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int i = 0; i < (int)BF_KMAX; ++i) {
-                const bool ok = iv[i] != 0xFFFFFFFFu;
-                uint32_t rank = 0; // entries that stand before this one: a larger score, or the same score and a smaller id
-#pragma unroll
-                for (int j = 0; j < (int)BF_KMAX; ++j)
-                    rank += (j != i && iv[j] != 0xFFFFFFFFu && (sv[j] > sv[i] || (sv[j] == sv[i] && iv[j] < iv[i]))) ? 1u : 0u;
-                if (ok && rank < P.kk) {
-                    P.part_ids[list * P.kk + rank] = (uint64_t)iv[i];
-                    const float d = 1.0f - sv[i] * qinv[s];
-                    P.part_d[list * P.kk + rank] = d > 0.0f ? d : 0.0f;
-                }
-                cnt += ok ? 1u : 0u;
-            }
-            cnt = cnt < P.kk ? cnt : P.kk;
-            for (uint32_t i = cnt; i < P.kk; ++i) {
-                P.part_ids[list * P.kk + i] = ~0ull;
-                P.part_d[list * P.kk + i] = __builtin_inff();
-            }
-            P.part_c[list] = cnt;
-        }
-    }
+    for (int s = 0; s < 2; ++s)
+        if (qlive[s] && h == 0u) sets.write(P, ql[s], blk.range, q[s], qinv[s]);
 }
 
 // 1 / |x| of every int8 row (0 for a zero row), once per index: eight lanes per 128-byte row

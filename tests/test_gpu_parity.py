@@ -897,6 +897,8 @@ def test_inline_tails_on_and_off_are_the_same_walk(ga, oracle, dim, max_search):
     by the tails (the dim % 32 last floats, added after the ordered sum: src/math.rs:32-39) of its neighbors' rows. On (the
     default) or off, every list length of the register walker returns the oracle's ids, distance bits and counters; rows
     shorter than 32 ids (and empty ones) read no tail of their own; the option can be flipped on a live index."""
+    if os.environ.get("GRANNE_HIP_INLINE_TAILS") is not None:
+        pytest.skip("GRANNE_HIP_INLINE_TAILS is set: the experiment knob overrides the option this test switches")
     from granne_amd import _lib
     rng = np.random.default_rng(dim * 7 + max_search)
     n, nq = 6000, 96
@@ -929,6 +931,8 @@ def test_inline_tails_on_and_off_are_the_same_walk(ga, oracle, dim, max_search):
 def test_inline_tails_follow_reorder_and_builder_output(ga, oracle):
     """The copy is made whenever an index's layers are final: from host layers, from a GPU builder's get_index, after
     Granne::reorder (ids and elements have moved: the tails must be the NEW neighbors')."""
+    if os.environ.get("GRANNE_HIP_INLINE_TAILS") is not None:
+        pytest.skip("GRANNE_HIP_INLINE_TAILS is set: the experiment knob overrides the option this test reads")
     from granne_amd import _lib
     rng = np.random.default_rng(99)
     n, dim, nq = 5000, 100, 64
@@ -1036,6 +1040,8 @@ def test_revisits_skipped_before_their_rows_are_fetched(ga, oracle, dim):
     rows that name a neighbor twice, with and without the walkers' copy of the layers (100-d / 200-d: the unrolled walkers; 96-d
     / 300-d: the streamed one, whose revisits follow the first new neighbor's row); the evaluations counted lie between
     the oracle's distinct nodes and what the walker without the cache evaluates."""
+    if os.environ.get("GRANNE_HIP_SEEN_MIN") is not None:
+        pytest.skip("GRANNE_HIP_SEEN_MIN is set: the experiment knob overrides the option this test switches")
     from granne_amd import _lib
     rng = np.random.default_rng(900 + dim)
     centers = random_floats(rng, 40, dim)
