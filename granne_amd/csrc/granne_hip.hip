@@ -1789,7 +1789,7 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
             if (plds > 64u * 1024u) HIP_TRY(hipFuncSetAttribute((const void*)fn_prime, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
             hipLaunchKernelGGL(fn_prime, dim3((nq + pqt - 1) / pqt, (uint32_t)Gs), dim3(pthreads), plds, s, Q);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(bf_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, (const float*)P.part_d, (uint32_t)Gs, nq, kk,
+            hipLaunchKernelGGL(bf_tau_kernel, dim3(nq), dim3(64), 0, s, (const float*)P.part_d, (uint32_t)Gs, nq, kk,
                                (float*)(scratch + o_tau));
             HIP_TRY(hipGetLastError());
             P.tau_in = (const float*)(scratch + o_tau);
