@@ -10,3 +10,5 @@ template __global__ void granne_hip::bf_i8_kernel<4, true>(const BruteParams);
 template __global__ void granne_hip::bf_f32_kernel<52, 4, false>(const BruteParams);
 template __global__ void granne_hip::bf_f32_kernel<100, 2, false>(const BruteParams);
 template __global__ void granne_hip::bf_f32_kernel<128, 1, false>(const BruteParams);
+template __global__ void granne_hip::bf_b16_kernel<7, 4, false>(const BruteParams);
+// (bf_i8_ring_kernel is not a template: it is emitted with this file as it is)
