@@ -18,9 +18,12 @@
 //            the reference's arithmetic, bit for bit -- and the k best by (distance, id) are returned. Distances are
 //            therefore the reference's; the id SET can differ from a scalar scan only where two elements' distances to
 //            the query differ by less than the MFMA's rounding (~1e-6) at the k + BF_EXTRA boundary.
-// Roofline: the f32 FORM is MFMA-bound (2 * nq * n * dim flops at 157 TFLOP/s dense f32: 13 ms for 1024 x 10M x 100; 17 ms
-// measured); f32 rows are scored on the bf16 matrix path since round 6 (bf_b16_kernel: 6.6 ms); int8 is HBM-bound.
-// bench.py reports the achieved rate; profiles/ holds the MFMA-busy counter.
+// Roofline: all three forms are bound by the matrix cores -- the f32 form by the f32 matrix rate (2 * nq * n * dim flops at
+// 157 TFLOP/s dense f32: 13 ms for 1024 x 10M x 100; 17 ms measured), the bf16 form (round 6, bf_b16_kernel: 6.6 ms) and the
+// int8 form (bf_i8_ring_kernel: 1.75-2.0 ms; the rows once from HBM are 1.28 GB, 0.2 ms) by what the chip SUSTAINS on them:
+// under dense matrix load it halves its shader clock (tools/mfma_rate.hip), and the scans' inner loops alone take 3.75-5.1 ms
+// and 0.95 ms (tools/mfma_lds_loop*.hip, profiles/r6_scan_matrix_rates.log). bench.py reports the achieved rate against the
+// guide's dense peaks and says so.
 #pragma once
 
 #include "util_kernels.h"
