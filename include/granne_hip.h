@@ -64,7 +64,12 @@ int granne_hip_device_count(int* out_count);
  * (FixedWidthSliceVector<u32>, src/slice_vector/mod.rs:42-45, 344-356). `elements` is the
  * payload of an angular(_int)::Vectors file: row-major [n_elements][dim] scalars
  * (src/slice_vector/mod.rs:213-221). All inputs are host memory and are copied to HBM; the
- * caller may free/unmap them afterwards. n_layers == 0 is a valid (empty) index.           */
+ * caller may free/unmap them afterwards. n_layers == 0 is a valid (empty) index.
+ * Capacity: the reference allows 2^32 - 2 elements per index (src/index/mod.rs:27-28, 420); the
+ * register walkers' list keys carry 31-bit ids, so an index of more than 2^31 elements is walked
+ * by the exact (slower) walker. That is a limit PER INDEX: the shards of a partitioned index
+ * (granne_hip_sharded_*) walk local ids and add their offsets afterwards -- and 2^31 rows of 100
+ * int8 dimensions are 275 GB before their graph, more than one device holds.               */
 int granne_hip_index_create(granne_hip_index** out, const void* elements, uint64_t n_elements,
                             uint32_t dim, int dtype, uint32_t n_layers, const uint64_t* layer_len,
                             const uint32_t* const* layer_rows, const uint32_t* layer_width,
