@@ -154,6 +154,9 @@ def test_append_then_build(ga, oracle):
     (500, 1024, False, 30, 40),   # 4 KB rows: 4 per round
     (600, 3000, True, 30, 40),    # int8 rows of the same length
     (500, 768, False, 40, 60),    # 64-id rows: more selected rows on the stage, 8 per round
+    (400, 1536, False, 30, 40),   # 6 KB rows: too long for the selected-rows stage -- read where they lie (BuildParams::sel_stage = 0)
+    (400, 6000, True, 30, 40),    # int8 rows of the same length
+    (300, 4096, False, 20, 30),   # 16 KB rows, 4 per round
 ])
 def test_long_rows_stage_fewer_candidates_per_round(ga, oracle, n, dim, int8, nn, ms):
     """builder_kernels.h build_chunk_for: the result does not depend on the chunk. Points of low intrinsic dimension so that
@@ -177,7 +180,7 @@ def test_long_rows_stage_fewer_candidates_per_round(ga, oracle, n, dim, int8, nn
 
 
 def test_rows_too_long_for_the_select_stage_are_refused(ga):
-    el = np.ones((64, 1536), np.float32)
+    el = np.ones((64, 9000), np.float32)  # five rows of 36 KB do not fit a CU's LDS (1536-d, refused until round 6, builds now)
     with pytest.raises(ga.GranneHipError, match="dimension too large"):
         ga.GranneBuilder("angular", el, num_neighbors=30).build()
 
