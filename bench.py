@@ -1532,7 +1532,10 @@ def _oracle_match(g):
     g = g or {}
     if "ids_bit_exact" in g:
         return bool(g.get("ids_bit_exact") and g.get("dists_bit_exact"))
-    return bool(g.get("those_shards_bit_exact_on_every_rank") and g.get("merged_equals_numpy_merge_of_ORACLE_shard_results"))
+    merged = g.get("merged_equals_numpy_merge_of_ORACLE_shard_results")
+    if merged is None:  # N > 1 ranks: no rank's oracle holds every shard; the shards' GPU results ARE the oracle's (checked on every rank)
+        merged = g.get("merged_equals_numpy_merge_of_shard_results")
+    return bool(g.get("those_shards_bit_exact_on_every_rank") and merged)
 
 
 def _compact_roofline(r):

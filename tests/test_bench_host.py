@@ -230,6 +230,12 @@ def test_compact_line_reads_both_forms_of_the_parity_record():
     assert not bench._oracle_match(dict(one, dists_bit_exact=False))
     assert not bench._oracle_match(dict(part, merged_equals_numpy_merge_of_ORACLE_shard_results=False))
     assert not bench._oracle_match({})
+    # N > 1 ranks: no rank's oracle holds every shard (the ORACLE merge is not made); every rank's shard equal to the oracle's and
+    # the merged result equal to the numpy merge of the shards' results is the whole evidence there is
+    many = dict(part, merged_equals_numpy_merge_of_ORACLE_shard_results=None)
+    assert bench._oracle_match(many)
+    assert not bench._oracle_match(dict(many, merged_equals_numpy_merge_of_shard_results=False))
+    assert not bench._oracle_match(dict(many, those_shards_bit_exact_on_every_rank=False))
     cb = {"value": 1.0, "unit": "queries/s", "cores": 16, "kind": "port", "sample": "s", "gpu_matches_oracle": part}
     assert bench._compact_cpu(cb)["gpu_matches_oracle"] == {"bit_exact": True, "queries": 4096}
     assert bench._compact_sub({"workload": "w", "value": 1.0, "cpu_baseline": cb})["bit_exact"] is True
