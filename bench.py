@@ -616,8 +616,9 @@ class Bench:
                                "useful_f32_equivalent_tflops": round(2.0 * nq * n * dim / ms / 1e9, 1),
                                "note": "3 * 2 * nq * n * K flops the matrix cores execute (K = dim padded to %d) / wall of the whole "
                                        "operator (HIP events); peak = dense bf16 MFMA (MI355X_MICROARCH.md); round 5 scored on the f32 "
-                                       "matrix path: 17.2 ms = 0.76 of ITS 157.3 TFLOP/s peak; the scan now waits for LDS (every wave reads "
-                                       "the whole element tile) and for the tile's conversion as much as for the matrix cores" % kpad})
+                                       "matrix path: 17.2 ms = 0.76 of ITS 157.3 TFLOP/s peak. Measured beside it (tools/mfma_lds_loop_b16.hip): "
+                                       "the scan's inner loop alone takes 3.75-5.1 ms per 1024 x 10M x 112 -- the chip halves its shader "
+                                       "clock under dense matrix load and sustains 1.3-1.8 PFLOP/s on this loop, not the peak's 2.5" % kpad})
             elif dtype == "f32":
                 flops = 2.0 * nq * n * dim
                 timing.update({"kernel": "bf_f32_kernel (v_mfma_f32_32x32x2_f32) + merge + exact re-ranking", "ms": round(ms, 3),
