@@ -243,18 +243,18 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     // (apply / final_prune only ever see cap + 1 candidates: their arrays keep the minimum size)
     const uint32_t cand_cap = build_cand_cap(max_search);
     // long rows stage fewer candidates per gather round (same results, more rounds): 32 up to 640-d f32, 16 at 768-d
-    uint32_t sel_stage = 1; // the rows select_neighbors has selected stay in LDS -- unless they are too long for that
-    uint32_t chunk = build_chunk_for(lrow, cap, cand_cap, 160u * 1024u, 1u);
+    uint32_t sel_lds = cap; // the rows select_neighbors has selected stay in LDS -- all of them, unless they are too long for that
+    uint32_t chunk = build_chunk_for(lrow, cap, cand_cap, 160u * 1024u);
     if (chunk == 0) {
-        sel_stage = 0;
-        chunk = build_chunk_for(lrow, cap, cand_cap, 160u * 1024u, 0u);
+        sel_lds = build_sel_lds_for(lrow, cap, cand_cap, 160u * 1024u);
+        if (sel_lds >= cap)
+            return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the GPU builder: select_neighbors stages the node's row and at "
+                        "least 4 candidate rows of %u bytes in LDS (%u bytes, a CU has 163840)", lrow,
+                        build_lds_bytes(lrow, cap, cand_cap, 4, 0u));
+        chunk = 4;
     }
-    if (chunk == 0)
-        return fail(GRANNE_HIP_ERR_INVALID, "dimension too large for the GPU builder: select_neighbors stages the node's row and at "
-                    "least 4 candidate rows of %u bytes in LDS (%u bytes, a CU has 163840)", lrow,
-                    build_lds_bytes(lrow, cap, cand_cap, 4, 0u));
-    const uint32_t lds = build_lds_bytes(lrow, cap, cand_cap, chunk, sel_stage);
-    const uint32_t lds_rows = build_lds_bytes_rows(lrow, cap, cand_cap, chunk, sel_stage); // apply / final_prune (<= lds)
+    const uint32_t lds = build_lds_bytes(lrow, cap, cand_cap, chunk, sel_lds);
+    const uint32_t lds_rows = build_lds_bytes_rows(lrow, cap, cand_cap, chunk, sel_lds); // apply / final_prune (<= lds)
     if (lds > 64u * 1024u) {
         HIP_TRY(hipFuncSetAttribute((const void*)K.select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipFuncSetAttribute((const void*)K.apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -303,7 +303,7 @@ static int index_elements_pass(granne_hip_builder* b, uint32_t m_layer, uint32_t
     P.selected = S.selected;
     P.cand_cap = cand_cap;
     P.chunk = chunk;
-    P.sel_stage = sel_stage;
+    P.sel_lds = sel_lds;
     HIP_TRY(hipMemsetAsync(S.selected, 0, layer_len ? layer_len : 1, s)); // nothing is known about the rows of a pass
 
     const bool debug = getenv("GRANNE_HIP_DEBUG") != nullptr;

@@ -62,8 +62,9 @@ struct BuildParams {
     uint32_t cand_cap;             // entries of the candidate arrays in LDS (>= max_search, >= cap + 1; a multiple of 64)
     uint32_t chunk;                // candidate rows staged per gather round: BUILD_CHUNK, or 16 / 8 / 4 when rows are long
                                    // (build_chunk_for); what is computed does not depend on it, only how many rounds it takes
-    uint32_t sel_stage;            // 1: select_neighbors keeps the rows it has selected in LDS; 0 (rows too long for that: beyond
-                                   // ~1150-d f32 at 30 neighbors): it reads them from the elements where they lie (L2 / HBM)
+    uint32_t sel_lds;              // how many of the rows select_neighbors has selected stay in LDS: cap (all of them), or -- rows too
+                                   // long for that, beyond ~1150-d f32 at 30 neighbors -- as many as fit; the others are read from
+                                   // the elements where they lie (L2 / HBM)
 };
 
 // LDS carve-up shared by the three kernels
@@ -85,27 +86,35 @@ __host__ __device__ inline uint32_t build_cand_cap(uint32_t max_search) {
     return c < BUILD_MIN_CAND_CAP ? BUILD_MIN_CAND_CAP : c;
 }
 __host__ __device__ inline uint32_t build_lds_bytes(uint32_t lrow, uint32_t cap, uint32_t cand_cap, uint32_t chunk = BUILD_CHUNK,
-                                                    uint32_t sel_stage = 1u) {
-    if (!sel_stage) return lrow * (1 + chunk) + PAIR_BYTES + cand_cap * 8 + 64 * 4 * 4; // no selected-rows stage
+                                                    uint32_t sel_lds = 0xFFFFFFFFu) {
+    if (sel_lds < cap) return lrow * (1 + chunk + sel_lds) + PAIR_BYTES + cand_cap * 8 + 64 * 4 * 4; // a partial selected-rows stage
     // the pairwise matrix shares the selected-rows stage when that is large enough
     return lrow * (1 + chunk + cap) + (lrow * cap < PAIR_BYTES ? PAIR_BYTES : 0u) + cand_cap * 8 + 64 * 4 * 4;
 }
 // the largest chunk stage with which select_neighbors' LDS fits a CU (0: not even 4 rows do). 100-d f32 rows take
 // the full 32; 768-d f32 rows (3 KB) take 16; the selected-rows stage (cap rows) holds up to about 1150-d f32 / 4600-d int8
-// at 30 neighbors -- longer rows go without it (sel_stage = 0: the selected rows are read where they lie), up to the
-// five rows (the node's + 4 candidates') that must fit: ~8000-d f32
-__host__ __device__ inline uint32_t build_chunk_for(uint32_t lrow, uint32_t cap, uint32_t cand_cap, uint32_t lds_max, uint32_t sel_stage = 1u) {
+// at 30 neighbors -- longer rows stage as many selected rows as fit beside the node's row and 4 candidates' (sel_lds < cap:
+// the others are read where they lie), down to none: ~8000-d f32
+__host__ __device__ inline uint32_t build_chunk_for(uint32_t lrow, uint32_t cap, uint32_t cand_cap, uint32_t lds_max) {
     for (uint32_t c = BUILD_CHUNK; c >= 4u; c >>= 1)
-        if (build_lds_bytes(lrow, cap, cand_cap, c, sel_stage) <= lds_max) return c;
+        if (build_lds_bytes(lrow, cap, cand_cap, c) <= lds_max) return c;
     return 0u;
+}
+// rows too long for the whole stage (build_chunk_for == 0): how many selected rows fit with 4 candidate rows per round
+// (cap: not even none does)
+__host__ __device__ inline uint32_t build_sel_lds_for(uint32_t lrow, uint32_t cap, uint32_t cand_cap, uint32_t lds_max) {
+    if (build_lds_bytes(lrow, cap, cand_cap, 4u, 0u) > lds_max) return cap;
+    uint32_t s = 0;
+    while (s + 1u < cap && build_lds_bytes(lrow, cap, cand_cap, 4u, s + 1u) <= lds_max) ++s;
+    return s;
 }
 // apply_kernel / final_prune_kernel only ever limit a row of at most cap + 1 candidates: while that is one chunk
 // (select_neighbors_pairs) the selected-rows stage is never touched and is left out -- 21 KB instead of 29 KB per
 // wave at 100-d f32, seven waves per CU instead of five
 __host__ __device__ inline bool build_lds_compact(uint32_t cap, uint32_t chunk = BUILD_CHUNK) { return cap + 1u <= chunk; }
 __host__ __device__ inline uint32_t build_lds_bytes_rows(uint32_t lrow, uint32_t cap, uint32_t cand_cap, uint32_t chunk = BUILD_CHUNK,
-                                                         uint32_t sel_stage = 1u) {
-    if (!sel_stage || !build_lds_compact(cap, chunk)) return build_lds_bytes(lrow, cap, cand_cap, chunk, sel_stage);
+                                                         uint32_t sel_lds = 0xFFFFFFFFu) {
+    if (sel_lds < cap || !build_lds_compact(cap, chunk)) return build_lds_bytes(lrow, cap, cand_cap, chunk, sel_lds);
     return lrow * (1 + chunk) + PAIR_BYTES + cand_cap * 8 + 64 * 4 * 4;
 }
 
@@ -123,8 +132,10 @@ struct RowWork {
         L.selrows = L.chunk + (size_t)p.chunk * p.lrow;
         uint8_t* a = L.selrows + (size_t)p.cap * p.lrow;
         L.pair = reinterpret_cast<float*>(L.selrows);
-        if (!p.sel_stage) { // no selected-rows stage: the pairwise matrix stands where it would begin
-            a = L.selrows + PAIR_BYTES;
+        if (p.sel_lds < p.cap) { // a partial selected-rows stage, the pairwise matrix behind it
+            a = L.selrows + (size_t)p.sel_lds * p.lrow;
+            L.pair = reinterpret_cast<float*>(a);
+            a += PAIR_BYTES;
         } else if (rows_only && build_lds_compact(p.cap, p.chunk)) {
             a = L.selrows + PAIR_BYTES;
         } else if (p.lrow * p.cap < PAIR_BYTES) {
@@ -228,12 +239,12 @@ struct RowWork {
                 bool bad = false;
                 if (lane < nsel) { // dist_to_element(n, &element_j): the selected row from its stage, or from the elements
                     float dd;
-                    if (P.sel_stage) dd = dist_lds(L.selrows + (size_t)lane * P.lrow, rj);
+                    if (lane < P.sel_lds) dd = dist_lds(L.selrows + (size_t)lane * P.lrow, rj);
                     else dd = dist_lds(P.elements + (size_t)L.sid[lane] * P.row_stride, rj);
                     bad = !(dj <= dd);
                 }
                 if (wave_ballot(bad) == 0) {
-                    if (P.sel_stage) copy_row(L.selrows + (size_t)nsel * P.lrow, rj);
+                    if (nsel < P.sel_lds) copy_row(L.selrows + (size_t)nsel * P.lrow, rj);
                     if (lane == 0) {
                         L.sid[nsel] = L.cid[j];
                         L.sd[nsel] = dj;
