@@ -606,9 +606,10 @@ class Bench:
             ms = e0.elapsed_time(e1)
             n, dim = (n or len(index)), index.dim
             if dtype == "f32" and os.environ.get("GRANNE_HIP_BF_B16", "1") != "0":
-                kpad = 112 if dim <= 112 else 208 if dim <= 208 else 256
+                kpad = 112 if dim <= 112 else 208 if dim <= 208 else 256 if dim <= 256 else (dim + 127) // 128 * 128
                 flops = 3.0 * 2.0 * nq * n * kpad  # what the matrix cores execute: three bf16 instructions per product, K padded
-                timing.update({"kernel": "bf_b16_kernel (f32 rows as two bf16 pieces each: 3 x v_mfma_f32_32x32x16_bf16 per 16 components) "
+                timing.update({"kernel": ("bf_b16_kernel" if dim <= 256 else "bf_b16_chunked_kernel (the vector in chunks of 128 components)") +
+                                         " (f32 rows as two bf16 pieces each: 3 x v_mfma_f32_32x32x16_bf16 per 16 components) "
                                          "+ merge + exact re-ranking", "ms": round(ms, 3),
                                "value": round(nq / (ms * 1e-3), 1), "value_unit": "queries/s at recall 1.0 (exact scan)",
                                "bound": "mfma", "achieved": round(flops / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",

@@ -498,6 +498,153 @@ __global__ __launch_bounds__(BF_B16_THREADS) void bf_b16_kernel(const BruteParam
     else bf_write_list(P, L, blk.range, q, qlive, h);
 }
 
+// f32 rows of ANY length on the bf16 path (round 6: bf_b16_kernel keeps a lane's half of its query in registers for the
+// whole scan, which ends at 256 dims). Here the vector is walked in chunks of 128 components: the accumulators of a
+// tile of 64 rows stay in registers across the chunks, a chunk of the tile goes HBM -> registers -> LDS as in
+// bf_b16_kernel, and a wave reads its 32 queries' pieces of the chunk again for every tile (from L2: 16 KB per wave and
+// chunk against 12 Mflop of matrix work). Slower per flop than the resident form -- two barriers and a query read per
+// 128 components -- and there for the dims it cannot take (768-d: bench.py's recall ground truth on embeddings).
+template <int R, bool PRIME = false>
+__global__ __launch_bounds__(BF_B16_THREADS) void bf_b16_chunked_kernel(const BruteParams P) {
+    extern __shared__ __align__(16) uint8_t smem_bf[];
+    constexpr int KG = 8;                           // groups of 8 components per lane half and chunk
+    constexpr uint32_t ET = 32u * R;                // elements per tile
+    constexpr uint32_t COMPS = 16u * KG;            // components per chunk
+    constexpr uint32_t STRIDE_B = 2u * COMPS + 16u; // bytes per LDS row of one piece: an odd number of 16-byte units
+    uint8_t* tile_hi = smem_bf;
+    uint8_t* tile_lo = smem_bf + (size_t)ET * STRIDE_B;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t col = lane & 31u, h = lane >> 5;
+    const BfBlock blk = bf_block();
+    const uint32_t q = blk.qt * BF_B16_QT + wave * 32u + col;
+    const bool qlive = q < P.nq;
+    const float* qp = reinterpret_cast<const float*>(P.queries) + (size_t)(qlive ? q : 0u) * P.dim;
+    const uint32_t nchunks = (P.dim + COMPS - 1u) / COMPS;
+    const bool qvec_ok = (P.dim & 3u) == 0u && (reinterpret_cast<uintptr_t>(P.queries) & 15u) == 0u; // every query starts on 16 bytes
+    BfList<PRIME ? 1 : BF_KMAX> L;
+    L.init();
+    float tau = bf_start_tau(P, q, qlive);
+    [[maybe_unused]] float best = -3.0e38f;
+
+    const uint64_t r0 = (uint64_t)blk.range * P.per_range;
+    const uint64_t r1 = r0 + P.per_range < P.n ? r0 + P.per_range : P.n;
+    const uint32_t row_f4 = P.row_bytes / 16u;      // float4 units of a device row that hold data
+    constexpr uint32_t UNITS = COMPS / 4u;          // float4 units per row and chunk
+    constexpr uint32_t NPF = (ET * UNITS + BF_B16_THREADS - 1u) / BF_B16_THREADS;
+    float4 pf[NPF];
+    auto fetch = [&](uint64_t e0, uint32_t c) { // chunk c of the tile at e0
+#pragma unroll
+        for (uint32_t j = 0; j < NPF; ++j) {
+            const uint32_t u = tid + BF_B16_THREADS * j;
+            const uint32_t row = u / UNITS, c4 = c * UNITS + (u - row * UNITS);
+            pf[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (u < ET * UNITS && e0 + row < r1 && c4 < row_f4)
+                pf[j] = *reinterpret_cast<const float4*>(P.elements + (e0 + row) * P.row_stride + (size_t)c4 * 16u);
+        }
+    };
+    if (r0 < r1) fetch(r0, 0);
+    for (uint64_t e0 = r0; e0 < r1; e0 += ET) {
+        bf_f32x16 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][v] = 0.0f;
+#pragma unroll 1
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            __syncthreads(); // the previous chunk has been consumed
+#pragma unroll
+            for (uint32_t j = 0; j < NPF; ++j) { // split into the two pieces on the way to LDS
+                const uint32_t u = tid + BF_B16_THREADS * j;
+                const uint32_t row = u / UNITS, c4 = u - row * UNITS;
+                if (u < ET * UNITS) {
+                    bf_b16x4 hi, lo;
+                    const float v[4] = {pf[j].x, pf[j].y, pf[j].z, pf[j].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        hi[t] = (__bf16)v[t];
+                        lo[t] = (__bf16)(v[t] - (float)hi[t]);
+                    }
+                    *reinterpret_cast<bf_b16x4*>(tile_hi + (size_t)row * STRIDE_B + c4 * 8u) = hi;
+                    *reinterpret_cast<bf_b16x4*>(tile_lo + (size_t)row * STRIDE_B + c4 * 8u) = lo;
+                }
+            }
+            __syncthreads();
+            if (c + 1u < nchunks) fetch(e0, c + 1u);
+            else if (e0 + ET < r1) fetch(e0 + ET, 0);
+            // the lane's half of its query's chunk as bf16 pieces
+            bf_b16x8 qh[KG], ql[KG];
+            const bool q_vec = qvec_ok && (c + 1u) * COMPS <= P.dim; // whole chunk inside the vector, 16-byte aligned: 16 loads instead of 64
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const uint32_t c0 = c * COMPS + h * 8u * KG + (uint32_t)g * 8u;
+                float v8[8];
+                if (q_vec) {
+                    const float4 a = *reinterpret_cast<const float4*>(qp + c0), b = *reinterpret_cast<const float4*>(qp + c0 + 4u);
+                    v8[0] = a.x, v8[1] = a.y, v8[2] = a.z, v8[3] = a.w, v8[4] = b.x, v8[5] = b.y, v8[6] = b.z, v8[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v8[j] = c0 + (uint32_t)j < P.dim ? qp[c0 + (uint32_t)j] : 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = qlive ? v8[j] : 0.0f;
+                    const __bf16 hi = (__bf16)v;
+                    qh[g][j] = hi;
+                    ql[g][j] = (__bf16)(v - (float)hi);
+                }
+            }
+            const size_t off0 = (size_t)col * STRIDE_B + (size_t)h * 16u * KG;
+            constexpr int NF = KG * R;
+            bf_b16x8 ah[2], al[2];
+            ah[0] = *reinterpret_cast<const bf_b16x8*>(tile_hi + off0);
+            al[0] = *reinterpret_cast<const bf_b16x8*>(tile_lo + off0);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int g = i / R, r = i % R;
+                if (i + 1 < NF) {
+                    const int gn = (i + 1) / R, rn = (i + 1) % R;
+                    ah[(i + 1) & 1] = *reinterpret_cast<const bf_b16x8*>(tile_hi + off0 + (size_t)rn * 32u * STRIDE_B + (size_t)gn * 16u);
+                    al[(i + 1) & 1] = *reinterpret_cast<const bf_b16x8*>(tile_lo + off0 + (size_t)rn * 32u * STRIDE_B + (size_t)gn * 16u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], qh[g], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], ql[g], acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], qh[g], acc[r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // result block r: acc[r][v] ~ dot(element e0 + r*32 + 8*(v/4) + 4*h + v%4, query `col` of this wave)
+        const bool whole = e0 + ET <= r1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if constexpr (PRIME) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                    best = (whole || e < r1) ? __builtin_fmaxf(best, acc[r][v]) : best;
+                }
+                continue;
+            }
+            float mx = acc[r][0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) mx = __builtin_fmaxf(mx, acc[r][v]);
+            if (__ballot(mx > tau)) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float sc = acc[r][v];
+                    const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                    if (sc > tau && (whole || e < r1)) {
+                        L.insert(sc, (uint32_t)e);
+                        tau = __builtin_fmaxf(tau, L.worst());
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (PRIME) bf_write_max(P, best, blk.range, q, qlive, h);
+    else bf_write_list(P, L, blk.range, q, qlive, h);
+}
+
 // int8: device rows of up to 128 bytes (dims up to 128; the scan refuses longer rows). K = 32 per MFMA
 // (v_mfma_i32_32x32x32_i8, gfx950): lanes 0-31 carry bytes 0-15 of a 32-byte group, lanes 32-63 bytes 16-31.
 // Score = dot / (|x| |q|) with the exact integer dot.

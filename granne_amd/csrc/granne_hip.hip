@@ -1653,7 +1653,6 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     if (nq == 0) return GRANNE_HIP_OK;
     if (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
     if (k == 0 || k > BF_KMAX) return fail(GRANNE_HIP_ERR_INVALID, "k must be in [1, %u]", BF_KMAX);
-    if (ix->dtype == GRANNE_HIP_F32 && ix->dim > 256) return fail(GRANNE_HIP_ERR_INVALID, "the scan takes f32 rows of up to 256 dimensions");
     if (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes > 128) return fail(GRANNE_HIP_ERR_INVALID, "the scan takes int8 rows of up to 128 dimensions");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
@@ -1691,6 +1690,12 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         fn = bf_b16_kernel<13, 2>;
         fn_prime = bf_b16_kernel<13, 2, true>;
         lds = 2u * 32u * R * (2u * 16u * 13u + 16u);
+        qt = BF_B16_QT, threads = BF_B16_THREADS;
+    } else if (ix->dim > 256) { // rows of any length: the vector in chunks of 128 components (brute_force.h, bf_b16_chunked_kernel)
+        R = 2; // (tiles of 64 rows: 128 take 256 registers and spill)
+        fn = bf_b16_chunked_kernel<2>;
+        fn_prime = bf_b16_chunked_kernel<2, true>;
+        lds = 2u * 32u * R * (2u * 16u * 8u + 16u);
         qt = BF_B16_QT, threads = BF_B16_THREADS;
     } else if (knobs().bf_b16) {
         R = 1;

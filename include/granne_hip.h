@@ -298,13 +298,14 @@ int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, co
 
 /* Exact k nearest elements of every query by a scan of ALL elements on the matrix cores: the many-to-many form of
  * ElementContainer::dists (src/elements/mod.rs:35-39, src/elements/dense_vector.rs:157-163) -- the recall ground truth
- * next to the graph walk, and the one contraction-shaped piece of the element side (v_mfma_f32_32x32x2_f32 /
- * v_mfma_i32_32x32x32_i8; granne_amd/csrc/brute_force.h). Candidates are SELECTED by the MFMA score; the returned
+ * next to the graph walk, and the one contraction-shaped piece of the element side (f32 rows as two bf16 pieces per
+ * component on v_mfma_f32_32x32x16_bf16, int8 rows on v_mfma_i32_32x32x32_i8; granne_amd/csrc/brute_force.h).
+ * Candidates are SELECTED by the MFMA score (f32: to ~4e-5 of a unit-vector dot); the returned
  * distances are recomputed in the reference's arithmetic (bit-exact for the returned ids) and the results are ordered
  * ascending by (distance, id). The id set can differ from a scalar scan only between elements whose distances to the
- * query are within the MFMA's rounding (~1e-6) of each other at the boundary of the selection: min(k + 6, 16)
+ * query are within the score's rounding of each other at the boundary of the selection: min(k + 6, 16)
  * candidates per query are selected and re-ranked, so k <= 10 has six spare candidates, k = 16 none. k <= 16; f32 rows
- * of up to 256 dimensions, int8 rows of up to 128. queries: dense [nq][dim], prepared like the elements (the Python and
+ * of any dimension (beyond 256 the vector is walked in chunks: about half the rate), int8 rows of up to 128. queries: dense [nq][dim], prepared like the elements (the Python and
  * C++ wrappers check the width). Asynchronous on `stream`. */
 int granne_hip_brute_force_device(const granne_hip_index* index, const void* d_queries, uint32_t nq, uint32_t k,
                                   uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, void* stream);
