@@ -628,22 +628,24 @@ class Bench:
                                "frac": round(flops / ms / 1e9 / 157.3, 4), "queries": nq, "elements": n, "dim": dim,
                                "note": "2 * nq * n * dim flops / wall of the whole operator (HIP events); peak = dense f32 MFMA"})
             else:
-                ring = index.dim > 64 and os.environ.get("GRANNE_HIP_BF_RING", "1") != "0"  # 128-byte rows: bf_i8_ring_kernel
+                ring = 64 < index.dim <= 128 and os.environ.get("GRANNE_HIP_BF_RING", "1") != "0"  # 128-byte rows: bf_i8_ring_kernel
+                rowb = 128 if index.dim <= 128 else 256 if index.dim <= 256 else 512 if index.dim <= 512 else (index.dim + 1023) // 1024 * 1024
                 tiles = (nq + 511) // 512 if ring else (nq + 255) // 256
-                byts = float(n) * 128  # the rows ONCE: the query tiles of a range run side by side and share them in L2
-                ops = 2.0 * nq * n * 128  # integer multiply-adds the matrix cores execute (rows of 100 padded to K = 128)
+                byts = float(n) * rowb  # the rows ONCE: the query tiles of a range run side by side and share them in L2
+                ops = 2.0 * nq * n * rowb  # integer multiply-adds the matrix cores execute (rows zero padded to whole 128-byte blocks)
                 timing.update({"kernel": ("bf_i8_ring_kernel (tiles by LDS-DMA into a ring, v_mfma_i32_32x32x32_i8, 64 queries per wave)"
-                                          if ring else "bf_i8_kernel (v_mfma_i32_32x32x32_i8)") + " + merge + exact re-ranking", "ms": round(ms, 3),
+                                          if ring else "bf_i8_chunked_kernel (rows in chunks of 128 bytes, v_mfma_i32_32x32x32_i8)" if index.dim > 128
+                                          else "bf_i8_kernel (v_mfma_i32_32x32x32_i8)") + " + merge + exact re-ranking", "ms": round(ms, 3),
                                "value": round(nq / (ms * 1e-3), 1), "value_unit": "queries/s at recall 1.0 (exact scan)",
                                "bound": "mfma", "achieved": round(ops / ms / 1e9, 1), "peak": 3944.0, "unit": "TOP/s",
                                "frac": round(ops / ms / 1e9 / 3944.0, 4), "queries": nq, "elements": n, "dim": dim,
                                "hbm": {"achieved": round(byts / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                        "frac": round(byts / ms / 1e6 / HBM_PEAK_GBPS, 4)},
-                               "note": "2 * nq * n * 128 operations / wall of the whole operator (HIP events); peak = the guide's dense int8 "
+                               "note": "2 * nq * n * row bytes operations / wall of the whole operator (HIP events); peak = the guide's dense int8 "
                                        "figure (MI355X_MICROARCH.md). Measured beside it (tools/mfma_lds_loop.hip): the scan's inner loop "
                                        "alone on random int8 data sustains 2.7e15 operations/s -- the shader clock drops to 0.9-1.1 GHz "
-                                       "under it -- so ~0.95 ms is this scan's floor at 1024 x 10M whatever its structure; hbm = the n "
-                                       "128-byte rows once (%d query tiles share them in L2)" % tiles})
+                                       "under it -- so ~0.95 ms is this scan's floor at 1024 x 10M x 128 bytes whatever its structure; hbm = the n "
+                                       "rows once (%d query tiles share them in L2)" % tiles})
         self._gt_dists = ds.cpu().numpy()
         return ids.cpu().numpy()
 

@@ -60,6 +60,7 @@ struct BruteParams {
     const float* inv_gmax;   // int8: [ceil(n / 32)][2] the largest 1 / |x| among the 16 rows a lane half sees of a 32-row block (inv_gmax_kernel)
     const float* tau_in;     // [nq] or null: a score that at least kk elements of the set reach (the priming pass's kk-th best)
     uint32_t* share_hist;    // [nq][BF_SHARE_BUCKETS] or null: elements seen so far per score bucket, by ALL ranges (BfShare)
+    const uint8_t* qpad;     // int8 rows of more than 128 bytes: the queries zero padded to row_bytes each, [nq][row_bytes] (bf_i8_chunked_kernel)
 };
 
 // Which (query tile, element range) a block takes. Workgroups go to the 8 XCDs round robin by their linear id, each XCD
@@ -851,6 +852,171 @@ __global__ __launch_bounds__(BF_THREADS) void bf_i8_kernel(const BruteParams P) 
     else bf_write_list(P, L, blk.range, q, qlive, h, qinv);
 }
 
+// int8 rows of MORE than 128 bytes (round 6; bf_i8_kernel and the ring keep a lane's part of its query in registers for the
+// whole scan: 128 bytes). The row is walked in chunks of 128 bytes: the integer accumulators of a tile of 32 R rows stay in
+// registers across the chunks, a chunk of the tile goes HBM -> registers -> LDS as in bf_i8_kernel, and a wave reads its 32
+// queries' 64 bytes per lane of the chunk again for every tile -- from a zero-padded, 16-byte aligned copy of the queries
+// (BruteParams::qpad: [nq][row_bytes], made per call by bf_pad_queries_kernel). Norms, block bounds, shared threshold and
+// lists as in bf_i8_kernel.
+__global__ void bf_pad_queries_kernel(const uint8_t* __restrict__ queries, uint32_t nq, uint32_t dim, uint32_t row_bytes, uint8_t* __restrict__ out) {
+    const uint64_t total = (uint64_t)nq * row_bytes;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t qi = (uint32_t)(t / row_bytes), c = (uint32_t)(t - (uint64_t)qi * row_bytes);
+        out[t] = c < dim ? queries[(size_t)qi * dim + c] : (uint8_t)0;
+    }
+}
+
+template <int R, bool PRIME = false>
+__global__ __launch_bounds__(BF_THREADS) void bf_i8_chunked_kernel(const BruteParams P) {
+    extern __shared__ __align__(16) uint8_t smem_bf[];
+    constexpr uint32_t ET = 32u * R;
+    constexpr uint32_t STRIDE = 128u + 16u; // bytes per LDS row: an odd number of 16-byte units
+    uint8_t* tile = smem_bf;
+    float* inv = reinterpret_cast<float*>(smem_bf + (size_t)ET * STRIDE); // [ET] 1 / |x|
+    float* gm = inv + ET;                                                   // [2][R] inv_gmax of the tile's blocks, by lane half
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t col = lane & 31u, h = lane >> 5;
+    const BfBlock blk = bf_block();
+    const uint32_t q = blk.qt * BF_QT + wave * 32u + col;
+    const bool qlive = q < P.nq;
+    const uint32_t nchunks = P.row_bytes / 128u; // (device rows of more than 128 bytes are whole 128-byte blocks, zero padded)
+    const uint8_t* qrow = P.qpad + (size_t)(qlive ? q : 0u) * P.row_bytes;
+    float qinv = 0.0f;
+    {
+        int dy = 0;
+        for (uint32_t u = h; u < P.row_bytes / 16u; u += 2u) {
+            const uint4 v = *reinterpret_cast<const uint4*>(qrow + (size_t)u * 16u);
+            dy = dot4_i8(v.x, v.x, dy);
+            dy = dot4_i8(v.y, v.y, dy);
+            dy = dot4_i8(v.z, v.z, dy);
+            dy = dot4_i8(v.w, v.w, dy);
+        }
+        dy += __shfl_xor(dy, 32, 64);
+        qinv = (qlive && dy > 0) ? 1.0f / __builtin_sqrtf((float)dy) : 0.0f;
+    }
+    BfList<PRIME ? 1 : BF_KMAX> L; // scores WITHOUT the query's 1 / |q|
+    L.init();
+    [[maybe_unused]] float best = -3.0e38f;
+    float tau = bf_start_tau(P, q, qlive);
+    tau = (tau > -1.0e38f && qinv > 0.0f) ? bf_next_below(tau / qinv) : -3.0e38f;
+    [[maybe_unused]] BfShare share;
+    if constexpr (!PRIME) share.init(P, qlive, tau);
+    const uint64_t r0 = (uint64_t)blk.range * P.per_range;
+    const uint64_t r1 = r0 + P.per_range < P.n ? r0 + P.per_range : P.n;
+    constexpr uint32_t NPF = (ET * 8u + BF_THREADS - 1u) / BF_THREADS;
+    static_assert((ET * 8u) % BF_THREADS == 0u, "every thread carries NPF units of a chunk");
+    uint4 pf[NPF];
+    float pfn[NPF];
+    [[maybe_unused]] float pfg = 0.0f;
+    const uint32_t my_row = tid >> 3, my_c = tid & 7u;
+    auto fetch = [&](uint64_t e0, uint32_t c) {
+        if (c == 0u) {
+            if constexpr (!PRIME) {
+                if (tid < 2u * R) pfg = e0 + 32u * (tid >> 1) < r1 ? P.inv_gmax[((e0 >> 5) + (tid >> 1)) * 2u + (tid & 1u)] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < NPF; ++j) {
+            const uint32_t row = my_row + (BF_THREADS / 8u) * j;
+            pf[j] = make_uint4(0, 0, 0, 0);
+            if (e0 + row < r1) pf[j] = *reinterpret_cast<const uint4*>(P.elements + (e0 + row) * P.row_stride + (size_t)c * 128u + my_c * 16u);
+            if (c == 0u) pfn[j] = (e0 + row < r1 && my_c == 0u) ? P.inv_norm[e0 + row] : 0.0f;
+        }
+    };
+    if (r0 < r1) fetch(r0, 0);
+    for (uint64_t e0 = r0; e0 < r1; e0 += ET) {
+        bf_i32x16 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][v] = 0;
+#pragma unroll 1
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            __syncthreads(); // the previous chunk (and the previous tile's norms) have been consumed
+            if constexpr (!PRIME) {
+                if (c == 0u && P.share_hist) tau = __builtin_fmaxf(tau, share.poll(P, q, h));
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < NPF; ++j) {
+                const uint32_t row = my_row + (BF_THREADS / 8u) * j;
+                *reinterpret_cast<uint4*>(tile + (size_t)row * STRIDE + my_c * 16u) = pf[j];
+                if (c == 0u && my_c == 0u) inv[row] = pfn[j];
+            }
+            if constexpr (!PRIME) {
+                if (c == 0u && tid < 2u * R) gm[(tid & 1u) * R + (tid >> 1)] = pfg;
+            }
+            __syncthreads();
+            if (c + 1u < nchunks) fetch(e0, c + 1u);
+            else if (e0 + ET < r1) fetch(e0 + ET, 0);
+            // the lane's 64 bytes of its query's chunk: bytes 32 g + 16 h .. + 15, g = 0..3
+            bf_i32x4 qr[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const bf_i32x4 v = *reinterpret_cast<const bf_i32x4*>(qrow + (size_t)c * 128u + (uint32_t)g * 32u + h * 16u);
+                qr[g] = qlive ? v : bf_i32x4{0, 0, 0, 0};
+            }
+            bf_i32x4 afrag[2][R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) afrag[0][r] = *reinterpret_cast<const bf_i32x4*>(tile + (size_t)(r * 32 + col) * STRIDE + h * 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        afrag[(g + 1) & 1][r] = *reinterpret_cast<const bf_i32x4*>(tile + (size_t)(r * 32 + col) * STRIDE + (g + 1) * 32 + h * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[g & 1][r], qr[g], acc[r], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const bool whole = e0 + ET <= r1;
+        [[maybe_unused]] float gmv[R];
+        if constexpr (!PRIME) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) gmv[r] = gm[h * R + r];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if constexpr (!PRIME) {
+                int im = 0;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) im = max(im, acc[r][v]);
+                if (!__ballot((float)im * gmv[r] > tau)) continue;
+            }
+            float sc[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 iv = *reinterpret_cast<const float4*>(inv + r * 32 + 8 * g4 + 4 * h);
+                sc[g4 * 4 + 0] = (float)acc[r][g4 * 4 + 0] * iv.x;
+                sc[g4 * 4 + 1] = (float)acc[r][g4 * 4 + 1] * iv.y;
+                sc[g4 * 4 + 2] = (float)acc[r][g4 * 4 + 2] * iv.z;
+                sc[g4 * 4 + 3] = (float)acc[r][g4 * 4 + 3] * iv.w;
+            }
+            if constexpr (PRIME) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                    best = (whole || e < r1) ? __builtin_fmaxf(best, sc[v]) : best;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const uint64_t e = e0 + (uint32_t)(r * 32 + 8 * (v / 4) + v % 4) + 4u * h;
+                if (sc[v] > tau && (whole || e < r1)) {
+                    L.insert(sc[v], (uint32_t)e);
+                    tau = __builtin_fmaxf(tau, L.worst());
+                    if (share.on()) share.count(P, q, sc[v]);
+                }
+            }
+        }
+    }
+    if constexpr (PRIME) bf_write_max(P, best * qinv, blk.range, q, qlive, h);
+    else bf_write_list(P, L, blk.range, q, qlive, h, qinv);
+}
+
 // ---- int8 rows of 128 bytes: the tiles travel HBM -> LDS by LDS-DMA into a ring, two query sets per wave (round 6) ----
 // What bounded bf_i8_kernel (profiles/r5_bruteforce_i8_*): a stage's rows went HBM -> registers -> LDS between two
 // barriers, with ONE stage in flight per block -- the staging alone took 1.1 ms of the 2.6 ms scan, the matrix work 0.6, and
@@ -1210,12 +1376,15 @@ __global__ __launch_bounds__(BF_RING_THREADS) void bf_i8_ring_kernel(const Brute
 __global__ void inv_norm_rows_kernel(const uint8_t* __restrict__ elements, uint64_t n, uint32_t row_bytes, float* __restrict__ out) {
     const uint32_t c = threadIdx.x & 7u, units = row_bytes / 16u;
     for (uint64_t row = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3; row < ((n + 31u) & ~31ull); row += ((uint64_t)gridDim.x * blockDim.x) >> 3) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < n && c < units) v = *reinterpret_cast<const uint4*>(elements + row * row_bytes + c * 16u);
-        int dx = dot4_i8(v.x, v.x, 0);
-        dx = dot4_i8(v.y, v.y, dx);
-        dx = dot4_i8(v.z, v.z, dx);
-        dx = dot4_i8(v.w, v.w, dx);
+        int dx = 0;
+        for (uint32_t u = c; u < units; u += 8u) { // (rows of more than 128 bytes: every lane takes every eighth unit)
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < n) v = *reinterpret_cast<const uint4*>(elements + row * row_bytes + (size_t)u * 16u);
+            dx = dot4_i8(v.x, v.x, dx);
+            dx = dot4_i8(v.y, v.y, dx);
+            dx = dot4_i8(v.z, v.z, dx);
+            dx = dot4_i8(v.w, v.w, dx);
+        }
         dx += __shfl_xor(dx, 1, 64);
         dx += __shfl_xor(dx, 2, 64);
         dx += __shfl_xor(dx, 4, 64);

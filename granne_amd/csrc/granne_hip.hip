@@ -343,7 +343,7 @@ static int make_inline_tails(granne_hip_index* ix, hipStream_t s) {
 // here, when the index is made (and again after reorder), on the creating stream -- a scan never allocates, never
 // synchronises its caller's stream and can be captured (round 5 made them lazily inside the first scan, under norm_mu).
 static int make_scan_norms(granne_hip_index* ix, hipStream_t s) {
-    if (ix->dtype != GRANNE_HIP_I8 || ix->row_bytes > 128 || ix->n_elements == 0) return GRANNE_HIP_OK;
+    if (ix->dtype != GRANNE_HIP_I8 || ix->n_elements == 0) return GRANNE_HIP_OK;
     std::lock_guard<std::mutex> lk(ix->norm_mu);
     if (ix->d_inv_norm) return GRANNE_HIP_OK;
     const uint64_t n = ix->n_elements, n_pad = (n + 31u) & ~31ull;
@@ -1653,7 +1653,6 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     if (nq == 0) return GRANNE_HIP_OK;
     if (!d_queries || !d_out_ids || !d_out_dists || !d_out_counts) return fail(GRANNE_HIP_ERR_INVALID, "null buffer");
     if (k == 0 || k > BF_KMAX) return fail(GRANNE_HIP_ERR_INVALID, "k must be in [1, %u]", BF_KMAX);
-    if (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes > 128) return fail(GRANNE_HIP_ERR_INVALID, "the scan takes int8 rows of up to 128 dimensions");
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(GRANNE_HIP_ERR_NO_DEVICE, "cannot select HIP device %d", ix->device);
     hipStream_t s = (hipStream_t)stream;
@@ -1670,7 +1669,11 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
         fn = bf_i8_kernel<4>;
         fn_prime = bf_i8_kernel<4, true>;
         lds = BF_I8_SUB * (32u * R * (128u + 16u) + 32u * R * 4u + 2u * R * 4u);
-        if (knobs().bf_ring && ix->row_bytes == 128u && ix->row_stride == 128u && n < (1ull << 29)) {
+        if (ix->row_bytes > 128u) { // rows of any length: in chunks of 128 bytes (brute_force.h, bf_i8_chunked_kernel)
+            fn = bf_i8_chunked_kernel<4>;
+            fn_prime = bf_i8_chunked_kernel<4, true>;
+            lds = 32u * R * (128u + 16u) + 32u * R * 4u + 2u * R * 4u;
+        } else if (knobs().bf_ring && ix->row_bytes == 128u && ix->row_stride == 128u && n < (1ull << 29)) {
             // tiles by LDS-DMA into a ring, 64 queries per wave (brute_force.h, bf_i8_ring_kernel); the priming pass stays
             prime_lds = lds, prime_qt = qt, prime_threads = threads;
             fn = bf_i8_ring_kernel;
@@ -1733,7 +1736,9 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     const size_t o_tau = (o_ex + (size_t)nq * kk * 4 + 15) & ~(size_t)15;
     const size_t o_share = (o_tau + (size_t)nq * 4 + 15) & ~(size_t)15; // what the ranges of a query have seen, per score bucket
     const size_t share_bytes = (size_t)nq * BF_SHARE_BUCKETS * 4;
-    const size_t total = o_share + share_bytes;
+    const size_t o_qpad = (o_share + share_bytes + 15) & ~(size_t)15; // int8 rows of more than 128 bytes: the queries, zero padded
+    const size_t qpad_bytes = (ix->dtype == GRANNE_HIP_I8 && ix->row_bytes > 128u) ? (size_t)nq * ix->row_bytes : 0;
+    const size_t total = o_qpad + qpad_bytes;
     uint8_t* scratch = nullptr;
     HIP_TRY(hipMallocAsync((void**)&scratch, total, s));
     struct Release {
@@ -1778,6 +1783,13 @@ extern "C" int granne_hip_brute_force_device(const granne_hip_index* ix, const v
     if (lds > 64u * 1024u) HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     P.tau_in = nullptr;
     P.share_hist = nullptr;
+    P.qpad = nullptr;
+    if (qpad_bytes) {
+        hipLaunchKernelGGL(bf_pad_queries_kernel, dim3(grid_for(qpad_bytes, 256)), dim3(256), 0, s, (const uint8_t*)d_queries, nq, ix->dim,
+                           ix->row_bytes, scratch + o_qpad);
+        HIP_TRY(hipGetLastError());
+        P.qpad = scratch + o_qpad;
+    }
     uint64_t zeros[64];
     memset(zeros, 0, sizeof(zeros)); // the lists hold global ids already
     if (G >= 32) {

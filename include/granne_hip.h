@@ -305,7 +305,8 @@ int granne_hip_merge_topk_device(const uint64_t* d_ids, const float* d_dists, co
  * ascending by (distance, id). The id set can differ from a scalar scan only between elements whose distances to the
  * query are within the score's rounding of each other at the boundary of the selection: min(k + 6, 16)
  * candidates per query are selected and re-ranked, so k <= 10 has six spare candidates, k = 16 none. k <= 16; f32 rows
- * of any dimension (beyond 256 the vector is walked in chunks: about half the rate), int8 rows of up to 128. queries: dense [nq][dim], prepared like the elements (the Python and
+ * and int8 rows of any dimension (f32 beyond 256 dims and int8 beyond 128 are walked in chunks of 128 components /
+ * bytes, at about half the rate per operation). queries: dense [nq][dim], prepared like the elements (the Python and
  * C++ wrappers check the width). Asynchronous on `stream`. */
 int granne_hip_brute_force_device(const granne_hip_index* index, const void* d_queries, uint32_t nq, uint32_t k,
                                   uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, void* stream);

@@ -27,6 +27,7 @@ def exact_topk(oracle, el, q, k):
 
 @pytest.mark.parametrize("int8,dim,n", [(False, 100, 5000), (False, 200, 3000), (False, 32, 700), (False, 256, 900), (False, 3, 300),
                                         (False, 300, 1300), (False, 768, 900), (False, 1000, 333),  # rows beyond 256 dims: the vector in chunks
+                                        (True, 200, 2000), (True, 300, 1500), (True, 1000, 500), (True, 129, 700),  # int8 rows beyond 128 bytes
                                         (True, 100, 5000), (True, 128, 1500), (True, 17, 400)])
 def test_brute_force_matches_a_scalar_scan(oracle, int8, dim, n):
     import granne_amd
@@ -61,7 +62,8 @@ def test_brute_force_matches_a_scalar_scan(oracle, int8, dim, n):
                                            # 128-byte int8 rows (the LDS-DMA ring, brute_force.h bf_i8_ring_kernel): four query tiles
                                            # of 512 and 64 ranges; one tile and 128 ranges merged in two steps; a last tile of 33 rows
                                            (True, 128, 70_049, 1600), (True, 100, 150_000, 513),
-                                           (False, 384, 60_000, 300)])  # f32 rows beyond 256 dims, with the priming pass
+                                           (False, 384, 60_000, 300),   # f32 rows beyond 256 dims, with the priming pass
+                                           (True, 256, 100_000, 300)])  # int8 rows beyond 128 bytes, priming + shared threshold
 def test_primed_scan_with_the_shared_threshold_matches_the_scalar_scan(oracle, int8, dim, n, nq):
     """Sets large enough for the priming pass and the per-query threshold that the ranges share (brute_force.h, BfShare):
     the result is the oracle's scan whatever order the ranges publish in -- run twice, identical."""
@@ -121,9 +123,8 @@ def test_brute_force_small_and_ragged(oracle):
         assert sorted(ids[qi, :9].tolist()) == list(range(9))
         keys = list(zip(ds[qi, :9].tolist(), ids[qi, :9].tolist()))
         assert keys == sorted(keys)
-    big = granne_amd.Granne("angular_int", oracle.quantize(random_floats(rng, 10, 300)), [])  # int8 rows of more than 128 bytes
     with pytest.raises(GranneHipError):
-        big.brute_force(oracle.quantize(random_floats(rng, 2, 300)), 5)
+        ix8.brute_force(q8, 0)
 
 
 def test_brute_force_is_the_recall_ground_truth_of_a_walk(oracle):
